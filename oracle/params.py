@@ -1,0 +1,136 @@
+"""Deterministic build-side weights for the oracle, the golden fixtures and the tests.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Key names and shapes are exactly those of the reference modules' state_dict()
+(lib/models/networks.py:216-324 UnetGenerator, :331-363 PatchGANDiscriminator), so the
+same dict can be fed to the reference via load_state_dict (done in
+tests/golden/make_golden.py) and to the HIP backend.
+
+Values come from numpy's PCG64 stream so they are bit-identical on every machine;
+bounds follow PyTorch's default conv init (kaiming_uniform a=sqrt(5) => U(-1/sqrt(fan_in), +)),
+BatchNorm affine/running stats are randomised so that every term of the
+normalisation is exercised.
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+
+def unet_channels(num_downs, ngf, in_c=1, out_c=1):
+    """Return per-level (1-based) conv/upconv channel tuples.
+
+    level k conv:   cin_k -> ch_k           (networks.py:285)
+    level k upconv: (2*ch_k or ch_k innermost) -> cout_k   (networks.py:293-309)
+    """
+    ch = [None]
+    for k in range(1, num_downs + 1):
+        ch.append(ngf * min(2 ** (k - 1), 8))
+    levels = []
+    for k in range(1, num_downs + 1):
+        cin = in_c if k == 1 else ch[k - 1]
+        up_in = ch[k] if k == num_downs else 2 * ch[k]
+        up_out = out_c if k == 1 else ch[k - 1]
+        levels.append(dict(k=k, cin=cin, ch=ch[k], up_in=up_in, up_out=up_out))
+    return levels
+
+
+def unet_key_layout(num_downs):
+    """state_dict key prefixes of every level, mirroring the recursive nesting of
+    UnetSkipConnectionBlock (networks.py:296-318)."""
+    out = []
+    prefix = "model.model"
+    for k in range(1, num_downs + 1):
+        if k == 1:  # outermost: [downconv, sub, uprelu, upconv, tanh]
+            d = dict(down=f"{prefix}.0", sub=f"{prefix}.1", up=f"{prefix}.3", dnorm=None, unorm=None)
+        elif k == num_downs:  # innermost: [downrelu, downconv, uprelu, upconv, upnorm]
+            d = dict(down=f"{prefix}.1", sub=None, up=f"{prefix}.3", dnorm=None, unorm=f"{prefix}.4")
+        else:  # middle: [downrelu, downconv, downnorm, sub, uprelu, upconv, upnorm(, dropout)]
+            d = dict(down=f"{prefix}.1", sub=f"{prefix}.3", up=f"{prefix}.5", dnorm=f"{prefix}.2",
+                     unorm=f"{prefix}.6")
+        out.append(d)
+        if d["sub"] is not None:
+            prefix = d["sub"] + ".model"
+    return out
+
+
+def dropout_levels(num_downs):
+    """Levels whose up path ends in Dropout(0.5): the `num_downs-5` ngf*8 blocks
+    (networks.py:237-238; use_dropout='False' is a truthy string, networks.py:18-19)."""
+    return list(range(5, num_downs))
+
+
+def _uniform(rng, shape, bound):
+    return ((rng.random(size=shape, dtype=np.float32) * 2.0 - 1.0) * np.float32(bound)).astype(np.float32)
+
+
+def _bn(rng, P, prefix, c):
+    P[f"{prefix}.weight"] = (0.5 + rng.random(size=(c,), dtype=np.float32)).astype(np.float32)
+    P[f"{prefix}.bias"] = _uniform(rng, (c,), 0.2)
+    P[f"{prefix}.running_mean"] = _uniform(rng, (c,), 0.1)
+    P[f"{prefix}.running_var"] = (0.5 + rng.random(size=(c,), dtype=np.float32)).astype(np.float32)
+    P[f"{prefix}.num_batches_tracked"] = np.array(0, dtype=np.int64)
+
+
+def make_unet_params(seed, num_downs=7, ngf=64, in_c=1, out_c=1):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P = OrderedDict()
+    levels = unet_channels(num_downs, ngf, in_c, out_c)
+    keys = unet_key_layout(num_downs)
+
+    def emit(k):
+        lv, ky = levels[k - 1], keys[k - 1]
+        P[f"{ky['down']}.weight"] = _uniform(rng, (lv["ch"], lv["cin"], 4, 4), 1.0 / np.sqrt(lv["cin"] * 16))
+        if ky["dnorm"]:
+            _bn(rng, P, ky["dnorm"], lv["ch"])
+        if k < num_downs:
+            emit(k + 1)
+        # ConvTranspose2d weight is [in, out, kh, kw]; torch takes fan_in from dim 1
+        P[f"{ky['up']}.weight"] = _uniform(rng, (lv["up_in"], lv["up_out"], 4, 4), 1.0 / np.sqrt(lv["up_out"] * 16))
+        if k == 1:
+            P[f"{ky['up']}.bias"] = _uniform(rng, (lv["up_out"],), 1.0 / np.sqrt(lv["up_out"] * 16))
+        if ky["unorm"]:
+            _bn(rng, P, ky["unorm"], lv["up_out"])
+
+    emit(1)
+    return P
+
+
+def patchgan_head_features(H, W):
+    """Generalised head: reference hard-codes Linear(25,1) (networks.py:354), valid for 128x128."""
+    return (H // 16 - 3) * (W // 16 - 3)
+
+
+def make_patchgan_params(seed, H=128, W=128, in_c=1, nf=64):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P = OrderedDict()
+    chans = [in_c, nf, nf * 2, nf * 4, nf * 8]
+    conv_idx = [0, 2, 5, 8]
+    bn_idx = [None, 3, 6, 9]
+    for i in range(4):
+        P[f"model.{conv_idx[i]}.weight"] = _uniform(rng, (chans[i + 1], chans[i], 4, 4), 1.0 / np.sqrt(chans[i] * 16))
+        if bn_idx[i] is not None:
+            _bn(rng, P, f"model.{bn_idx[i]}", chans[i + 1])
+    P["model.11.weight"] = _uniform(rng, (1, chans[4], 4, 4), 1.0 / np.sqrt(chans[4] * 16))
+    F = patchgan_head_features(H, W)
+    P["model.13.weight"] = _uniform(rng, (1, F), 1.0 / np.sqrt(F))
+    P["model.13.bias"] = _uniform(rng, (1,), 1.0 / np.sqrt(F))
+    return P
+
+
+def synth_batch(seed, N, H, W, fractional_edge=False):
+    """Synthetic masked-image batch: ground ~ U[0,1), one axis-aligned
+    rectangle of ones per image with h,w in [H/8, H/2]."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ground = rng.random(size=(N, 1, H, W), dtype=np.float32)
+    mask = np.zeros((N, 1, H, W), dtype=np.float32)
+    for n in range(N):
+        h = int(rng.integers(H // 8, H // 2 + 1))
+        w = int(rng.integers(W // 8, W // 2 + 1))
+        y0 = int(rng.integers(0, H - h + 1))
+        x0 = int(rng.integers(0, W - w + 1))
+        mask[n, 0, y0:y0 + h, x0:x0 + w] = 1.0
+        if fractional_edge:  # values in (0,1) on the border, to exercise ceil()
+            mask[n, 0, y0, x0:x0 + w] = 0.25
+            mask[n, 0, y0:y0 + h, x0] = 0.5
+    return ground, mask

@@ -1,0 +1,343 @@
+"""Functional CPU restatement of the reference hot path on torch-CPU primitives.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py). fp32 (or fp64 on request), NCHW,
+torch.nn.functional ops + autograd for the backward passes.
+
+Every function cites the reference lines it follows (paths under the upstream repo).
+Pinned against the imported reference by tests/golden (tests/test_oracle_golden.py).
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import params as _p
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def to_torch(P, dtype=torch.float32, requires_grad=True):
+    """numpy state dict -> torch leaf tensors (float params require grad, buffers do not)."""
+    out = OrderedDict()
+    for k, v in P.items():
+        t = torch.from_numpy(np.array(v))
+        if k.endswith("num_batches_tracked"):
+            out[k] = t.clone()
+            continue
+        t = t.to(dtype).clone()
+        if requires_grad and not (k.endswith("running_mean") or k.endswith("running_var")):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def named_parameter_keys(P):
+    """Keys that nn.Module.named_parameters() would yield, in order."""
+    return [k for k in P if not (k.endswith("running_mean") or k.endswith("running_var")
+                                 or k.endswith("num_batches_tracked"))]
+
+
+def _bn(P, prefix, x, train):
+    # nn.BatchNorm2d(affine=True, track_running_stats=True): networks.py:38, :288-290, :341
+    if train:
+        P[prefix + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, P[prefix + ".running_mean"], P[prefix + ".running_var"],
+                        P[prefix + ".weight"], P[prefix + ".bias"], train, BN_MOMENTUM, BN_EPS)
+
+
+def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None):
+    """UnetGenerator.forward (networks.py:246-253) through the recursive
+    UnetSkipConnectionBlock.forward (networks.py:320-324), unrolled.
+
+    Quirks reproduced:
+      * downrelu is LeakyReLU(0.2, inplace=True) applied to the block input, so the tensor that
+        is concatenated as the skip is leaky_relu(x), not x (networks.py:287, :324);
+      * uprelu (in place) then acts on the whole concat (networks.py:289);
+      * use_dropout='False' is truthy: Dropout(0.5) after upnorm of levels 5..num_downs-1
+        (networks.py:18-19, :313-314).
+    dropout_masks: {level: keep-mask tensor (N,C,H,W) of 0/1}; required in train mode for
+    those levels (the oracle never draws its own random numbers).
+    """
+    keys = _p.unet_key_layout(num_downs)
+    drops = _p.dropout_levels(num_downs)
+    skips = {}
+    h = F.conv2d(x, P[keys[0]["down"] + ".weight"], None, stride=2, padding=1)
+    for k in range(2, num_downs + 1):
+        s = F.leaky_relu(h, 0.2)
+        skips[k - 1] = s
+        h = F.conv2d(s, P[keys[k - 1]["down"] + ".weight"], None, stride=2, padding=1)
+        if keys[k - 1]["dnorm"]:
+            h = _bn(P, keys[k - 1]["dnorm"], h, train)
+    u = h
+    for k in range(num_downs, 0, -1):
+        inp = F.relu(u) if k == num_downs else F.relu(torch.cat([skips[k], u], 1))
+        bias = P.get(keys[k - 1]["up"] + ".bias")
+        u = F.conv_transpose2d(inp, P[keys[k - 1]["up"] + ".weight"], bias, stride=2, padding=1)
+        if keys[k - 1]["unorm"]:
+            u = _bn(P, keys[k - 1]["unorm"], u, train)
+        if train and k in drops:
+            u = u * dropout_masks[k].to(u.dtype) * 2.0
+    return torch.tanh(u)
+
+
+def patchgan_forward(P, x, sigmoid=True, train=True):
+    """PatchGANDiscriminator.forward (networks.py:335-363); Linear(25,1) generalised to
+    Linear((H/16-3)*(W/16-3),1) for sizes other than 128x128."""
+    h = F.leaky_relu(F.conv2d(x, P["model.0.weight"], None, stride=2, padding=1), 0.2)
+    for conv, bn in ((2, 3), (5, 6), (8, 9)):
+        h = F.conv2d(h, P[f"model.{conv}.weight"], None, stride=2, padding=1)
+        h = F.leaky_relu(_bn(P, f"model.{bn}", h, train), 0.2)
+    h = F.conv2d(h, P["model.11.weight"], None, stride=1, padding=0)
+    h = h.reshape(h.shape[0], -1)
+    h = F.linear(h, P["model.13.weight"], P["model.13.bias"])
+    if sigmoid:
+        h = torch.sigmoid(h)
+    return h.view(-1, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# mask pipeline and losses
+# ---------------------------------------------------------------------------------------------
+
+def mask_pipeline(ground, mask, ceil=True):
+    """experiment_list/minimaxgan_l1.py:114-117: mask=ceil(mask); masked = ground*(1-mask)."""
+    m = torch.ceil(mask) if ceil else mask
+    return m, ground * (1 - m)
+
+
+def composite(masked, gen_out, mask):
+    """minimaxgan_l1.py:122: inpainted = masked + inpainted*mask."""
+    return masked + gen_out * mask
+
+
+def l1_loss(a, b):
+    return torch.mean(torch.abs(a - b))  # nn.L1Loss, minimaxgan_l1.py:62,166
+
+
+def rmse_loss(yhat, y, eps=1e-16):
+    return torch.sqrt(torch.mean((yhat - y) ** 2) + eps)  # lib/models/loss.py:11-19
+
+
+def local_loss(yhat, y, mask, base="l1"):
+    """lib/models/loss.py:24-47 as literally coded: sum(base(y*m, yhat*m)) / count(m != 0);
+    the sqrt branch never fires because self.loss is never an RMSELoss instance (:30-31,:44).
+    base='rmse' is the evident intent (sqrt of the masked mean square + eps), kept as a
+    labelled extension."""
+    d = y * mask - yhat * mask
+    cnt = (mask != 0).to(d.dtype).sum()
+    if base == "l1":
+        return torch.abs(d).sum() / cnt
+    if base == "mse":
+        return (d * d).sum() / cnt
+    if base == "rmse":
+        return torch.sqrt((d * d).sum() / cnt + 1e-16)
+    raise ValueError(base)
+
+
+def bce_loss(p, target):
+    """nn.BCELoss (minimaxgan_l1.py:61,135,141,162): log terms clamped at -100."""
+    lp = torch.clamp(torch.log(p), min=-100.0)
+    l1p = torch.clamp(torch.log(1 - p), min=-100.0)
+    return -(target * lp + (1 - target) * l1p).mean()
+
+
+def mse_loss(p, target):
+    return torch.mean((p - target) ** 2)  # LSGAN, experiment1_global_local_D.py:119,162
+
+
+def gradient_penalty(PD, real, fake, eps, lam=10.0, sigmoid=False):
+    """WGAN-GP extension (NOT in the reference): lam*E[(||grad_x D(x_hat)||_2-1)^2],
+    x_hat = eps*real + (1-eps)*fake, eps (N,1,1,1)."""
+    xhat = (eps * real + (1 - eps) * fake).detach().requires_grad_(True)
+    d = patchgan_forward(PD, xhat, sigmoid=sigmoid, train=True)
+    (g,) = torch.autograd.grad(d.sum(), xhat, create_graph=True)
+    norm = g.reshape(g.shape[0], -1).norm(2, dim=1)
+    return lam * ((norm - 1) ** 2).mean()
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizers (same update rules as the torch built-ins the plugins call)
+# ---------------------------------------------------------------------------------------------
+
+class Adam:
+    """torch.optim.Adam(lr=2e-4, betas=(0.5,0.999), eps=1e-8): minimaxgan_l1.py:64-65."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
+        self.params, self.lr, self.b1, self.b2, self.eps = list(params), lr, betas[0], betas[1], eps
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.t = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        bc1 = 1 - self.b1 ** self.t
+        bc2 = 1 - self.b2 ** self.t
+        for p, m, v in zip(self.params, self.m, self.v):
+            if p.grad is None:
+                continue
+            g = p.grad
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            denom = (v.sqrt() / math.sqrt(bc2)).add_(self.eps)
+            p.addcdiv_(m, denom, value=-self.lr / bc1)
+
+
+class RMSprop:
+    """torch.optim.RMSprop(lr=5e-5) defaults alpha=0.99, eps=1e-8: wgan_l1.py:64-65."""
+
+    def __init__(self, params, lr=5e-5, alpha=0.99, eps=1e-8):
+        self.params, self.lr, self.alpha, self.eps = list(params), lr, alpha, eps
+        self.sq = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        for p, sq in zip(self.params, self.sq):
+            if p.grad is None:
+                continue
+            g = p.grad
+            sq.mul_(self.alpha).addcmul_(g, g, value=1 - self.alpha)
+            p.addcdiv_(g, sq.sqrt().add_(self.eps), value=-self.lr)
+
+
+def clamp_params(params, lo=-0.01, hi=0.01):
+    """wgan_l1.py:151-153: every D parameter (BN affine and Linear included)."""
+    with torch.no_grad():
+        for p in params:
+            p.clamp_(lo, hi)
+
+
+def trainable(P):
+    return [P[k] for k in named_parameter_keys(P)]
+
+
+def set_requires_grad(P, flag):
+    """lib/models/util.py:19-22."""
+    for k in named_parameter_keys(P):
+        P[k].requires_grad_(flag)
+
+
+def grad_absmean(P):
+    """minimaxgan_l1.py:180-182: mean(|grad|) of every parameter whose name has no 'bias'."""
+    return OrderedDict((k, float(P[k].grad.abs().mean())) for k in named_parameter_keys(P)
+                       if "bias" not in k and P[k].grad is not None)
+
+
+# ---------------------------------------------------------------------------------------------
+# step sequences (re-typed from the plugin sources, read as text)
+# ---------------------------------------------------------------------------------------------
+
+def minimax_step(PG, PD, optG, optD, ground, mask, num_downs, dropout_masks, recon="l1"):
+    """One batch of experiment_list/minimaxgan_l1.py:110-173 (recon='rmse': minimaxgan_rmse.py)."""
+    m, masked = mask_pipeline(ground, mask)
+    inpainted = composite(masked, unet_forward(PG, masked, num_downs, True, dropout_masks), m)
+    set_requires_grad(PD, True)
+    optD.zero_grad()
+    n = ground.shape[0]
+    d_real = patchgan_forward(PD, ground, True, True).view(-1)
+    d_loss_real = bce_loss(d_real, torch.ones(n, dtype=d_real.dtype))
+    d_loss_real.backward()
+    d_fake = patchgan_forward(PD, inpainted.detach(), True, True).view(-1)
+    d_loss_fake = bce_loss(d_fake, torch.zeros(n, dtype=d_real.dtype))
+    d_loss_fake.backward()
+    d_grad_stats = grad_absmean(PD)
+    optD.step()
+    set_requires_grad(PD, False)
+    optG.zero_grad()
+    d_fake2 = patchgan_forward(PD, inpainted, True, True).view(-1)
+    g_adv = bce_loss(d_fake2, torch.ones(n, dtype=d_real.dtype))
+    rec = l1_loss(ground, inpainted) if recon == "l1" else rmse_loss(ground, inpainted)
+    g_loss = g_adv + rec
+    g_loss.backward()
+    g_grad_stats = grad_absmean(PG)
+    optG.step()
+    return dict(d_loss_real=float(d_loss_real.detach()), d_loss_fake=float(d_loss_fake.detach()), g_adv=float(g_adv.detach()),
+                recon=float(rec.detach()), g_loss=float(g_loss.detach()), inpainted=inpainted.detach(),
+                g_grad_absmean=g_grad_stats, d_grad_absmean=d_grad_stats)
+
+
+def wgan_step(PG, PD, optG, optD, ground, mask, num_downs, dropout_masks, update_g, recon="l1",
+              clip=0.01):
+    """One batch of experiment_list/wgan_l1.py:110-186 with one=+1, mone=-1 (the file's
+    torch.FloatTensor(1) is uninitialised memory). update_g is the
+    cadence decision of wgan_l1.py:157-163, taken by the caller."""
+    m, masked = mask_pipeline(ground, mask)
+    inpainted = composite(masked, unet_forward(PG, masked, num_downs, True, dropout_masks), m)
+    set_requires_grad(PD, True)
+    optD.zero_grad()
+    d_real = patchgan_forward(PD, ground, False, True)
+    d_fake = patchgan_forward(PD, inpainted.detach(), False, True)
+    d_loss_real = d_real.mean().view(1)
+    d_loss_real.backward(torch.ones(1, dtype=d_real.dtype))
+    d_loss_fake = d_fake.mean().view(1)
+    d_loss_fake.backward(-torch.ones(1, dtype=d_real.dtype))
+    d_grad_stats = grad_absmean(PD)
+    optD.step()
+    clamp_params(trainable(PD), -clip, clip)
+    out = dict(d_loss_real=float(d_loss_real), d_loss_fake=float(d_loss_fake),
+               d_loss=float(d_loss_real - d_loss_fake), inpainted=inpainted.detach(),
+               d_grad_absmean=d_grad_stats)
+    if update_g:
+        set_requires_grad(PD, False)
+        optG.zero_grad()
+        d_fake2 = patchgan_forward(PD, inpainted, False, True).view(-1)
+        g_adv = d_fake2.mean().view(1)
+        rec = l1_loss(ground, inpainted) if recon == "l1" else rmse_loss(ground, inpainted)
+        g_loss = g_adv + rec
+        g_loss.backward()
+        out.update(g_adv=float(g_adv), recon=float(rec), g_loss=float(g_loss),
+                   g_grad_absmean=grad_absmean(PG))
+        optG.step()
+    return out
+
+
+def wgan_update_g(batch_index, g_iter_count, update_g_every=5):
+    """wgan_l1.py:157-163."""
+    period = 140 if (g_iter_count < 25 or g_iter_count % 500 == 0) else update_g_every
+    return batch_index % period == 0 and batch_index > 0
+
+
+def dual_d_step(PG, PDg, PDl, optG, optD, ground, mask, num_downs, dropout_masks, lam1=300.0,
+                lam2=300.0):
+    """One batch of experiment_list/experiment1_global_local_D.py:139-200: G step first, LSGAN
+    losses, mask NOT ceil-ed, output NOT composited; one Adam over both discriminators (:123)."""
+    masked = ground * (1 - mask)
+    n = ground.shape[0]
+    set_requires_grad(PDg, False)
+    set_requires_grad(PDl, False)
+    optG.zero_grad()
+    inpainted = unet_forward(PG, masked, num_downs, True, dropout_masks)
+    pg = patchgan_forward(PDg, inpainted, True, True).view(-1)
+    pl = patchgan_forward(PDl, mask * inpainted, True, True).view(-1)
+    ones, zeros = torch.ones(n, dtype=pg.dtype), torch.zeros(n, dtype=pg.dtype)
+    g_adv_g, g_adv_l = mse_loss(pg, ones), mse_loss(pl, ones)
+    rec_g = rmse_loss(ground, inpainted)
+    rec_l = rmse_loss(mask * ground, mask * inpainted)
+    g_loss = g_adv_g + g_adv_l + lam1 * rec_g + lam2 * rec_l
+    g_loss.backward()
+    g_grad_stats = grad_absmean(PG)
+    optG.step()
+    set_requires_grad(PDg, True)
+    set_requires_grad(PDl, True)
+    optD.zero_grad()
+    fake = inpainted.detach()
+    d_loss = (mse_loss(patchgan_forward(PDl, ground * mask, True, True).view(-1), ones)
+              + mse_loss(patchgan_forward(PDl, fake * mask, True, True).view(-1), zeros)
+              + mse_loss(patchgan_forward(PDg, ground, True, True).view(-1), ones)
+              + mse_loss(patchgan_forward(PDg, fake, True, True).view(-1), zeros))
+    d_loss.backward()
+    optD.step()
+    return dict(g_loss=float(g_loss), d_loss=float(d_loss), rmse_global=float(rec_g),
+                rmse_local=float(rec_l), g_adv_global=float(g_adv_g), g_adv_local=float(g_adv_l),
+                inpainted=fake, g_grad_absmean=g_grad_stats)

@@ -1,0 +1,429 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (run in the build container only).
+
+    python tests/golden/make_golden.py [--ref /root/reference]
+
+What it does
+  * registers an empty `torchvision` stub (the reference imports it at networks.py:3 but only
+    uses it inside VGG19Wrapper.__init__, networks.py:371) and imports the reference's
+    lib/models/networks.py and lib/models/util.py as they lie under --ref;
+  * loads build-generated deterministic weights (oracle/params.py) with load_state_dict;
+  * runs forward / backward / the per-batch step sequences (re-typed from
+    experiment_list/minimaxgan_l1.py:110-173, wgan_l1.py:110-186,
+    experiment1_global_local_D.py:139-200, with torch.optim / torch.nn loss built-ins exactly as
+    those plugins call them; one=+1, mone=-1);
+  * captures the Dropout keep-masks with forward hooks;
+  * asserts that the repo's own oracle (oracle/torch_ref.py) reproduces every recorded number
+    (this is the pin), and writes small fixtures (data only: seeds, outputs, losses, statistics).
+
+Nothing from the reference is copied: the fixtures hold inputs' seeds and numeric outputs.
+"""
+import argparse
+import itertools
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import params as op  # noqa: E402
+from oracle import torch_ref as orc  # noqa: E402
+
+
+def import_reference(ref_root):
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tv.models)
+    sys.path.insert(0, ref_root)
+    import lib.models.networks as networks  # noqa
+    import lib.models.util as util  # noqa
+    sys.path.pop(0)
+    return networks, util
+
+
+def load(module, P):
+    sd = OrderedDict((k, torch.from_numpy(np.array(v))) for k, v in P.items())
+    module.load_state_dict(sd, strict=True)
+    return module
+
+
+class MaskCapture:
+    """Forward hooks on the reference's nn.Dropout modules: keep-mask = (output != 0)."""
+
+    def __init__(self, net_G, num_downs):
+        self.masks = {}
+        self.levels = {}
+        drops = [m for m in net_G.modules() if isinstance(m, torch.nn.Dropout)]
+        # modules() is a pre-order walk and each block's Dropout follows its submodule, so the
+        # first Dropout met belongs to the deepest dropout level (num_downs-1)
+        for lvl, m in zip(reversed(op.dropout_levels(num_downs)), drops):
+            m.register_forward_hook(self._hook(lvl))
+
+    def _hook(self, lvl):
+        def fn(mod, inp, out):
+            if mod.training:
+                self.masks[lvl] = (out != 0).to(torch.uint8).clone()
+        return fn
+
+
+def pack_masks(masks):
+    out = {}
+    for lvl, m in masks.items():
+        a = m.numpy().astype(np.uint8)
+        out[f"mask{lvl}_shape"] = np.array(a.shape, dtype=np.int64)
+        out[f"mask{lvl}_bits"] = np.packbits(a.reshape(-1))
+    return out
+
+
+def grad_stats(module):
+    names, absmean, head = [], [], []
+    for n, p in module.named_parameters():
+        names.append(n)
+        absmean.append(float(p.grad.abs().mean()) if p.grad is not None else float("nan"))
+        head.append(p.grad.reshape(-1)[:32].numpy().copy() if p.grad is not None else np.zeros(0, np.float32))
+    return names, np.array(absmean, np.float64), head
+
+
+def param_stats(module):
+    return np.array([[float(p.double().sum()), float(p.double().abs().sum())] for _, p in module.named_parameters()])
+
+
+def bn_stats(module):
+    out = OrderedDict()
+    for k, v in module.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            out[k] = v.numpy().copy()
+    return out
+
+
+def close(a, b, tol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.max(np.abs(a - b) / (np.abs(b) + 1e-6)) if a.size else 0.0
+    assert err <= tol, f"oracle != reference for {what}: rel err {err:.3e}"
+    return err
+
+
+def case_unet(networks, name, seed, N, HW, num_downs, train):
+    torch.manual_seed(1000 + seed)
+    P = op.make_unet_params(seed, num_downs=num_downs, ngf=64)
+    if num_downs == 7:
+        net = networks.get_network("generator", "unet")  # networks.py:17-19
+    else:
+        net = networks.UnetGenerator(1, 1, num_downs, ngf=64,
+                                     norm_layer=networks.get_norm_layer(norm_type="batch"),
+                                     use_dropout="False")
+    load(net, P)
+    net.train(train)
+    cap = MaskCapture(net, num_downs)
+    ground, mask = op.synth_batch(seed + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask))
+    rng = np.random.Generator(np.random.PCG64(seed + 99))
+    R = torch.from_numpy(rng.standard_normal(size=(N, 1, HW, HW), dtype=np.float32))
+    out = net(x)
+    fx = dict(seed=seed, N=N, HW=HW, num_downs=num_downs, train=int(train), out=out.detach().numpy())
+    # --- oracle pin
+    OP = orc.to_torch(P)
+    masks = {k: v for k, v in cap.masks.items()}
+    oout = orc.unet_forward(OP, x, num_downs, train, masks)
+    e = close(oout.detach().numpy(), fx["out"], 1e-6, name + ".out")
+    if train:
+        (out * R).sum().backward()
+        names, absmean, head = grad_stats(net)
+        (oout * R).sum().backward()
+        for i, n in enumerate(names):
+            close(float(OP[n].grad.abs().mean()), absmean[i], 1e-5, f"{name}.grad[{n}]")
+        fx.update(grad_names=np.array(names), grad_absmean=absmean,
+                  **{f"ghead_{i}": h for i, h in enumerate(head)})
+        for k, v in bn_stats(net).items():
+            close(OP[k].numpy(), v, 1e-6, f"{name}.{k}")
+            fx["bn::" + k] = v
+        fx.update(pack_masks(cap.masks))
+    print(f"  {name}: out err {e:.2e}")
+    return fx
+
+
+def case_patchgan(networks, name, seed, N):
+    P = op.make_patchgan_params(seed, 128, 128)
+    fx = dict(seed=seed, N=N)
+    ground, _ = op.synth_batch(seed + 3, N, 128, 128)
+    rng = np.random.Generator(np.random.PCG64(seed + 5))
+    r = torch.from_numpy(rng.standard_normal(size=(N, 1), dtype=np.float32))
+    for sig in (True, False):
+        net = load(networks.PatchGANDiscriminator(sigmoid=sig), P)  # networks.py:331, wgan_l1.py:58
+        net.train(True)
+        x = torch.from_numpy(ground).clone().requires_grad_(True)
+        out = net(x)
+        (out * r).sum().backward()
+        names, absmean, head = grad_stats(net)
+        tag = "sig" if sig else "lin"
+        fx[f"out_{tag}"] = out.detach().numpy()
+        fx[f"grad_absmean_{tag}"] = absmean
+        fx[f"dx_absmean_{tag}"] = float(x.grad.abs().mean())
+        fx[f"dx_head_{tag}"] = x.grad.reshape(-1)[:256].numpy().copy()
+        fx["grad_names"] = np.array(names)
+        OP = orc.to_torch(P)
+        ox = torch.from_numpy(ground).clone().requires_grad_(True)
+        oout = orc.patchgan_forward(OP, ox, sig, True)
+        (oout * r).sum().backward()
+        close(oout.detach().numpy(), fx[f"out_{tag}"], 1e-6, f"{name}.out_{tag}")
+        close(ox.grad.numpy(), x.grad.numpy(), 1e-4, f"{name}.dx_{tag}")
+        for i, n in enumerate(names):
+            close(float(OP[n].grad.abs().mean()), absmean[i], 1e-5, f"{name}.grad_{tag}[{n}]")
+        for k, v in bn_stats(net).items():
+            close(OP[k].numpy(), v, 1e-6, f"{name}.{k}")
+            fx[f"bn_{tag}::" + k] = v
+        # eval-mode forward too
+        net.train(False)
+        fx[f"out_eval_{tag}"] = net(torch.from_numpy(ground)).detach().numpy()
+        # (running stats were updated by the train-mode forward above, in both copies)
+        close(orc.patchgan_forward(OP, torch.from_numpy(ground), sig, False).detach().numpy(),
+              fx[f"out_eval_{tag}"], 1e-6, f"{name}.out_eval_{tag}")
+    print(f"  {name}: ok")
+    return fx
+
+
+def _record_step(fx, i, rec):
+    for k, v in rec.items():
+        fx[f"it{i}_{k}"] = np.asarray(v)
+
+
+def case_minimax(networks, util, name, seed, N, iters):
+    """minimaxgan_l1.py:110-173 replayed on the reference modules."""
+    PG, PD = op.make_unet_params(seed), op.make_patchgan_params(seed + 1)
+    net_G = load(networks.get_network("generator", "unet"), PG)
+    net_D = load(networks.get_network("discriminator", "patchgan"), PD)
+    cap = MaskCapture(net_G, 7)
+    bce, l1 = torch.nn.BCELoss(), torch.nn.L1Loss()
+    G_opt = torch.optim.Adam(net_G.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    D_opt = torch.optim.Adam(net_D.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    OG, OD = orc.to_torch(PG), orc.to_torch(PD)
+    oG, oD = orc.Adam(orc.trainable(OG)), orc.Adam(orc.trainable(OD))
+    fx = dict(seed=seed, N=N, iters=iters)
+    torch.manual_seed(seed)
+    for it in range(iters):
+        g_np, m_np = op.synth_batch(seed * 100 + it, N, 128, 128, fractional_edge=(it == 0))
+        ground, mask = torch.from_numpy(g_np), torch.ceil(torch.from_numpy(m_np))
+        masked = ground * (1 - mask)
+        inpainted = net_G(masked)
+        inpainted = masked + inpainted * mask
+        util.set_requires_grad([net_D], True)
+        D_opt.zero_grad()
+        d_pred_real = net_D(ground).view(-1)
+        d_loss_real = bce(d_pred_real, torch.ones(len(d_pred_real)))
+        d_loss_real.backward()
+        d_pred_fake = net_D(inpainted.detach()).view(-1)
+        d_loss_fake = bce(d_pred_fake, torch.zeros(len(d_pred_fake)))
+        d_loss_fake.backward()
+        _, d_absmean, _ = grad_stats(net_D)
+        D_opt.step()
+        util.set_requires_grad([net_D], False)
+        G_opt.zero_grad()
+        d_pred_fake = net_D(inpainted).view(-1)
+        g_adv = bce(d_pred_fake, torch.ones(len(d_pred_fake)))
+        recon = l1(ground, inpainted)
+        g_loss = g_adv + recon
+        g_loss.backward()
+        _, g_absmean, _ = grad_stats(net_G)
+        G_opt.step()
+        rec = dict(d_loss_real=float(d_loss_real), d_loss_fake=float(d_loss_fake), g_adv=float(g_adv),
+                   recon=float(recon), g_loss=float(g_loss), g_grad_absmean=g_absmean,
+                   d_grad_absmean=d_absmean, g_param_stats=param_stats(net_G),
+                   d_param_stats=param_stats(net_D))
+        _record_step(fx, it, rec)
+        fx.update({f"it{it}_{k}": v for k, v in pack_masks(cap.masks).items()})
+        if it == iters - 1:
+            fx["final_inpainted"] = inpainted.detach().numpy()
+        # --- oracle pin
+        o = orc.minimax_step(OG, OD, oG, oD, torch.from_numpy(g_np), torch.from_numpy(m_np), 7, dict(cap.masks))
+        for k in ("d_loss_real", "d_loss_fake", "g_adv", "recon", "g_loss"):
+            close(o[k], rec[k], 2e-5, f"{name}.it{it}.{k}")
+        gnames = [n for n, _ in net_G.named_parameters()]
+        for i, n in enumerate(gnames):
+            if "bias" not in n:
+                close(o["g_grad_absmean"][n], g_absmean[i], 1e-4, f"{name}.it{it}.g_absmean[{n}]")
+        ostats = np.array([[float(OG[n].double().sum()), float(OG[n].double().abs().sum())] for n in gnames])
+        close(ostats[:, 1], rec["g_param_stats"][:, 1], 1e-6, f"{name}.it{it}.g_params")
+        print(f"  {name} it{it}: g_loss {rec['g_loss']:.6f} d_real {rec['d_loss_real']:.6f} ok")
+    fx["g_param_names"] = np.array([n for n, _ in net_G.named_parameters()])
+    fx["d_param_names"] = np.array([n for n, _ in net_D.named_parameters()])
+    return fx
+
+
+def case_wgan(networks, util, name, seed, N, pattern):
+    """wgan_l1.py:110-186 replayed on the reference modules; `pattern` forces the G-update
+    decision per batch (the cadence rule itself is host logic, tested separately)."""
+    PG, PD = op.make_unet_params(seed), op.make_patchgan_params(seed + 1)
+    net_G = load(networks.get_network("generator", "unet"), PG)
+    net_D = load(networks.PatchGANDiscriminator(sigmoid=False), PD)
+    cap = MaskCapture(net_G, 7)
+    l1 = torch.nn.L1Loss()
+    G_opt = torch.optim.RMSprop(net_G.parameters(), lr=0.00005)
+    D_opt = torch.optim.RMSprop(net_D.parameters(), lr=0.00005)
+    one = torch.ones(1)
+    mone = one * -1
+    OG, OD = orc.to_torch(PG), orc.to_torch(PD)
+    oG, oD = orc.RMSprop(orc.trainable(OG)), orc.RMSprop(orc.trainable(OD))
+    fx = dict(seed=seed, N=N, pattern=np.array(pattern, np.int64))
+    torch.manual_seed(seed)
+    for it, upd in enumerate(pattern):
+        g_np, m_np = op.synth_batch(seed * 100 + it, N, 128, 128)
+        ground, mask = torch.from_numpy(g_np), torch.ceil(torch.from_numpy(m_np))
+        masked = ground * (1 - mask)
+        inpainted = net_G(masked)
+        inpainted = masked + inpainted * mask
+        util.set_requires_grad([net_D], True)
+        D_opt.zero_grad()
+        d_pred_real = net_D(ground)
+        d_pred_fake = net_D(inpainted.detach())
+        d_loss_real = torch.mean(d_pred_real).view(1)
+        d_loss_real.backward(one)
+        d_loss_fake = torch.mean(d_pred_fake).view(1)
+        d_loss_fake.backward(mone)
+        _, d_absmean, _ = grad_stats(net_D)
+        D_opt.step()
+        for p in net_D.parameters():
+            p.data.clamp_(-0.01, 0.01)
+        rec = dict(d_loss_real=float(d_loss_real), d_loss_fake=float(d_loss_fake), d_grad_absmean=d_absmean)
+        if upd:
+            util.set_requires_grad([net_D], False)
+            G_opt.zero_grad()
+            d_pred_fake = net_D(inpainted).view(-1)
+            g_adv = torch.mean(d_pred_fake).view(1)
+            recon = l1(ground, inpainted)
+            g_loss = g_adv + recon
+            g_loss.backward()
+            _, g_absmean, _ = grad_stats(net_G)
+            G_opt.step()
+            rec.update(g_adv=float(g_adv), recon=float(recon), g_loss=float(g_loss), g_grad_absmean=g_absmean)
+        rec.update(g_param_stats=param_stats(net_G), d_param_stats=param_stats(net_D))
+        _record_step(fx, it, rec)
+        fx.update({f"it{it}_{k}": v for k, v in pack_masks(cap.masks).items()})
+        o = orc.wgan_step(OG, OD, oG, oD, torch.from_numpy(g_np), torch.from_numpy(m_np), 7, dict(cap.masks), bool(upd))
+        for k in ("d_loss_real", "d_loss_fake") + (("g_adv", "recon", "g_loss") if upd else ()):
+            close(o[k], rec[k], 5e-5, f"{name}.it{it}.{k}")
+        dnames = [n for n, _ in net_D.named_parameters()]
+        ostats = np.array([[float(OD[n].double().sum()), float(OD[n].double().abs().sum())] for n in dnames])
+        close(ostats[:, 1], rec["d_param_stats"][:, 1], 1e-6, f"{name}.it{it}.d_params")
+        print(f"  {name} it{it}: d_real {rec['d_loss_real']:.6f} d_fake {rec['d_loss_fake']:.6f} upd={upd} ok")
+    fx["g_param_names"] = np.array([n for n, _ in net_G.named_parameters()])
+    fx["d_param_names"] = np.array([n for n, _ in net_D.named_parameters()])
+    return fx
+
+
+def case_dual(networks, util, name, seed, N):
+    """experiment1_global_local_D.py:139-200 (script-style file, loop body re-typed)."""
+    PG, PDg, PDl = op.make_unet_params(seed), op.make_patchgan_params(seed + 1), op.make_patchgan_params(seed + 2)
+    net_G = load(networks.get_network("generator", "unet"), PG)
+    net_Dg = load(networks.get_network("discriminator", "patchgan"), PDg)
+    net_Dl = load(networks.get_network("discriminator", "patchgan"), PDl)
+    cap = MaskCapture(net_G, 7)
+    mse = torch.nn.MSELoss()
+
+    def rmse(a, b):  # loss.py:11-19 (the file itself cannot be imported: loss.py:4)
+        return torch.sqrt(mse(a, b) + 1e-16)
+
+    G_opt = torch.optim.Adam(net_G.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    D_opt = torch.optim.Adam(itertools.chain(net_Dl.parameters(), net_Dg.parameters()), lr=0.0002, betas=(0.5, 0.999))
+    lambda1 = lambda2 = 300.0
+    g_np, m_np = op.synth_batch(seed * 100, N, 128, 128)
+    ground, mask = torch.from_numpy(g_np), torch.from_numpy(m_np)
+    torch.manual_seed(seed)
+    masked = ground * (1 - mask)
+    util.set_requires_grad([net_Dg, net_Dl], False)
+    G_opt.zero_grad()
+    inpainted = net_G(masked)
+    pg = net_Dg(inpainted).view(-1)
+    pl = net_Dl(mask * inpainted).view(-1)
+    g_adv_g = mse(pg, torch.ones(len(pg)))
+    g_adv_l = mse(pl, torch.ones(len(pl)))
+    rec_g = rmse(ground, inpainted)
+    rec_l = rmse(mask * ground, mask * inpainted)
+    g_loss = g_adv_g + g_adv_l + lambda1 * rec_g + lambda2 * rec_l
+    g_loss.backward()
+    _, g_absmean, _ = grad_stats(net_G)
+    G_opt.step()
+    util.set_requires_grad([net_Dg, net_Dl], True)
+    D_opt.zero_grad()
+    d_loss = (mse(net_Dg(ground).view(-1), torch.ones(N)) + mse(net_Dg(inpainted.detach()).view(-1), torch.zeros(N))
+              + mse(net_Dl(ground * mask).view(-1), torch.ones(N))
+              + mse(net_Dl(inpainted.detach() * mask).view(-1), torch.zeros(N)))
+    d_loss.backward()
+    D_opt.step()
+    fx = dict(seed=seed, N=N, g_loss=float(g_loss), d_loss=float(d_loss), rmse_global=float(rec_g),
+              rmse_local=float(rec_l), g_adv_global=float(g_adv_g), g_adv_local=float(g_adv_l),
+              g_grad_absmean=g_absmean, g_param_stats=param_stats(net_G), dg_param_stats=param_stats(net_Dg),
+              dl_param_stats=param_stats(net_Dl), **pack_masks(cap.masks))
+    OG, ODg, ODl = orc.to_torch(PG), orc.to_torch(PDg), orc.to_torch(PDl)
+    oG = orc.Adam(orc.trainable(OG))
+    oD = orc.Adam(orc.trainable(ODl) + orc.trainable(ODg))
+    o = orc.dual_d_step(OG, ODg, ODl, oG, oD, ground, mask, 7, dict(cap.masks))
+    for k in ("g_loss", "d_loss", "rmse_global", "rmse_local"):
+        close(o[k], fx[k], 5e-5, f"{name}.{k}")
+    for tag, OP, net in (("dg", ODg, net_Dg), ("dl", ODl, net_Dl)):
+        names = [n for n, _ in net.named_parameters()]
+        ostats = np.array([[float(OP[n].double().sum()), float(OP[n].double().abs().sum())] for n in names])
+        close(ostats[:, 1], fx[f"{tag}_param_stats"][:, 1], 1e-6, f"{name}.{tag}_params")
+    print(f"  {name}: g_loss {fx['g_loss']:.5f} d_loss {fx['d_loss']:.5f} ok")
+    return fx
+
+
+def case_optim(name):
+    """torch.optim.Adam / RMSprop vs the oracle's update rules on random tensors."""
+    rng = np.random.Generator(np.random.PCG64(77))
+    w0 = rng.standard_normal(4096).astype(np.float32)
+    grads = [rng.standard_normal(4096).astype(np.float32) * 0.01 for _ in range(3)]
+    fx = dict(w0=w0, **{f"g{i}": g for i, g in enumerate(grads)})
+    for kind in ("adam", "rmsprop"):
+        p = torch.nn.Parameter(torch.from_numpy(w0.copy()))
+        q = torch.from_numpy(w0.copy()).requires_grad_(True)
+        if kind == "adam":
+            opt, oo = torch.optim.Adam([p], lr=0.0002, betas=(0.5, 0.999)), orc.Adam([q])
+        else:
+            opt, oo = torch.optim.RMSprop([p], lr=0.00005), orc.RMSprop([q])
+        for g in grads:
+            p.grad = torch.from_numpy(g.copy())
+            q.grad = torch.from_numpy(g.copy())
+            opt.step()
+            oo.step()
+        fx[f"w_{kind}"] = p.detach().numpy().copy()
+        close(q.detach().numpy(), fx[f"w_{kind}"], 1e-6, f"{name}.{kind}")
+    print(f"  {name}: ok")
+    return fx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.set_num_threads(8)
+    networks, util = import_reference(args.ref)
+    cases = OrderedDict(
+        unet128_train=lambda: case_unet(networks, "unet128_train", 11, 2, 128, 7, True),
+        unet128_eval=lambda: case_unet(networks, "unet128_eval", 12, 2, 128, 7, False),
+        unet256_train=lambda: case_unet(networks, "unet256_train", 13, 1, 256, 7, True),
+        unet64_nd6_train=lambda: case_unet(networks, "unet64_nd6_train", 14, 2, 64, 6, True),
+        patchgan128=lambda: case_patchgan(networks, "patchgan128", 21, 3),
+        minimax_steps=lambda: case_minimax(networks, util, "minimax_steps", 31, 2, 2),
+        wgan_steps=lambda: case_wgan(networks, util, "wgan_steps", 41, 2, [0, 1, 0]),
+        dual_d_step=lambda: case_dual(networks, util, "dual_d_step", 51, 2),
+        optim=lambda: case_optim("optim"),
+    )
+    for name, fn in cases.items():
+        if args.only and name not in args.only.split(","):
+            continue
+        print(name)
+        fx = fn()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

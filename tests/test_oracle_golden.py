@@ -1,0 +1,123 @@
+"""CPU tier: the oracle (oracle/torch_ref.py) against the fixtures recorded from the imported
+reference (tests/golden/make_golden.py). This is the parity pin of the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import params as op
+from oracle import torch_ref as orc
+from util_golden import load, relerr, unpack_masks
+
+
+@pytest.mark.parametrize("name", ["unet128_train", "unet128_eval", "unet64_nd6_train"])
+def test_unet_forward_backward(name):
+    fx = load(name)
+    seed, N, HW, nd, train = (int(fx[k]) for k in ("seed", "N", "HW", "num_downs", "train"))
+    P = orc.to_torch(op.make_unet_params(seed, num_downs=nd))
+    ground, mask = op.synth_batch(seed + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask))
+    out = orc.unet_forward(P, x, nd, bool(train), unpack_masks(fx))
+    assert relerr(out.detach().numpy(), fx["out"]) < 1e-5
+    if not train:
+        return
+    R = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 99)).standard_normal(
+        size=(N, 1, HW, HW), dtype=np.float32))
+    (out * R).sum().backward()
+    names = [str(n) for n in fx["grad_names"]]
+    for i, n in enumerate(names):
+        assert relerr(float(P[n].grad.abs().mean()), fx["grad_absmean"][i]) < 1e-4, n
+        assert relerr(P[n].grad.reshape(-1)[:32].numpy(), fx[f"ghead_{i}"], floor=1e-4) < 1e-3, n
+    for k in fx.files:
+        if k.startswith("bn::"):
+            assert relerr(P[k[4:]].numpy(), fx[k]) < 1e-5, k
+
+
+def test_patchgan():
+    fx = load("patchgan128")
+    seed, N = int(fx["seed"]), int(fx["N"])
+    ground, _ = op.synth_batch(seed + 3, N, 128, 128)
+    r = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 5)).standard_normal(size=(N, 1), dtype=np.float32))
+    for sig, tag in ((True, "sig"), (False, "lin")):
+        P = orc.to_torch(op.make_patchgan_params(seed, 128, 128))
+        x = torch.from_numpy(ground).clone().requires_grad_(True)
+        out = orc.patchgan_forward(P, x, sig, True)
+        assert relerr(out.detach().numpy(), fx[f"out_{tag}"]) < 1e-5
+        (out * r).sum().backward()
+        assert relerr(x.grad.reshape(-1)[:256].numpy(), fx[f"dx_head_{tag}"], floor=1e-7) < 1e-3
+        for i, n in enumerate(str(s) for s in fx["grad_names"]):
+            assert relerr(float(P[n].grad.abs().mean()), fx[f"grad_absmean_{tag}"][i]) < 1e-4, n
+        ev = orc.patchgan_forward(P, torch.from_numpy(ground), sig, False)
+        assert relerr(ev.detach().numpy(), fx[f"out_eval_{tag}"]) < 1e-5
+
+
+def _pstats(P, names):
+    return np.array([[float(P[n].double().sum()), float(P[n].double().abs().sum())] for n in names])
+
+
+def test_minimax_steps():
+    fx = load("minimax_steps")
+    seed, N, iters = int(fx["seed"]), int(fx["N"]), int(fx["iters"])
+    PG, PD = orc.to_torch(op.make_unet_params(seed)), orc.to_torch(op.make_patchgan_params(seed + 1))
+    oG, oD = orc.Adam(orc.trainable(PG)), orc.Adam(orc.trainable(PD))
+    for it in range(iters):
+        g, m = op.synth_batch(seed * 100 + it, N, 128, 128, fractional_edge=(it == 0))
+        o = orc.minimax_step(PG, PD, oG, oD, torch.from_numpy(g), torch.from_numpy(m), 7,
+                             unpack_masks(fx, f"it{it}_"))
+        for k in ("d_loss_real", "d_loss_fake", "g_adv", "recon", "g_loss"):
+            assert relerr(o[k], fx[f"it{it}_{k}"]) < 1e-4, (it, k)
+        gn = [str(s) for s in fx["g_param_names"]]
+        dn = [str(s) for s in fx["d_param_names"]]
+        assert relerr(_pstats(PG, gn)[:, 1], fx[f"it{it}_g_param_stats"][:, 1]) < 1e-5
+        assert relerr(_pstats(PD, dn)[:, 1], fx[f"it{it}_d_param_stats"][:, 1]) < 1e-5
+    assert relerr(o["inpainted"].numpy(), fx["final_inpainted"], floor=1e-3) < 1e-3
+
+
+def test_wgan_steps():
+    fx = load("wgan_steps")
+    seed, N = int(fx["seed"]), int(fx["N"])
+    PG, PD = orc.to_torch(op.make_unet_params(seed)), orc.to_torch(op.make_patchgan_params(seed + 1))
+    oG, oD = orc.RMSprop(orc.trainable(PG)), orc.RMSprop(orc.trainable(PD))
+    for it, upd in enumerate(int(v) for v in fx["pattern"]):
+        g, m = op.synth_batch(seed * 100 + it, N, 128, 128)
+        o = orc.wgan_step(PG, PD, oG, oD, torch.from_numpy(g), torch.from_numpy(m), 7,
+                          unpack_masks(fx, f"it{it}_"), bool(upd))
+        keys = ("d_loss_real", "d_loss_fake") + (("g_adv", "recon", "g_loss") if upd else ())
+        for k in keys:
+            assert relerr(o[k], fx[f"it{it}_{k}"], floor=1e-4) < 1e-3, (it, k)
+        dn = [str(s) for s in fx["d_param_names"]]
+        st = _pstats(PD, dn)
+        assert relerr(st[:, 1], fx[f"it{it}_d_param_stats"][:, 1]) < 1e-5
+        # weight clipping, wgan_l1.py:151-153
+        assert max(float(PD[n].abs().max()) for n in dn) <= 0.01 + 1e-9
+
+
+def test_dual_d_step():
+    fx = load("dual_d_step")
+    seed, N = int(fx["seed"]), int(fx["N"])
+    PG = orc.to_torch(op.make_unet_params(seed))
+    PDg, PDl = orc.to_torch(op.make_patchgan_params(seed + 1)), orc.to_torch(op.make_patchgan_params(seed + 2))
+    oG = orc.Adam(orc.trainable(PG))
+    oD = orc.Adam(orc.trainable(PDl) + orc.trainable(PDg))
+    g, m = op.synth_batch(seed * 100, N, 128, 128)
+    o = orc.dual_d_step(PG, PDg, PDl, oG, oD, torch.from_numpy(g), torch.from_numpy(m), 7, unpack_masks(fx))
+    for k in ("g_loss", "d_loss", "rmse_global", "rmse_local", "g_adv_global", "g_adv_local"):
+        assert relerr(o[k], fx[k]) < 1e-4, k
+
+
+def test_optimizers():
+    fx = load("optim")
+    for kind, cls in (("adam", orc.Adam), ("rmsprop", orc.RMSprop)):
+        q = torch.from_numpy(fx["w0"].copy()).requires_grad_(True)
+        oo = cls([q])
+        for i in range(3):
+            q.grad = torch.from_numpy(fx[f"g{i}"].copy())
+            oo.step()
+        assert relerr(q.detach().numpy(), fx[f"w_{kind}"]) < 1e-5
+
+
+def test_wgan_cadence():
+    # wgan_l1.py:157-163: period 140 while G_iter_count < 25 or % 500 == 0, else 5; never at batch 0
+    assert not orc.wgan_update_g(0, 0)
+    assert orc.wgan_update_g(140, 0) and not orc.wgan_update_g(5, 0)
+    assert orc.wgan_update_g(5, 30) and not orc.wgan_update_g(6, 30)
+    assert not orc.wgan_update_g(5, 500) and orc.wgan_update_g(280, 500)
