@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build libganinpaint.so for gfx950 (cross-compiles without a GPU). Usage: ./build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+OUT=../libganinpaint.so
+SRCS="api.hip igemm.hip wgrad.hip c1.hip elementwise.hip net.hip"
+OBJS=""
+mkdir -p build
+pids=""
+for s in $SRCS; do
+  o=build/${s%.hip}.o
+  OBJS="$OBJS $o"
+  if [ ! -f $o ] || [ $s -nt $o ] || [ common.h -nt $o ] || [ ../../include/ganinpaint.h -nt $o ]; then
+    ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable "$@" -c $s -o $o ) &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
+echo "built $(readlink -f $OUT)"

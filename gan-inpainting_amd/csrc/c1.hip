@@ -1,0 +1,447 @@
+// HBM-bound kernels for the layers whose large-resolution side has ONE channel:
+//   generator d1  Conv2d(1->ngf)            (lib/models/networks.py:285, outermost block :296)
+//   generator u1  ConvTranspose2d(2ngf->1)  (networks.py:293-297) + bias + tanh
+//   discriminator Conv2d(1->64)             (networks.py:337)
+// and their gradients. Weights are fp32 [c][16] (= [a][ky][kx][b] with b == 1). The image side is
+// the public fp32 (n,1,H,W) tensor, the feature side NHWC of type T.
+// These layers carry <1% of the FLOPs and ~45% of the activation bytes, so they are written as
+// vectorised streaming kernels (16-byte feature accesses, weights in registers/LDS), not GEMMs.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+
+// ---- gather: out[p][c] = act(sum_tap img[n,2y-1+ky,2x-1+kx] * w[c][tap]) ---------------------
+template <typename T>
+__global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                        char* out, int n, int Hs, int Ws, int c, int ldout,
+                                                        int coffout, int act, float in_scale) {
+  constexpr int G = 8;  // channels per thread
+  extern __shared__ float sw[];  // [c][16]
+  for (int i = threadIdx.x; i < c * 16; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int groups = c / G;
+  const int64_t total = (int64_t)n * Hs * Ws * groups;
+  const int H = 2 * Hs, W = 2 * Ws;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int grp = (int)(gid % groups);
+    const int64_t pix = gid / groups;
+    const int x = (int)(pix % Ws);
+    const int64_t t = pix / Ws;
+    const int y = (int)(t % Hs);
+    const int nn = (int)(t / Hs);
+    float v[16];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
+        v[ky * 4 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[((int64_t)nn * H + iy) * W + ix] * in_scale : 0.f;
+      }
+    float o[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+      const float* wr = sw + (grp * G + j) * 16;
+      float s = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) s = fmaf(v[tt], wr[tt], s);
+      o[j] = act_f(s, act);
+    }
+    T* dst = (T*)(out + (pix * ldout + coffout + grp * G) * (int64_t)sizeof(T));
+    if constexpr (std::is_same<T, half_t>::value) {
+      h8_t h;
+#pragma unroll
+      for (int j = 0; j < G; ++j) h[j] = (half_t)o[j];
+      *(h8_t*)dst = h;
+    } else {
+      *(f4_t*)dst = f4_t{o[0], o[1], o[2], o[3]};
+      *(f4_t*)(dst + 4) = f4_t{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
+// ---- scatter (transposed conv to one channel), one lane group per small-resolution pixel ------
+// The 2x2 output quad (2j..2j+1, 2i..2i+1) reads the 3x3 neighbourhood of (j,i):
+//   out(2j+py, 2i+px) = sum_{ty,tx} X[j+py-ty][i+px-tx] . w[:, (1-py+2ty)*4 + (1-px+2tx)]
+template <typename T>
+__global__ void __launch_bounds__(256) c1_scatter_kernel(const char* X, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* img, int n, int Hs,
+                                                         int Ws, int c, int ldx, int coffx, int relu_in, int post,
+                                                         float out_scale) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int LPP = c / EPC;  // lanes per pixel (power of two <= 64)
+  const int cl = threadIdx.x % LPP;
+  float wr[16][EPC];  // this lane's weights
+#pragma unroll
+  for (int j = 0; j < EPC; ++j)
+#pragma unroll
+    for (int tt = 0; tt < 16; ++tt) wr[tt][j] = w[(cl * EPC + j) * 16 + tt];
+  const float b = bias ? bias[0] : 0.f;
+  const int gpb = 256 / LPP;
+  const int64_t total = (int64_t)n * Hs * Ws;
+  const int H = 2 * Hs, W = 2 * Ws;
+  const int64_t niter = (total + (int64_t)gridDim.x * gpb - 1) / ((int64_t)gridDim.x * gpb);
+  for (int64_t it = 0; it < niter; ++it) {
+    const int64_t pix = (it * gridDim.x + blockIdx.x) * gpb + threadIdx.x / LPP;
+    const bool live = pix < total;
+    const int i = live ? (int)(pix % Ws) : 0;
+    const int64_t t = live ? pix / Ws : 0;
+    const int j = (int)(t % Hs);
+    const int nn = (int)(t / Hs);
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int sy = j + dy, sx = i + dx;
+          if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) continue;
+          const char* src = X + ((((int64_t)nn * Hs + sy) * Ws + sx) * ldx + coffx + cl * EPC) * (int64_t)sizeof(T);
+          float xv[EPC];
+          if constexpr (std::is_same<T, half_t>::value) {
+            const h8_t h = *(const h8_t*)src;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) xv[e] = (float)h[e];
+          } else {
+            const f4_t f = *(const f4_t*)src;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) xv[e] = f[e];
+          }
+          if (relu_in) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) xv[e] = xv[e] > 0.f ? xv[e] : 0.f;
+          }
+#pragma unroll
+          for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+              const int ty = py - dy, tx = px - dx;  // source = (j+py-ty, i+px-tx)
+              if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+              const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+              float s = 0.f;
+#pragma unroll
+              for (int e = 0; e < EPC; ++e) s = fmaf(xv[e], wr[tap][e], s);
+              o[py * 2 + px] += s;
+            }
+        }
+    }
+    for (int off = LPP >> 1; off > 0; off >>= 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] += __shfl_xor(o[q], off);
+    }
+    if (live && cl == 0) {
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        float v0 = o[py * 2] + b, v1 = o[py * 2 + 1] + b;
+        if (post == 1) { v0 = tanhf(v0); v1 = tanhf(v1); }
+        float2 r = make_float2(v0 * out_scale, v1 * out_scale);
+        *(float2*)(img + ((int64_t)nn * H + 2 * j + py) * W + 2 * i) = r;
+      }
+    }
+  }
+}
+
+// ---- weight gradient: dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx] ------
+template <typename T>
+__global__ void __launch_bounds__(256) c1_wgrad_kernel(const char* X, const float* __restrict__ img, float* dW, int n,
+                                                       int Hs, int Ws, int c, int ldx, int coffx, int relu_in,
+                                                       float scale, float img_scale, int pix_per_block) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  extern __shared__ float sred[];  // [pl][c][4] per round
+  const int LPP = c / EPC;
+  const int cl = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+  const int gpb = 256 / LPP;
+  const int64_t total = (int64_t)n * Hs * Ws;
+  const int H = 2 * Hs, W = 2 * Ws;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p1 = min(total, p0 + pix_per_block);
+  float acc[16][EPC];
+#pragma unroll
+  for (int tt = 0; tt < 16; ++tt)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[tt][e] = 0.f;
+  for (int64_t pix = p0 + pl; pix < p1; pix += gpb) {
+    const int x = (int)(pix % Ws);
+    const int64_t t = pix / Ws;
+    const int y = (int)(t % Hs);
+    const int nn = (int)(t / Hs);
+    const char* src = X + (pix * ldx + coffx + cl * EPC) * (int64_t)sizeof(T);
+    float xv[EPC];
+    if constexpr (std::is_same<T, half_t>::value) {
+      const h8_t h = *(const h8_t*)src;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) xv[e] = (float)h[e];
+    } else {
+      const f4_t f = *(const f4_t*)src;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) xv[e] = f[e];
+    }
+    if (relu_in) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) xv[e] = xv[e] > 0.f ? xv[e] : 0.f;
+    }
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
+        const float g = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[((int64_t)nn * H + iy) * W + ix] * img_scale : 0.f;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) acc[ky * 4 + kx][e] = fmaf(xv[e], g, acc[ky * 4 + kx][e]);
+      }
+  }
+  // block reduction over pixel lanes, 4 taps per round: sred[pl][c][4]
+#pragma unroll
+  for (int rnd = 0; rnd < 4; ++rnd) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sred[(pl * c + cl * EPC + e) * 4 + q] = acc[rnd * 4 + q][e];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < c * 4; idx += 256) {
+      float s = 0.f;
+      for (int k = 0; k < gpb; ++k) s += sred[k * c * 4 + idx];
+      const int ch = idx >> 2, q = idx & 3;
+      atomicAdd(dW + ch * 16 + rnd * 4 + q, s * scale);
+    }
+  }
+}
+
+// ---- discriminator head ----------------------------------------------------------------------
+// h[n,py,px] = sum_{ky,kx,c} a4[n,py+ky,px+kx,c] * w5[ky*4+kx][c]     (Conv2d(512,1,4,1,0), networks.py:352)
+template <typename T>
+__global__ void __launch_bounds__(256) head_conv_kernel(const char* a4, const float* __restrict__ w5, float* h, int Hh,
+                                                        int Wh, int c) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ float red[4];
+  const int Ph = Hh - 3, Pw = Wh - 3;
+  const int o = blockIdx.x;  // (n, py, px)
+  const int px = o % Pw, py = (o / Pw) % Ph, nn = o / (Pw * Ph);
+  const int cpt = c / EPC;  // chunks per tap
+  float s = 0.f;
+  for (int idx = threadIdx.x; idx < 16 * cpt; idx += 256) {
+    const int tap = idx / cpt, cc = idx % cpt;
+    const int iy = py + (tap >> 2), ix = px + (tap & 3);
+    const char* src = a4 + ((((int64_t)nn * Hh + iy) * Wh + ix) * c + cc * EPC) * (int64_t)sizeof(T);
+    const float* wr = w5 + tap * c + cc * EPC;
+    if constexpr (std::is_same<T, half_t>::value) {
+      const h8_t v = *(const h8_t*)src;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s = fmaf((float)v[e], wr[e], s);
+    } else {
+      const f4_t v = *(const f4_t*)src;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s = fmaf(v[e], wr[e], s);
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) h[o] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[n] = [sigmoid](bl + sum_p wl[p]*h[n,p])     (Flatten + Linear(P,1) [+ Sigmoid], networks.py:353-357)
+__global__ void __launch_bounds__(64) head_linear_kernel(const float* h, const float* wl, const float* bl, float* out,
+                                                         int P, int sigmoid) {
+  const int nn = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < P; i += 64) s = fmaf(h[(int64_t)nn * P + i], wl[i], s);
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if (threadIdx.x == 0) {
+    s += bl[0];
+    out[nn] = sigmoid ? 1.f / (1.f + expf(-s)) : s;
+  }
+}
+
+// dz[n] = dy[n] * (sigmoid ? out(1-out) : 1); dh[n,p] = dz[n]*wl[p]; dwl[p] += sum_n dz[n]*h[n,p]; dbl += sum dz
+__global__ void __launch_bounds__(256) head_linear_bwd_kernel(const float* dy, const float* out, const float* h,
+                                                              const float* wl, float* dh, float* dwl, float* dbl, int n,
+                                                              int P, int sigmoid) {
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < P; p += gridDim.x * 256) {
+    float gw = 0.f;
+    for (int nn = 0; nn < n; ++nn) {
+      const float o = out[nn];
+      const float dz = dy[nn] * (sigmoid ? o * (1.f - o) : 1.f);
+      dh[(int64_t)nn * P + p] = dz * wl[p];
+      gw = fmaf(dz, h[(int64_t)nn * P + p], gw);
+    }
+    if (dwl) atomicAdd(dwl + p, gw);
+  }
+  if (dbl && blockIdx.x == 0 && threadIdx.x == 0) {
+    float gb = 0.f;
+    for (int nn = 0; nn < n; ++nn) {
+      const float o = out[nn];
+      gb += dy[nn] * (sigmoid ? o * (1.f - o) : 1.f);
+    }
+    atomicAdd(dbl, gb);
+  }
+}
+
+// da4[n,y,x,c] = loss_scale * sum_{tap: (y-ky,x-kx) valid} dh[n,y-ky,x-kx] * w5[tap][c]
+template <typename T>
+__global__ void __launch_bounds__(256) head_dgrad_kernel(const float* dh, const float* __restrict__ w5, char* da4, int n,
+                                                         int Hh, int Wh, int c, float loss_scale) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int Ph = Hh - 3, Pw = Wh - 3;
+  const int cpt = c / EPC;
+  const int64_t total = (int64_t)n * Hh * Wh * cpt;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(gid % cpt);
+    const int64_t pix = gid / cpt;
+    const int x = (int)(pix % Wh), y = (int)((pix / Wh) % Hh), nn = (int)(pix / ((int64_t)Wh * Hh));
+    float s[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const int py = y - (tap >> 2), px = x - (tap & 3);
+      if (py < 0 || py >= Ph || px < 0 || px >= Pw) continue;
+      const float g = dh[((int64_t)nn * Ph + py) * Pw + px];
+      const float* wr = w5 + tap * c + cc * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, wr[e], s[e]);
+    }
+    T* dst = (T*)(da4 + (pix * c + cc * EPC) * (int64_t)sizeof(T));
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dst[e] = (T)(s[e] * loss_scale);
+  }
+}
+
+// dw5[tap][c] += sum_{n,p} dh[n,p] * a4[n,p+tap][c]   (grid.y = n)
+template <typename T>
+__global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const char* a4, float* dw5, int Hh, int Wh,
+                                                         int c) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int Ph = Hh - 3, Pw = Wh - 3;
+  const int cpt = c / EPC;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 16 * cpt) return;
+  const int tap = idx / cpt, cc = idx % cpt;
+  const int nn = blockIdx.y;
+  float s[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+  for (int py = 0; py < Ph; ++py)
+    for (int px = 0; px < Pw; ++px) {
+      const float g = dh[((int64_t)nn * Ph + py) * Pw + px];
+      const char* src = a4 + ((((int64_t)nn * Hh + py + (tap >> 2)) * Wh + px + (tap & 3)) * c + cc * EPC) * (int64_t)sizeof(T);
+      if constexpr (std::is_same<T, half_t>::value) {
+        const h8_t v = *(const h8_t*)src;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, (float)v[e], s[e]);
+      } else {
+        const f4_t v = *(const f4_t*)src;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, v[e], s[e]);
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) atomicAdd(dw5 + tap * c + cc * EPC + e, s[e]);
+}
+
+int grid_for(int64_t work_items, int per_block, int cap) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs, int Ws, int c,
+                 int ldout, int coffout, int act_out, float in_scale) {
+  GI_REQUIRE(c % 8 == 0 && c <= 1024, "c1_gather: c=%d", c);
+  const int64_t total = (int64_t)n * Hs * Ws * (c / 8);
+  const int grid = grid_for(total, 256, 256 * 16);
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(c1_gather_kernel<half_t>, dim3(grid), dim3(256), c * 16 * 4, st, img, w, (char*)out, n, Hs, Ws, c,
+                       ldout, coffout, act_out, in_scale);
+  else
+    hipLaunchKernelGGL(c1_gather_kernel<float>, dim3(grid), dim3(256), c * 16 * 4, st, img, w, (char*)out, n, Hs, Ws, c,
+                       ldout, coffout, act_out, in_scale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img, int n, int Hs,
+                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  const int lpp = c / epc;
+  GI_REQUIRE(c % epc == 0 && gi_is_pow2(lpp) && lpp <= 64, "c1_scatter: c=%d unsupported", c);
+  const int64_t total = (int64_t)n * Hs * Ws;
+  const int grid = grid_for(total, 256 / lpp, 256 * 8);
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(c1_scatter_kernel<half_t>, dim3(grid), dim3(256), 0, st, (const char*)X, w, bias, img, n, Hs, Ws,
+                       c, ldx, coffx, relu_in, post, out_scale);
+  else
+    hipLaunchKernelGGL(c1_scatter_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)X, w, bias, img, n, Hs, Ws, c,
+                       ldx, coffx, relu_in, post, out_scale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws, int c,
+                int ldx, int coffx, int relu_in, float scale, float img_scale) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  const int lpp = c / epc;
+  GI_REQUIRE(c % epc == 0 && gi_is_pow2(lpp) && lpp <= 64, "c1_wgrad: c=%d unsupported", c);
+  const int64_t total = (int64_t)n * Hs * Ws;
+  const int gpb = 256 / lpp;
+  int ppb = (int)((total + 1023) / 1024);
+  ppb = (ppb + gpb - 1) / gpb * gpb;
+  if (ppb < gpb) ppb = gpb;
+  const int grid = (int)((total + ppb - 1) / ppb);
+  const size_t lds = (size_t)gpb * c * 4 * 4;
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(c1_wgrad_kernel<half_t>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, c,
+                       ldx, coffx, relu_in, scale, img_scale, ppb);
+  else
+    hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, c, ldx,
+                       coffx, relu_in, scale, img_scale, ppb);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
+  const int Ph = a.Hh - 3, Pw = a.Wh - 3;
+  GI_REQUIRE(Ph >= 1 && Pw >= 1, "head: feature map %dx%d too small", a.Hh, a.Wh);
+  const int blocks = a.n * Ph * Pw;
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(head_conv_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const char*)a.a4, a.w5, a.h, a.Hh, a.Wh, a.c);
+  else
+    hipLaunchKernelGGL(head_conv_kernel<float>, dim3(blocks), dim3(256), 0, st, (const char*)a.a4, a.w5, a.h, a.Hh, a.Wh, a.c);
+  GI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(head_linear_kernel, dim3(a.n), dim3(64), 0, st, a.h, a.wl, a.bl, a.out, Ph * Pw, a.sigmoid);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
+  const int Ph = a.Hh - 3, Pw = a.Wh - 3, P = Ph * Pw;
+  hipLaunchKernelGGL(head_linear_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.dh, a.dwl,
+                     a.dbl, a.n, P, a.sigmoid);
+  GI_LAUNCH_CHECK();
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  const int64_t total = (int64_t)a.n * a.Hh * a.Wh * (a.c / epc);
+  const int grid = grid_for(total, 256, 4096);
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(head_dgrad_kernel<half_t>, dim3(grid), dim3(256), 0, st, a.dh, a.w5, (char*)a.da4, a.n, a.Hh, a.Wh, a.c, a.loss_scale);
+  else
+    hipLaunchKernelGGL(head_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, a.dh, a.w5, (char*)a.da4, a.n, a.Hh, a.Wh, a.c, a.loss_scale);
+  GI_LAUNCH_CHECK();
+  if (a.dw5) {
+    dim3 g((16 * (a.c / epc) + 255) / 256, a.n);
+    if (dtype == GI_F16)
+      hipLaunchKernelGGL(head_wgrad_kernel<half_t>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
+    else
+      hipLaunchKernelGGL(head_wgrad_kernel<float>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
+    GI_LAUNCH_CHECK();
+  }
+  return GI_OK;
+}

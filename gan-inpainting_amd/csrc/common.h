@@ -1,0 +1,188 @@
+// Shared definitions for libganinpaint (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <type_traits>
+
+#include "../../include/ganinpaint.h"
+
+typedef _Float16 half_t;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));  // one 16-byte chunk (native vector: SROA-friendly)
+typedef float f16_t __attribute__((ext_vector_type(16)));
+
+void gi_set_error(const char* fmt, ...);
+
+// compile-time unrolled loop: f(std::integral_constant<int, i>) for i in [0, N). Register arrays
+// indexed through it never fall back to scratch memory.
+template <int N, typename F>
+__host__ __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+#define GI_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      gi_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return GI_ERR_HIP;                                                              \
+    }                                                                                 \
+  } while (0)
+
+#define GI_LAUNCH_CHECK()                                                             \
+  do {                                                                                \
+    hipError_t _e = hipGetLastError();                                                \
+    if (_e != hipSuccess) {                                                           \
+      gi_set_error("%s:%d: kernel launch -> %s", __FILE__, __LINE__, hipGetErrorString(_e)); \
+      return GI_ERR_HIP;                                                              \
+    }                                                                                 \
+  } while (0)
+
+#define GI_REQUIRE(cond, ...)                                                         \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      gi_set_error(__VA_ARGS__);                                                      \
+      return GI_ERR_INVALID;                                                          \
+    }                                                                                 \
+  } while (0)
+
+#define GI_TRY(expr)                \
+  do {                              \
+    int _s = (expr);                \
+    if (_s != GI_OK) return _s;     \
+  } while (0)
+
+struct gi_ctx {
+  int device;
+  hipStream_t stream;
+};
+
+static inline size_t gi_dtype_size(int dtype) { return dtype == GI_F16 ? 2 : 4; }
+static inline int64_t gi_align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+static inline int gi_ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static inline bool gi_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// ------------------------------------------------------------------------------------------
+// kernel launch wrappers (ops_*.hip). All tensors NHWC, element type T selected by dtype.
+// ------------------------------------------------------------------------------------------
+
+// Implicit-GEMM geometry shared by the strided conv ("CONV": gathers a 4x4 window of the
+// large-resolution tensor) and the transposed conv ("PHASE": four 2x2 sub-pixel convolutions of
+// the small-resolution tensor). Rows of the GEMM are always small-resolution pixels (n,y,x).
+struct IgemmArgs {
+  const void* in;      // CONV: large tensor (n,2Hs,2Ws,cin) ; PHASE: small tensor (n,Hs,Ws,cin)
+  const void* w;       // CONV: T [cout][16*cin] ; PHASE: T [4][cout][4*cin]
+  void* out;           // CONV: small tensor (n,Hs,Ws,cout) ; PHASE: large tensor (n,2Hs,2Ws,cout)
+  const float* bias;   // [cout] or null
+  float* partials;     // [tiles][2][cout] column sum / sum of squares, or null
+  float* ws;           // fp32 split-K scratch (>= out pixels * cout floats) or null
+  int64_t ws_bytes;
+  int n, Hs, Ws;       // small-resolution geometry
+  int cin, ldin, coffin;
+  int cout, ldout, coffout;
+  int relu_in;         // relu applied to `in` while staging
+  int act_out;         // gi_act on the result
+  int force_splitk;    // 0 = heuristic, >0 forces that split
+  int ntiles_out;      // (returned) number of partial rows written
+};
+int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
+
+struct WgradArgs {
+  const void* S;   // small tensor (n,Hs,Ws,ca), ld=ldS, channel offset coffS
+  const void* L;   // large tensor (n,2Hs,2Ws,cb), ld=ldL, channel offset coffL
+  float* dW;       // fp32 [ca][16][cb], accumulated with atomics
+  int n, Hs, Ws;
+  int ca, ldS, coffS;
+  int cb, ldL, coffL;
+  int relu_S;
+  float scale;
+};
+int op_wgrad(hipStream_t st, int dtype, const WgradArgs& a);
+
+// single-channel-side kernels (generator first conv / last transposed conv, discriminator first
+// conv): weights fp32 [c][16] (= [a][ky][kx][b] with b == 1)
+// out[p][c] = act(sum_tap img[n,2y-1+ky,2x-1+kx] * w[c][tap])      img fp32 (n,2Hs,2Ws)
+int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs,
+                 int Ws, int c, int ldout, int coffout, int act_out, float in_scale);
+// img[n,Y,X] = post( bias + sum_{c,tap} relu?(X[p][c]) * w[c][tap] ) (overlap-add of the 4x4 taps)
+// post: 0 none, 1 tanh. img fp32 (n,2Hs,2Ws); out_scale multiplies the result (loss-scale removal)
+int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img,
+                  int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale);
+// dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx]
+int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws,
+                int c, int ldx, int coffx, int relu_in, float scale, float img_scale);
+
+// BatchNorm helpers -------------------------------------------------------------------------
+// partials [rows][2][c] -> scale/shift (y = x*scale + shift), saved mean / invstd; train mode also
+// updates running stats (momentum 0.1, unbiased variance), eval mode uses the running stats.
+int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64_t count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float* scale, float* shift,
+                   float* save_mean, float* save_invstd, int train, float momentum, float eps);
+// y[p*ldy+coffy+c] = drop( act( x[p*c+..]*scale[c] + shift[c] ) ) ; x dense (ld = c)
+int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
+                const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale);
+// column sum / sumsq of a dense (pixels,c) tensor -> partials [blocks][2][c]; returns rows in *rows_out
+int op_col_stats(hipStream_t st, int dtype, const void* x, int64_t pixels, int c, float* partials, int* rows_out);
+
+// backward through [drop] -> act -> [BN]:  dz = (g1 + g2*[y>0]) * slope(y) * drop_scale
+//   slope(y): act==LRELU: y>0?1:0.2 ; RELU: [y>0] ; NONE: 1
+// pass 1 (has_bn): partial sums of dz and dz*xhat ; pass 2: dx = scale_bn*(dz - mean_dz - xhat*mean_dzxhat)
+struct ActBnBwdArgs {
+  const void* g1; int ldg1, coffg1;   // may be null
+  const void* g2; int ldg2, coffg2;   // may be null (masked by [y>0])
+  const void* y;  int ldy, coffy;     // saved activation output (for the masks)
+  const void* x;                      // raw pre-BN tensor, dense (ld=c); null when !has_bn
+  void* dx;                           // dense (ld=c) result
+  int64_t pixels; int c;
+  int act; float drop_scale;
+  int has_bn;
+  const float* gamma; const float* save_mean; const float* save_invstd;
+  float* dgamma; float* dbeta;        // accumulated (+=) with 1/loss_scale when non-null
+  float inv_loss_scale;
+  float* partials;                    // scratch [blocks][2][c]
+  float* sums;                        // scratch [2][c]
+};
+int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a);
+
+// discriminator head: conv(512->1,k4,s1,p0) + Flatten + Linear(P,1) [+ sigmoid]
+struct HeadArgs {
+  const void* a4;      // (n,Hh,Wh,c) T dense
+  const float* w5;     // [16][c]  (= [1][ky][kx][c])
+  const float* wl;     // [P]
+  const float* bl;     // [1]
+  float* h;            // (n,P) conv output (saved)
+  float* out;          // (n,1)
+  int n, Hh, Wh, c, sigmoid;
+};
+int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a);
+struct HeadBwdArgs {
+  const void* a4; const float* w5; const float* wl; const float* h; const float* out;
+  const float* dy;     // (n,1) grad wrt out
+  void* da4;           // (n,Hh,Wh,c) T, scaled by loss_scale
+  float* dw5; float* dwl; float* dbl;   // accumulated, may be null (frozen)
+  float* dh;           // scratch (n,P)
+  int n, Hh, Wh, c, sigmoid;
+  float loss_scale;
+};
+int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a);
+
+// weight packing / conversions
+int op_pack_weights(hipStream_t st, int dtype, const float* w, int ca, int cb, void* w_packed, void* w_phase);
+int op_convert(hipStream_t st, int dtype, const float* src, void* dst, int64_t count);
+int op_convert_back(hipStream_t st, int dtype, const void* src, float* dst, int64_t count);
+int op_tanh_bwd(hipStream_t st, const float* dy, const float* y, float* dx, int64_t count, float scale);
+int op_fill_dropout(hipStream_t st, uint8_t* mask_nhwc, int64_t count, uint64_t seed, float p);
+int op_mask_nchw_to_nhwc(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int c, int hw, int to_nhwc);

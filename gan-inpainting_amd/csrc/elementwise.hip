@@ -1,0 +1,670 @@
+// HBM-bound elementwise and reduction kernels: BatchNorm2d (statistics finalize / apply / backward),
+// activation masks, dropout, mask compositing, reconstruction and adversarial losses, fused
+// optimizers, gradient statistics, weight packing. All reductions are two-stage and deterministic
+// (per-block partials + fixed-order final sum) except where an accumulate-into-gradient semantic
+// makes a float atomic the natural form.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+
+template <typename T, int EPC>
+__device__ __forceinline__ void load_vec(const char* base, int64_t elem_off, float (&v)[EPC]) {
+  if constexpr (std::is_same<T, half_t>::value) {
+    const h8_t h = *(const h8_t*)(base + elem_off * 2);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = (float)h[e];
+  } else {
+    const f4_t f = *(const f4_t*)(base + elem_off * 4);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = f[e];
+  }
+}
+template <typename T, int EPC>
+__device__ __forceinline__ void store_vec(char* base, int64_t elem_off, const float (&v)[EPC]) {
+  if constexpr (std::is_same<T, half_t>::value) {
+    h8_t h;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) h[e] = (half_t)v[e];
+    *(h8_t*)(base + elem_off * 2) = h;
+  } else {
+    *(f4_t*)(base + elem_off * 4) = f4_t{v[0], v[1], v[2], v[3]};
+  }
+}
+
+// ---- BatchNorm statistics --------------------------------------------------------------------
+// partials [rows][2][c] -> per-channel scale/shift (+ running-stat update in train mode).
+// nn.BatchNorm2d semantics (lib/models/networks.py:38): biased variance for normalisation,
+// unbiased for running_var, momentum 0.1, eps 1e-5.
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials, int rows, int c, float count,
+                                                          const float* gamma, const float* beta, float* rmean,
+                                                          float* rvar, float* scale, float* shift, float* smean,
+                                                          float* sinv, int train, float momentum, float eps) {
+  __shared__ double rs[256], rq[256];
+  const int ch = blockIdx.x;
+  float mean, var;
+  if (train) {
+    double s = 0.0, q = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      s += (double)partials[((int64_t)r * 2) * c + ch];
+      q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
+    }
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+      __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const double m = rs[0] / count;
+    double v = rq[0] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    const float unbiased = count > 1.f ? (float)(v * (double)count / ((double)count - 1.0)) : var;
+    rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean;
+    rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * unbiased;
+  } else {
+    if (threadIdx.x != 0) return;
+    mean = rmean[ch];
+    var = rvar[ch];
+  }
+  const float inv = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[ch] * inv;
+  scale[ch] = sc;
+  shift[ch] = beta[ch] - mean * sc;
+  smean[ch] = mean;
+  sinv[ch] = inv;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, int64_t pixels, int c, int ldy, int coffy,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int act, const uint8_t* drop, float drop_scale) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cpp = c / EPC;
+  const int64_t total = pixels * cpp;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(gid % cpp);
+    const int64_t pix = gid / cpp;
+    float v[EPC];
+    load_vec<T, EPC>(x, pix * c + cc * EPC, v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float t = scale ? fmaf(v[e], scale[cc * EPC + e], shift[cc * EPC + e]) : v[e];
+      if (act == GI_ACT_RELU) t = t > 0.f ? t : 0.f;
+      else if (act == GI_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
+      if (drop) t = drop[pix * c + cc * EPC + e] ? t * drop_scale : 0.f;
+      v[e] = t;
+    }
+    store_vec<T, EPC>(y, pix * ldy + coffy + cc * EPC, v);
+  }
+}
+
+// column sum / sumsq of a dense (pixels,c) tensor -> partials [blocks][2][c]
+template <typename T>
+__global__ void __launch_bounds__(256) col_stats_kernel(const char* x, int64_t pixels, int c, float* partials,
+                                                        int rows_per_block) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ float red[2 * 256 * EPC];
+  const int Q = c / EPC, RL = 256 / Q;
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(pixels, r0 + rows_per_block);
+  float s[EPC], sq[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s[e] = sq[e] = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    float v[EPC];
+    load_vec<T, EPC>(x, r * c + q * EPC, v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s[e] += v[e]; sq[e] = fmaf(v[e], v[e], sq[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { red[threadIdx.x * EPC + e] = s[e]; red[256 * EPC + threadIdx.x * EPC + e] = sq[e]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < RL; ++i)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { s[e] += red[(i * Q + q) * EPC + e]; sq[e] += red[256 * EPC + (i * Q + q) * EPC + e]; }
+    float* ps = partials + ((int64_t)blockIdx.x * 2) * c + q * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { ps[e] = s[e]; ps[c + e] = sq[e]; }
+  }
+}
+
+// ---- backward through [dropout] -> activation -> [BatchNorm] ---------------------------------
+struct BwdP {
+  const char* g1; int ldg1, coffg1;
+  const char* g2; int ldg2, coffg2;
+  const char* y; int ldy, coffy;
+  const char* x;
+  char* dx;
+  int64_t pixels; int c; int act; float drop_scale;
+  const float* gamma; const float* mean; const float* inv;
+  float* partials; const float* sums;
+  int rows_per_block;
+};
+
+template <typename T, int EPC>
+__device__ __forceinline__ void compute_dz(const BwdP& p, int64_t pix, int ch0, float (&dz)[EPC]) {
+  float yv[EPC];
+  load_vec<T, EPC>(p.y, pix * p.ldy + p.coffy + ch0, yv);
+  float g[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+  if (p.g1) load_vec<T, EPC>(p.g1, pix * p.ldg1 + p.coffg1 + ch0, g);
+  if (p.g2) {
+    float g2[EPC];
+    load_vec<T, EPC>(p.g2, pix * p.ldg2 + p.coffg2 + ch0, g2);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) g[e] += yv[e] > 0.f ? g2[e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    float sl = 1.f;
+    if (p.act == GI_ACT_LRELU) sl = yv[e] > 0.f ? 1.f : 0.2f;
+    else if (p.act == GI_ACT_RELU) sl = yv[e] > 0.f ? 1.f : 0.f;
+    dz[e] = g[e] * sl * p.drop_scale;
+  }
+}
+
+// pass 1: partial sums of dz and dz*xhat
+template <typename T>
+__global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ float red[2 * 256 * EPC];
+  const int Q = p.c / EPC, RL = 256 / Q;
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block, r1 = min(p.pixels, r0 + p.rows_per_block);
+  float s[EPC], sx[EPC], mu[EPC], iv[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { s[e] = sx[e] = 0.f; mu[e] = p.mean[q * EPC + e]; iv[e] = p.inv[q * EPC + e]; }
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    float dz[EPC], xv[EPC];
+    compute_dz<T, EPC>(p, r, q * EPC, dz);
+    load_vec<T, EPC>(p.x, r * p.c + q * EPC, xv);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s[e] += dz[e]; sx[e] = fmaf(dz[e], (xv[e] - mu[e]) * iv[e], sx[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { red[threadIdx.x * EPC + e] = s[e]; red[256 * EPC + threadIdx.x * EPC + e] = sx[e]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < RL; ++i)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { s[e] += red[(i * Q + q) * EPC + e]; sx[e] += red[256 * EPC + (i * Q + q) * EPC + e]; }
+    float* ps = p.partials + ((int64_t)blockIdx.x * 2) * p.c + q * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { ps[e] = s[e]; ps[p.c + e] = sx[e]; }
+  }
+}
+
+// partials [rows][2][c] -> sums [2][c]; also accumulates dgamma/dbeta
+__global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, int rows, int c, float* sums, float* dgamma,
+                                                       float* dbeta, float inv_loss_scale) {
+  __shared__ double rs[256], rq[256];
+  const int ch = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    s += (double)partials[((int64_t)r * 2) * c + ch];
+    q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
+  }
+  rs[threadIdx.x] = s;
+  rq[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sums[ch] = (float)rs[0];
+    sums[c + ch] = (float)rq[0];
+    if (dbeta) dbeta[ch] += (float)rs[0] * inv_loss_scale;
+    if (dgamma) dgamma[ch] += (float)rq[0] * inv_loss_scale;
+  }
+}
+
+// pass 2 (or the only pass when there is no BN): writes dx
+template <typename T, int HAS_BN>
+__global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cpp = p.c / EPC;
+  const int64_t total = p.pixels * cpp;
+  const float invM = 1.f / (float)p.pixels;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(gid % cpp);
+    const int64_t pix = gid / cpp;
+    float dz[EPC];
+    compute_dz<T, EPC>(p, pix, cc * EPC, dz);
+    if (HAS_BN) {
+      float xv[EPC];
+      load_vec<T, EPC>(p.x, pix * p.c + cc * EPC, xv);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int ch = cc * EPC + e;
+        const float xh = (xv[e] - p.mean[ch]) * p.inv[ch];
+        dz[e] = p.gamma[ch] * p.inv[ch] * (dz[e] - p.sums[ch] * invM - xh * p.sums[p.c + ch] * invM);
+      }
+    }
+    store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, dz);
+  }
+}
+
+// ---- mask pipeline (bit-exact: selects / multiplies by 0 or 1) --------------------------------
+__global__ void __launch_bounds__(256) mask_apply_kernel(const float* ground, const float* mask, float* mask_c,
+                                                         float* masked, int64_t count, int do_ceil) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float m = do_ceil ? ceilf(mask[i]) : mask[i];
+    if (mask_c) mask_c[i] = m;
+    masked[i] = ground[i] * (1.f - m);
+  }
+}
+__global__ void __launch_bounds__(256) mask_composite_kernel(const float* masked, const float* gen, const float* mask_c,
+                                                             float* out, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    out[i] = masked[i] + gen[i] * mask_c[i];   // two roundings like the reference (mul, then add)
+}
+__global__ void __launch_bounds__(256) mul_kernel(const float* a, const float* b, float* out, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) out[i] = a[i] * b[i];
+}
+__global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* dy, const float* y, float* dx, int64_t count, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    dx[i] = dy[i] * (1.f - y[i] * y[i]) * scale;
+}
+
+// ---- reconstruction losses --------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// kind: 0 sum|a-b| ; 1 sum (a-b)^2 ; 2/3 masked versions (y*m - yhat*m), second sum = count(m != 0)
+__global__ void __launch_bounds__(256) loss_partial_kernel(const float* a, const float* b, const float* m, int64_t count,
+                                                           int kind, float* scratch) {
+  __shared__ double sh[4];
+  double s = 0.0, cnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    float d;
+    if (m) {
+      const float mm = m[i];
+      d = b[i] * mm - a[i] * mm;
+      cnt += (mm != 0.f) ? 1.0 : 0.0;
+    } else {
+      d = a[i] - b[i];
+    }
+    s += (kind & 1) ? (double)d * d : (double)fabsf(d);
+  }
+  s = block_sum(s, sh);
+  cnt = block_sum(cnt, sh);
+  if (threadIdx.x == 0) { scratch[blockIdx.x * 2] = (float)s; scratch[blockIdx.x * 2 + 1] = (float)cnt; }
+}
+// mode: 0 mean ; 1 sqrt(mean + eps)
+__global__ void __launch_bounds__(256) loss_final_kernel(const float* scratch, int nblocks, double denom, int use_cnt,
+                                                         int mode, float eps, float* loss_out) {
+  __shared__ double sh[4];
+  double s = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { s += scratch[i * 2]; c += scratch[i * 2 + 1]; }
+  s = block_sum(s, sh);
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    const double d = use_cnt ? c : denom;
+    double l = s / d;
+    if (mode == 1) l = sqrt(l + (double)eps);
+    loss_out[0] = (float)l;
+    loss_out[1] = (float)d;   // denominator kept for the gradient kernel
+  }
+}
+// gkind: 0 L1 ; 1 MSE ; 2 RMSE  (masked when m != null: gradient w.r.t. yhat = a)
+__global__ void __launch_bounds__(256) loss_grad_kernel(const float* a, const float* b, const float* m, int64_t count,
+                                                        int gkind, const float* loss, float gscale, float* grad) {
+  const float l = loss[0], den = loss[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    float d, mm = 1.f;
+    if (m) { mm = m[i]; d = a[i] * mm - b[i] * mm; }
+    else d = a[i] - b[i];
+    float g;
+    if (gkind == 0) g = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / den;
+    else if (gkind == 1) g = 2.f * d / den;
+    else g = d / (den * l);
+    grad[i] = g * mm * gscale;
+  }
+}
+
+// adversarial losses on (n,) predictions
+__global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n, int kind, float target, float* loss_out,
+                                                       float* grad, float gscale) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float p = pred[i];
+    float l, g;
+    if (kind == 0) {  // nn.BCELoss: log clamped at -100; backward (p-t)/max(p(1-p),1e-12)
+      const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+      l = -(target * lp + (1.f - target) * l1p);
+      g = (p - target) / fmaxf(p * (1.f - p), 1e-12f);
+    } else if (kind == 1) {
+      l = (p - target) * (p - target);
+      g = 2.f * (p - target);
+    } else {
+      l = p;
+      g = 1.f;
+    }
+    s += l;
+    if (grad) grad[i] = g / (float)n * gscale;
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) loss_out[0] = (float)(s / n);
+}
+
+// ---- optimizers --------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t count, float lr,
+                                                   float b1, float b2, float eps, float bc1, float sqrt_bc2, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float gg = g[i] * gs;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / sqrt_bc2 + eps;
+    p[i] = p[i] - (lr / bc1) * (mm / denom);
+  }
+}
+__global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, float* sq, int64_t count, float lr,
+                                                      float alpha, float eps, float clampv, float gs) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float gg = g[i] * gs;
+    const float s = alpha * sq[i] + (1.f - alpha) * gg * gg;
+    sq[i] = s;
+    float w = p[i] - lr * (gg / (sqrtf(s) + eps));
+    if (clampv > 0.f) w = fminf(fmaxf(w, -clampv), clampv);
+    p[i] = w;
+  }
+}
+__global__ void __launch_bounds__(256) clamp_kernel(float* p, int64_t count, float lo, float hi) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+// grid (slices, nseg): out[s] += sum|g| over slice / len
+__global__ void __launch_bounds__(256) absmean_kernel(const float* g, const int64_t* off, const int64_t* len, float* out) {
+  __shared__ double sh[4];
+  const int sgm = blockIdx.y;
+  const int64_t o = off[sgm], l = len[sgm];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < l; i += (int64_t)gridDim.x * 256) s += fabsf(g[o + i]);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0 && s != 0.0) atomicAdd(out + sgm, (float)(s / (double)l));
+}
+
+// ---- weight packing / conversion ---------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) convert_kernel(const float* src, T* dst, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = (T)src[i];
+}
+template <typename T>
+__global__ void __launch_bounds__(256) convert_back_kernel(const T* src, float* dst, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) dst[i] = (float)src[i];
+}
+// w [a][16][b] -> wph [4 phases][b][4 taps][a], tap t=(ty,tx) of phase (py,px) is (ky,kx)=(1-py+2ty, 1-px+2tx).
+// 32x32 (a,b) tile transposed through LDS so that both the read (b fastest) and the write
+// (a fastest) are coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_phase_kernel(const float* w, T* wph, int ca, int cb) {
+  __shared__ float tile[32][33];
+  const int k16 = blockIdx.z;   // ph*4 + t
+  const int ph = k16 >> 2, t = k16 & 3;
+  const int ky = 1 - (ph >> 1) + 2 * (t >> 1), kx = 1 - (ph & 1) + 2 * (t & 1);
+  const int a0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int a = a0 + r, b = b0 + tx;
+    tile[r][tx] = (a < ca && b < cb) ? w[((int64_t)a * 16 + ky * 4 + kx) * cb + b] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int b = b0 + r, a = a0 + tx;
+    if (a < ca && b < cb) wph[(((int64_t)ph * cb + b) * 4 + t) * ca + a] = (T)tile[tx][r];
+  }
+}
+
+__global__ void __launch_bounds__(256) dropout_fill_kernel(uint8_t* mask, int64_t count, uint64_t seed, uint32_t thresh) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);   // splitmix64 of a counter
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    mask[i] = ((uint32_t)(z >> 32) >= thresh) ? 1 : 0;   // keep with probability 1-p
+  }
+}
+__global__ void __launch_bounds__(256) mask_layout_kernel(const uint8_t* src, uint8_t* dst, int n, int c, int hw, int to_nhwc) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i indexes the NHWC tensor
+    const int ch = (int)(i % c);
+    const int64_t t = i / c;
+    const int p = (int)(t % hw);
+    const int nn = (int)(t / hw);
+    const int64_t j = ((int64_t)nn * c + ch) * hw + p;   // NCHW index
+    if (to_nhwc) dst[i] = src[j];
+    else dst[j] = src[i];
+  }
+}
+
+inline int nblocks(int64_t count, int per_thread = 4) {
+  int64_t b = (count + 256ll * per_thread - 1) / (256ll * per_thread);
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+// =================================================================================================
+int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64_t count, const float* gamma,
+                   const float* beta, float* running_mean, float* running_var, float* scale, float* shift,
+                   float* save_mean, float* save_invstd, int train, float momentum, float eps) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, st, partials, rows, c, (float)count, gamma, beta,
+                     running_mean, running_var, scale, shift, save_mean, save_invstd, train, momentum, eps);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
+                const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  GI_REQUIRE(c % epc == 0, "bn_apply: c=%d", c);
+  const int grid = nblocks(pixels * (c / epc), 2);
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(bn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+static int rows_per_block_for(int64_t pixels, int* blocks_out) {
+  int64_t rpb = (pixels + 1023) / 1024;
+  if (rpb < 32) rpb = 32;
+  *blocks_out = (int)((pixels + rpb - 1) / rpb);
+  return (int)rpb;
+}
+
+int op_col_stats(hipStream_t st, int dtype, const void* x, int64_t pixels, int c, float* partials, int* rows_out) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  const int Q = c / epc;
+  GI_REQUIRE(c % epc == 0 && gi_is_pow2(Q) && Q <= 256, "col_stats: c=%d unsupported", c);
+  int blocks;
+  const int rpb = rows_per_block_for(pixels, &blocks);
+  if (dtype == GI_F16)
+    hipLaunchKernelGGL(col_stats_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const char*)x, pixels, c, partials, rpb);
+  else
+    hipLaunchKernelGGL(col_stats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const char*)x, pixels, c, partials, rpb);
+  GI_LAUNCH_CHECK();
+  *rows_out = blocks;
+  return GI_OK;
+}
+
+int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  const int Q = a.c / epc;
+  GI_REQUIRE(a.c % epc == 0 && gi_is_pow2(Q) && Q <= 256, "act_bn_bwd: c=%d unsupported", a.c);
+  BwdP p;
+  p.g1 = (const char*)a.g1; p.ldg1 = a.ldg1; p.coffg1 = a.coffg1;
+  p.g2 = (const char*)a.g2; p.ldg2 = a.ldg2; p.coffg2 = a.coffg2;
+  p.y = (const char*)a.y; p.ldy = a.ldy; p.coffy = a.coffy;
+  p.x = (const char*)a.x; p.dx = (char*)a.dx;
+  p.pixels = a.pixels; p.c = a.c; p.act = a.act; p.drop_scale = a.drop_scale;
+  p.gamma = a.gamma; p.mean = a.save_mean; p.inv = a.save_invstd;
+  p.partials = a.partials; p.sums = a.sums;
+  int blocks = 0;
+  p.rows_per_block = rows_per_block_for(a.pixels, &blocks);
+  const int grid2 = nblocks(a.pixels * Q, 2);
+  if (a.has_bn) {
+    if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p);
+    GI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, blocks, a.c, a.sums, a.dgamma, a.dbeta, a.inv_loss_scale);
+    GI_LAUNCH_CHECK();
+    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1>), dim3(grid2), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1>), dim3(grid2), dim3(256), 0, st, p);
+  } else {
+    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 0>), dim3(grid2), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 0>), dim3(grid2), dim3(256), 0, st, p);
+  }
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_pack_weights(hipStream_t st, int dtype, const float* w, int ca, int cb, void* w_packed, void* w_phase) {
+  const int64_t count = (int64_t)ca * 16 * cb;
+  if (w_packed) GI_TRY(op_convert(st, dtype, w, w_packed, count));
+  if (w_phase) {
+    dim3 grid((ca + 31) / 32, (cb + 31) / 32, 16);
+    if (dtype == GI_F16) hipLaunchKernelGGL(pack_phase_kernel<half_t>, grid, dim3(256), 0, st, w, (half_t*)w_phase, ca, cb);
+    else hipLaunchKernelGGL(pack_phase_kernel<float>, grid, dim3(256), 0, st, w, (float*)w_phase, ca, cb);
+    GI_LAUNCH_CHECK();
+  }
+  return GI_OK;
+}
+
+int op_convert(hipStream_t st, int dtype, const float* src, void* dst, int64_t count) {
+  if (dtype == GI_F16) hipLaunchKernelGGL(convert_kernel<half_t>, dim3(nblocks(count)), dim3(256), 0, st, src, (half_t*)dst, count);
+  else hipLaunchKernelGGL(convert_kernel<float>, dim3(nblocks(count)), dim3(256), 0, st, src, (float*)dst, count);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int op_convert_back(hipStream_t st, int dtype, const void* src, float* dst, int64_t count) {
+  if (dtype == GI_F16) hipLaunchKernelGGL(convert_back_kernel<half_t>, dim3(nblocks(count)), dim3(256), 0, st, (const half_t*)src, dst, count);
+  else hipLaunchKernelGGL(convert_back_kernel<float>, dim3(nblocks(count)), dim3(256), 0, st, (const float*)src, dst, count);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int op_tanh_bwd(hipStream_t st, const float* dy, const float* y, float* dx, int64_t count, float scale) {
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(nblocks(count)), dim3(256), 0, st, dy, y, dx, count, scale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int op_fill_dropout(hipStream_t st, uint8_t* mask, int64_t count, uint64_t seed, float p) {
+  const double t = (double)p * 4294967296.0;
+  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  hipLaunchKernelGGL(dropout_fill_kernel, dim3(nblocks(count)), dim3(256), 0, st, mask, count, seed, thresh);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int op_mask_nchw_to_nhwc(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int c, int hw, int to_nhwc) {
+  hipLaunchKernelGGL(mask_layout_kernel, dim3(nblocks((int64_t)n * c * hw)), dim3(256), 0, st, src, dst, n, c, hw, to_nhwc);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+// ---- C-ABI entry points that are pure elementwise ops -------------------------------------------
+extern "C" {
+
+int gi_mask_apply(gi_ctx* ctx, const float* ground, const float* mask, float* mask_c, float* masked, int64_t count, int do_ceil) {
+  hipLaunchKernelGGL(mask_apply_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, ground, mask, mask_c, masked, count, do_ceil);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_mask_composite(gi_ctx* ctx, const float* masked, const float* gen, const float* mask_c, float* inpainted, int64_t count) {
+  hipLaunchKernelGGL(mask_composite_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, masked, gen, mask_c, inpainted, count);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_mul(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count) {
+  hipLaunchKernelGGL(mul_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, a, b, out, count);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+static int loss_generic(gi_ctx* ctx, const float* a, const float* b, const float* m, int64_t count, int pkind, int mode,
+                        int gkind, float eps, float* loss_out, float* grad, float gscale, float* scratch) {
+  GI_REQUIRE(scratch != nullptr, "loss: scratch is required (>= 4096 floats)");
+  const int nb = nblocks(count) > 1024 ? 1024 : nblocks(count);
+  hipLaunchKernelGGL(loss_partial_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, m, count, pkind, scratch);
+  GI_LAUNCH_CHECK();
+  // loss_out needs two floats (value, denominator): stage in scratch tail then copy the value
+  float* tmp = scratch + 2048;
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, ctx->stream, scratch, nb, (double)count, m ? 1 : 0, mode, eps, tmp);
+  GI_LAUNCH_CHECK();
+  GI_HIP(hipMemcpyAsync(loss_out, tmp, sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  if (grad) {
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, a, b, m, count, gkind, tmp, gscale, grad);
+    GI_LAUNCH_CHECK();
+  }
+  return GI_OK;
+}
+
+int gi_loss_l1(gi_ctx* ctx, const float* a, const float* b, int64_t count, float* loss_out, float* grad_a, float gscale, float* scratch) {
+  return loss_generic(ctx, a, b, nullptr, count, 0, 0, 0, 0.f, loss_out, grad_a, gscale, scratch);
+}
+int gi_loss_mse(gi_ctx* ctx, const float* a, const float* b, int64_t count, float* loss_out, float* grad_a, float gscale, float* scratch) {
+  return loss_generic(ctx, a, b, nullptr, count, 1, 0, 1, 0.f, loss_out, grad_a, gscale, scratch);
+}
+int gi_loss_rmse(gi_ctx* ctx, const float* a, const float* b, int64_t count, float eps, float* loss_out, float* grad_a, float gscale, float* scratch) {
+  return loss_generic(ctx, a, b, nullptr, count, 1, 1, 2, eps, loss_out, grad_a, gscale, scratch);
+}
+int gi_loss_local(gi_ctx* ctx, const float* yhat, const float* y, const float* mask, int64_t count, int kind, float* loss_out,
+                  float* grad_yhat, float gscale, float* scratch) {
+  GI_REQUIRE(kind >= 0 && kind <= 2, "loss_local: kind=%d", kind);
+  return loss_generic(ctx, yhat, y, mask, count, kind == 0 ? 0 : 1, kind == 2 ? 1 : 0, kind, 1e-16f, loss_out, grad_yhat, gscale, scratch);
+}
+int gi_loss_adv(gi_ctx* ctx, const float* pred, int n, int kind, float target, float* loss_out, float* grad_pred, float gscale) {
+  GI_REQUIRE(kind >= 0 && kind <= 2 && n > 0, "loss_adv: kind=%d n=%d", kind, n);
+  hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, ctx->stream, pred, n, kind, target, loss_out, grad_pred, gscale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int gi_adam_step(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                 float eps, int step, float grad_scale) {
+  GI_REQUIRE(step >= 1, "adam: step=%d must be >= 1", step);
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, m, v, count, lr, beta1, beta2, eps,
+                     (float)bc1, (float)sqrt(bc2), grad_scale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_rmsprop_step(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps, float clamp,
+                    float grad_scale) {
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, sq, count, lr, alpha, eps, clamp, grad_scale);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi) {
+  hipLaunchKernelGGL(clamp_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, count, lo, hi);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_grad_absmean(gi_ctx* ctx, const float* g, const int64_t* seg_off, const int64_t* seg_len, int nseg, float* out) {
+  GI_REQUIRE(nseg > 0, "grad_absmean: nseg=%d", nseg);
+  GI_HIP(hipMemsetAsync(out, 0, sizeof(float) * nseg, ctx->stream));
+  hipLaunchKernelGGL(absmean_kernel, dim3(32, nseg), dim3(256), 0, ctx->stream, g, seg_off, seg_len, out);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+}  // extern "C"

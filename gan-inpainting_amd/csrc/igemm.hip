@@ -1,0 +1,470 @@
+// MFMA implicit-GEMM kernels for the 4x4 / stride-2 / pad-1 convolution family (gfx950).
+//
+//   CONV  : out[n,y,x,a]        = sum_{ky,kx,b} in[n,2y-1+ky,2x-1+kx,b] * W[a][ky][kx][b]
+//           (Conv2d forward, lib/models/networks.py:285,337-348; ConvTranspose2d input-gradient)
+//   PHASE : out[n,2y+py,2x+px,b] = sum_{ty,tx,a} in[n,y+py-ty,x+px-tx,a] * W[a][ky][kx][b],
+//           ky = 1-py+2ty, kx = 1-px+2tx   (ConvTranspose2d forward, networks.py:293-309, as four
+//           sub-pixel 2x2 convolutions; Conv2d input-gradient)
+//
+// GEMM rows are small-resolution pixels, columns are output channels, K = taps x input channels.
+// NHWC activations, K-contiguous weights. A/B tiles are staged global -> registers -> LDS
+// (128-byte K rows, XOR-swizzled 16-byte chunks for fp16; k-major padded rows for fp32),
+// double-buffered with the next tile's global loads issued before the MFMA block.
+// fp16: v_mfma_f32_16x16x32_f16, fp32: v_mfma_f32_32x32x2_f32 (exact fp32), fp32 accumulate.
+// Epilogue: optional bias + activation, per-tile column sum / sum-of-squares (BatchNorm batch
+// statistics, deterministic: no atomics), result staged through LDS and stored with 16-byte
+// coalesced rows. Small-M layers use split-K with fp32 atomics into a scratch + a finish kernel.
+#include "common.h"
+
+namespace {
+
+struct KP {
+  const char* in;
+  const char* w;
+  char* out;
+  const float* bias;
+  float* partials;
+  float* ws;
+  int M, Hs, Ws;
+  int cin, ldin, coffin;
+  int cout, ldout, coffout;
+  int Ktot, nk, splitk, kt_per_split;
+  int relu_in, act_out;
+  int Hin, Win, Hout, Wout;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ u4_t relu16(u4_t v) {
+  if constexpr (std::is_same<T, half_t>::value) {
+    h8_t h = __builtin_bit_cast(h8_t, v);
+    h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    h = __builtin_elementwise_max(h, z);
+    return __builtin_bit_cast(u4_t, h);
+  } else {
+    f4_t f = __builtin_bit_cast(f4_t, v);
+    f4_t z = {0.f, 0.f, 0.f, 0.f};
+    f = __builtin_elementwise_max(f, z);
+    return __builtin_bit_cast(u4_t, f);
+  }
+}
+
+template <typename T, int PHASE, int BM, int BN, int WGM, int WGN>
+__global__ void __launch_bounds__(256) igemm_kernel(KP p) {
+  constexpr bool F16 = std::is_same<T, half_t>::value;
+  constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
+  constexpr int BK = 8 * EPC;               // 128-byte K rows
+  constexpr int AP = BM / 32, BP = BN / 32;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TS = F16 ? 16 : 32;         // MFMA tile side
+  constexpr int MT = WM / TS, NT = WN / TS;
+  constexpr int LDA32 = BM + 1, LDB32 = BN + 1;  // fp32 k-major padded leading dims
+  constexpr int STAGE_BYTES = F16 ? (BM + BN) * 128 : 32 * (LDA32 + LDB32) * 4;
+  constexpr int A_BYTES = F16 ? BM * 128 : 32 * LDA32 * 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int chunk = tid & 7;
+  const int rbase = tid >> 3;
+
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int ks = blockIdx.z % p.splitk;
+  const int ph = blockIdx.z / p.splitk;
+  const int py = ph >> 1, px = ph & 1;
+
+  const char* wptr = p.w + (PHASE ? (int64_t)ph * p.cout * p.Ktot * (int64_t)sizeof(T) : 0);
+
+  // ---- per-row gather bases and tap-validity masks ----------------------------------------
+  int abase[AP];
+  unsigned amask[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + rbase + 32 * i;
+    abase[i] = 0;
+    amask[i] = 0;
+    if (m < p.M) {
+      const int x = m % p.Ws;
+      const int t = m / p.Ws;
+      const int y = t % p.Hs;
+      const int n = t / p.Hs;
+      if (PHASE) {
+        const int y0 = y + py, x0 = x + px;
+        abase[i] = ((n * p.Hs + y0) * p.Ws + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int iy = y0 - (tt >> 1), ix = x0 - (tt & 1);
+          if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) amask[i] |= 1u << tt;
+        }
+      } else {
+        const int y0 = 2 * y - 1, x0 = 2 * x - 1;
+        abase[i] = ((n * p.Hin + y0) * p.Win + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+          const int iy = y0 + (tt >> 2), ix = x0 + (tt & 3);
+          if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) amask[i] |= 1u << tt;
+        }
+      }
+    }
+  }
+
+  const int kt_begin = ks * p.kt_per_split;
+  const int kt_end = min(p.nk, kt_begin + p.kt_per_split);
+  int tap = (kt_begin * BK) / p.cin;
+  int c0 = (kt_begin * BK) % p.cin;
+
+  u4_t ra[AP], rb[BP];
+
+  auto gload = [&](int kt) {
+    int soff;
+    if (PHASE) soff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
+    else soff = ((tap >> 2) * p.Win + (tap & 3)) * p.ldin;
+    soff += c0 + chunk * EPC;
+    static_for<AP>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      u4_t v = u4_t{0u, 0u, 0u, 0u};
+      if ((amask[i] >> tap) & 1u) v = *(const u4_t*)(p.in + (int64_t)(abase[i] + soff) * (int64_t)sizeof(T));
+      ra[i] = v;
+    });
+    const int64_t koff = (int64_t)kt * BK + chunk * EPC;
+    static_for<BP>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const int row = n0 + rbase + 32 * i;
+      rb[i] = *(const u4_t*)(wptr + ((int64_t)row * p.Ktot + koff) * (int64_t)sizeof(T));
+    });
+    c0 += BK;
+    if (c0 >= p.cin) { c0 = 0; ++tap; }
+  };
+
+  auto lds_store = [&](int stage) {
+    char* sA = smem + stage * STAGE_BYTES;
+    char* sB = sA + A_BYTES;
+    if (p.relu_in) {
+      static_for<AP>([&](auto I) { ra[decltype(I)::value] = relu16<T>(ra[decltype(I)::value]); });
+    }
+    if constexpr (F16) {
+      static_for<AP>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int r = rbase + 32 * i;
+        *(u4_t*)(sA + r * 128 + ((chunk ^ (r & 7)) << 4)) = ra[i];
+      });
+      static_for<BP>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int r = rbase + 32 * i;
+        *(u4_t*)(sB + r * 128 + ((chunk ^ (r & 7)) << 4)) = rb[i];
+      });
+    } else {
+      float* fA = (float*)sA;
+      float* fB = (float*)sB;
+      static_for<AP>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int r = rbase + 32 * i;
+        const f4_t v = __builtin_bit_cast(f4_t, ra[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fA[(chunk * 4 + j) * LDA32 + r] = v[j];
+      });
+      static_for<BP>([&](auto I) {
+        constexpr int i = decltype(I)::value;
+        const int r = rbase + 32 * i;
+        const f4_t v = __builtin_bit_cast(f4_t, rb[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fB[(chunk * 4 + j) * LDB32 + r] = v[j];
+      });
+    }
+  };
+
+  using acc_t = typename std::conditional<F16, f4_t, f16_t>::type;
+  acc_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < (F16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int stage) {
+    const char* sA = smem + stage * STAGE_BYTES;
+    const char* sB = sA + A_BYTES;
+    if constexpr (F16) {
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        h8_t af[MT], bf[NT];
+        const int ch = k2 * 4 + (lane >> 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int r = wm * WM + mt * 16 + (lane & 15);
+          af[mt] = *(const h8_t*)(sA + r * 128 + ((ch ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int r = wn * WN + nt * 16 + (lane & 15);
+          bf[nt] = *(const h8_t*)(sB + r * 128 + ((ch ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+      }
+    } else {
+      const float* fA = (const float*)sA;
+      const float* fB = (const float*)sB;
+#pragma unroll 4
+      for (int kk = 0; kk < 16; ++kk) {
+        const int k = 2 * kk + (lane >> 5);
+        float af[MT], bf[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = fA[k * LDA32 + wm * WM + mt * 32 + (lane & 31)];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = fB[k * LDB32 + wn * WN + nt * 32 + (lane & 31)];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- main loop: one barrier per K tile, next tile's loads in flight during the MFMAs -----
+  if (kt_begin < kt_end) {
+    gload(kt_begin);
+    lds_store(0);
+    __syncthreads();
+    int stage = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = (kt + 1 < kt_end);
+      if (more) gload(kt + 1);
+      compute(stage);
+      if (more) lds_store(stage ^ 1);
+      __syncthreads();
+      stage ^= 1;
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------
+  auto elem_row = [&](int mt, int r) -> int {
+    if constexpr (F16) return wm * WM + mt * 16 + (lane >> 4) * 4 + r;
+    else return wm * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+  };
+  auto elem_col = [&](int nt) -> int {
+    if constexpr (F16) return wn * WN + nt * 16 + (lane & 15);
+    else return wn * WN + nt * 32 + (lane & 31);
+  };
+  auto out_pixel = [&](int m) -> int {
+    if (!PHASE) return m;
+    const int x = m % p.Ws;
+    const int t = m / p.Ws;
+    const int y = t % p.Hs;
+    const int n = t / p.Hs;
+    return (n * p.Hout + 2 * y + py) * p.Wout + 2 * x + px;
+  };
+  constexpr int NR = F16 ? 4 : 16;
+
+  if (p.splitk > 1) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int m = m0 + elem_row(mt, r);
+        if (m < p.M) {
+          const int64_t o = (int64_t)out_pixel(m) * p.cout + n0;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) atomicAdd(p.ws + o + elem_col(nt), acc[mt][nt][r]);
+        }
+      }
+    return;
+  }
+
+  constexpr int SPAD = 16 / (int)sizeof(T);
+  constexpr int SLD = BN + SPAD;
+  T* stg = (T*)smem;
+  float* red = (float*)(smem + (int64_t)BM * SLD * sizeof(T));  // [WGM][BN][2]
+
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = elem_col(nt);
+    const float b = p.bias ? p.bias[n0 + col] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        float v = acc[mt][nt][r] + b;
+        s += v;
+        q += v * v;
+        v = apply_act(v, p.act_out);
+        stg[elem_row(mt, r) * SLD + col] = (T)v;
+      }
+    if (p.partials) {
+      if constexpr (F16) {
+        s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (lane < 16) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+      } else {
+        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+        if (lane < 32) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+      }
+    }
+  }
+  __syncthreads();
+  if (p.partials && tid < BN) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < WGM; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
+    const int64_t trow = (int64_t)blockIdx.x + (int64_t)gridDim.x * ph;
+    p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
+    p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+  }
+  constexpr int CPRO = BN / EPC;          // 16-byte chunks per output row
+  constexpr int RPP = 256 / CPRO;         // rows per pass
+  const int oc = tid % CPRO;
+#pragma unroll 1
+  for (int r = tid / CPRO; r < BM; r += RPP) {
+    const int m = m0 + r;
+    if (m < p.M) {
+      const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * EPC;
+      *(u4_t*)(p.out + o * (int64_t)sizeof(T)) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * EPC) * sizeof(T));
+    }
+  }
+}
+
+// split-K finish: ws (fp32, dense [pixels][cout]) -> bias/act -> T out (+ column statistics)
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, const float* bias, char* out,
+                                                            float* partials, int64_t pixels, int cout,
+                                                            int ldout, int coffout, int act, int rows_per_block) {
+  __shared__ float red[2 * 256 * 4];
+  const int Q = cout / 4;            // column quads
+  const int RL = 256 / Q;            // row lanes (cout <= 1024)
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(pixels, r0 + rows_per_block);
+  f4_t b = {0.f, 0.f, 0.f, 0.f};
+  if (bias) b = *(const f4_t*)(bias + q * 4);
+  f4_t s = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  if (rl < RL) {
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      f4_t v = *(const f4_t*)(ws + r * cout + q * 4) + b;
+      s += v;
+      sq += v * v;
+      T o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (T)apply_act(v[j], act);
+      T* dst = (T*)(out + (r * ldout + coffout + q * 4) * (int64_t)sizeof(T));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dst[j] = o[j];
+    }
+  }
+  if (!partials) return;
+  // reduce over row lanes
+  for (int j = 0; j < 4; ++j) {
+    red[(threadIdx.x) * 4 + j] = s[j];
+    red[1024 + threadIdx.x * 4 + j] = sq[j];
+  }
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < RL; ++i)
+      for (int j = 0; j < 4; ++j) {
+        s[j] += red[(i * Q + q) * 4 + j];
+        sq[j] += red[1024 + (i * Q + q) * 4 + j];
+      }
+    float* ps = partials + ((int64_t)blockIdx.x * 2) * cout + q * 4;
+    for (int j = 0; j < 4; ++j) { ps[j] = s[j]; ps[cout + j] = sq[j]; }
+  }
+}
+
+template <typename T, int PHASE, int BM, int BN, int WGM, int WGN>
+int launch_cfg(hipStream_t st, const KP& kp, dim3 grid) {
+  constexpr bool F16 = std::is_same<T, half_t>::value;
+  constexpr int STAGE_BYTES = F16 ? (BM + BN) * 128 : 32 * (BM + 1 + BN + 1) * 4;
+  constexpr int EPI = BM * (BN + 16 / (int)sizeof(T)) * (int)sizeof(T) + WGM * BN * 2 * 4;
+  constexpr int LDS = (2 * STAGE_BYTES > EPI ? 2 * STAGE_BYTES : EPI);
+  auto kern = igemm_kernel<T, PHASE, BM, BN, WGM, WGN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, kp);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+template <typename T, int PHASE>
+int run(hipStream_t st, IgemmArgs& a) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int BK = 8 * EPC;
+  GI_REQUIRE(a.cin % BK == 0, "igemm: cin=%d must be a multiple of %d", a.cin, BK);
+  GI_REQUIRE(a.cout % 64 == 0, "igemm: cout=%d must be a multiple of 64", a.cout);
+  GI_REQUIRE(a.ldin % EPC == 0 && a.coffin % EPC == 0 && a.ldout % EPC == 0 && a.coffout % EPC == 0,
+             "igemm: leading dims / channel offsets must be 16-byte aligned");
+  KP kp;
+  kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out;
+  kp.bias = a.bias; kp.partials = a.partials; kp.ws = a.ws;
+  kp.M = a.n * a.Hs * a.Ws; kp.Hs = a.Hs; kp.Ws = a.Ws;
+  kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
+  kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
+  kp.Ktot = (PHASE ? 4 : 16) * a.cin;
+  kp.nk = kp.Ktot / BK;
+  kp.relu_in = a.relu_in; kp.act_out = a.act_out;
+  if (PHASE) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
+  else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
+  const int64_t in_elems = (int64_t)a.n * kp.Hin * kp.Win * a.ldin;
+  const int64_t out_pixels = (int64_t)a.n * kp.Hout * kp.Wout;
+  GI_REQUIRE(in_elems < (1ll << 31) && out_pixels * a.ldout < (1ll << 31), "igemm: tensor too large for 32-bit offsets");
+
+  const bool wide = (a.cout % 128 == 0);
+  const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+  const int phases = PHASE ? 4 : 1;
+  const int mt = (kp.M + BM - 1) / BM, nt = a.cout / BN;
+  const int tiles = mt * nt * phases;
+  int splitk = 1;
+  if (a.force_splitk > 0) splitk = a.force_splitk;
+  else if (tiles < 128 && kp.nk >= 8) {
+    splitk = (384 + tiles - 1) / tiles;
+    if (splitk > kp.nk / 4) splitk = kp.nk / 4;
+    if (splitk > 64) splitk = 64;
+    if (splitk < 1) splitk = 1;
+  }
+  if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < out_pixels * a.cout * 4)) splitk = 1;
+  kp.kt_per_split = (kp.nk + splitk - 1) / splitk;
+  splitk = (kp.nk + kp.kt_per_split - 1) / kp.kt_per_split;
+  kp.splitk = splitk;
+  if (splitk > 1) {
+    GI_HIP(hipMemsetAsync(a.ws, 0, out_pixels * a.cout * 4, st));
+    kp.partials = nullptr;
+  }
+  dim3 grid(mt, nt, phases * splitk);
+  if (wide) GI_TRY((launch_cfg<T, PHASE, 128, 128, 2, 2>(st, kp, grid)));
+  else GI_TRY((launch_cfg<T, PHASE, 256, 64, 4, 1>(st, kp, grid)));
+  a.ntiles_out = mt * phases;
+  if (splitk > 1) {
+    const int rpb = 64;
+    const int blocks = (int)((out_pixels + rpb - 1) / rpb);
+    GI_REQUIRE(a.cout <= 1024, "igemm split-K finish: cout=%d > 1024", a.cout);
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, st, a.ws, a.bias, (char*)a.out,
+                       a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb);
+    GI_LAUNCH_CHECK();
+    a.ntiles_out = blocks;
+  }
+  return GI_OK;
+}
+
+}  // namespace
+
+int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a) {
+  if (dtype == GI_F16) return phase_mode ? run<half_t, 1>(st, a) : run<half_t, 0>(st, a);
+  if (dtype == GI_F32) return phase_mode ? run<float, 1>(st, a) : run<float, 0>(st, a);
+  gi_set_error("igemm: bad dtype %d", dtype);
+  return GI_ERR_INVALID;
+}

@@ -1,0 +1,692 @@
+// Host-side schedules: which kernels run, in which order, on which buffers, for
+//   UnetGenerator      (lib/models/networks.py:216-324)  forward + backward
+//   PatchGANDiscriminator (networks.py:331-363)          forward + backward
+// Data layout in HBM (per activation slot): NHWC tensors of the compute type T; for every U-Net
+// level k one "concat buffer" C[k] = [skip a_k | decoder u_{k+1}] (2*ch_k channels) that both
+// producers write at their channel offset, so torch.cat (networks.py:324) never materialises.
+#include <string>
+#include <vector>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+struct TensorDesc {
+  std::string name;
+  int kind;  // 0 conv weight, 1 contiguous param, 2 running_mean, 3 running_var
+  int64_t shape[4];
+  int ndim;
+  int64_t offset, numel;
+};
+
+struct Conv {            // 4x4 weight [a][16][b] fp32 master at params+w_off
+  int ca = 0, cb = 0;
+  int64_t w_off = -1, bias_off = -1;
+  int64_t packed_off = -1, phase_off = -1;  // workspace offsets of the T copies (-1: b == 1 layer)
+};
+struct BN {
+  int c = 0;
+  int64_t gamma_off = -1, beta_off = -1, rmean_off = -1, rvar_off = -1;
+  int64_t stat_off = -1;  // per-slot: [scale|shift|mean|inv] * c floats (offset inside slot)
+};
+
+struct Arena {
+  int64_t size = 0;
+  int64_t take(int64_t bytes) {
+    const int64_t o = size;
+    size += gi_align_up(bytes < 16 ? 16 : bytes, 256);
+    return o;
+  }
+};
+
+}  // namespace
+
+struct gi_net {
+  gi_ctx* ctx = nullptr;
+  int kind = 0;  // 0 unet, 1 patchgan
+  int dtype = GI_F32;
+  int H = 0, W = 0, max_n = 0, n_slots = 1;
+  int train = 1;
+  float loss_scale = 1.f;
+  uint64_t drop_seed = 0x5EED0000ull, drop_counter = 0;
+  // unet
+  int nd = 0, ngf = 0;
+  float dropout_p = 0.f;
+  std::vector<int> ch, Hk, Wk;       // 1-based per level
+  std::vector<Conv> conv, up;        // 1-based
+  std::vector<BN> dnorm, unorm;      // 1-based (c == 0: absent)
+  // patchgan
+  int sigmoid = 1;
+  Conv dconv[5];                     // 1..4
+  BN dbn[5];                         // 2..4
+  int64_t w5_off = -1, wl_off = -1, bl_off = -1;
+  int P = 0, Hh = 0, Wh = 0;
+
+  std::vector<TensorDesc> tensors;
+  int64_t n_params = 0, n_buffers = 0;
+  // workspace layout
+  Arena arena;
+  int64_t slot_bytes = 0, slot_base = 0;
+  std::vector<int64_t> oC, oR, oU, oMask;  // per-slot offsets (1-based level)
+  int64_t oE = -1, oOut = -1, oX = -1, oStats = -1, oHh = -1;
+  int64_t oA[5] = {-1, -1, -1, -1, -1}, oRd[5] = {-1, -1, -1, -1, -1};
+  // shared scratch
+  std::vector<int64_t> ogC, ogA;
+  int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1;
+  int64_t part_floats = 0, split_bytes = 0;
+  std::vector<int> slot_n, slot_train;
+  std::vector<std::vector<const uint8_t*>> ext_mask;  // [slot][level]
+
+  float* params = nullptr;
+  float* grads = nullptr;
+  float* buffers = nullptr;
+  char* ws = nullptr;
+  bool bound = false;
+
+  size_t tsz() const { return gi_dtype_size(dtype); }
+  char* slot(int s, int64_t off) const { return ws + slot_base + (int64_t)s * slot_bytes + off; }
+  char* shared(int64_t off) const { return ws + off; }
+};
+
+namespace {
+
+void add_tensor(gi_net* net, const std::string& name, int kind, std::initializer_list<int64_t> shape, int64_t* off_out) {
+  TensorDesc t;
+  t.name = name;
+  t.kind = kind;
+  t.ndim = (int)shape.size();
+  t.numel = 1;
+  int i = 0;
+  for (int64_t s : shape) { t.shape[i++] = s; t.numel *= s; }
+  for (; i < 4; ++i) t.shape[i] = 1;
+  int64_t& ctr = (kind <= 1) ? net->n_params : net->n_buffers;
+  t.offset = ctr;
+  ctr += gi_align_up(t.numel, 64);
+  *off_out = t.offset;
+  net->tensors.push_back(t);
+}
+
+void add_bn(gi_net* net, const std::string& prefix, BN& bn, int c, std::vector<std::pair<std::string, BN*>>& later) {
+  bn.c = c;
+  add_tensor(net, prefix + ".weight", 1, {c}, &bn.gamma_off);
+  add_tensor(net, prefix + ".bias", 1, {c}, &bn.beta_off);
+  later.push_back({prefix, &bn});
+}
+
+int64_t max64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+// upper bound on partial-statistics rows any kernel may write for a (pixels, c) tensor
+int64_t part_rows(int64_t pixels) { return max64(pixels / 64 + 8, 1100); }
+
+}  // namespace
+
+// =================================================================================================
+// creation
+// =================================================================================================
+extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, int W, int max_n, int dtype,
+                              int n_slots, gi_net** out) {
+  GI_REQUIRE(out, "unet_create: null argument");  // ctx may be null: inventory-only handle
+  GI_REQUIRE(dtype == GI_F16 || dtype == GI_F32, "unet_create: dtype=%d", dtype);
+  GI_REQUIRE(num_downs >= 5 && num_downs <= 9, "unet_create: num_downs=%d (supported 5..9)", num_downs);
+  GI_REQUIRE(ngf % 64 == 0 && ngf >= 64, "unet_create: ngf=%d must be a multiple of 64", ngf);
+  GI_REQUIRE(gi_is_pow2(H) && gi_is_pow2(W) && (H >> num_downs) >= 1 && (W >> num_downs) >= 1,
+             "unet_create: H=%d W=%d must be powers of two >= 2^num_downs", H, W);
+  GI_REQUIRE(max_n >= 1 && n_slots >= 1 && n_slots <= 8, "unet_create: max_n=%d n_slots=%d", max_n, n_slots);
+  gi_net* net = new gi_net();
+  net->ctx = ctx; net->kind = 0; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
+  net->nd = num_downs; net->ngf = ngf; net->dropout_p = dropout_p;
+  net->loss_scale = dtype == GI_F16 ? 1024.f : 1.f;
+  const int nd = num_downs;
+  net->ch.assign(nd + 1, 0); net->Hk.assign(nd + 1, 0); net->Wk.assign(nd + 1, 0);
+  net->conv.assign(nd + 1, Conv()); net->up.assign(nd + 1, Conv());
+  net->dnorm.assign(nd + 1, BN()); net->unorm.assign(nd + 1, BN());
+  for (int k = 1; k <= nd; ++k) {
+    int m = 1 << (k - 1);
+    if (m > 8) m = 8;
+    net->ch[k] = ngf * m;
+    net->Hk[k] = H >> k;
+    net->Wk[k] = W >> k;
+  }
+  // parameters in the reference's named_parameters() order (recursive nesting, networks.py:296-318)
+  std::vector<std::pair<std::string, BN*>> bns;
+  std::vector<std::string> prefix(nd + 2);
+  prefix[1] = "model.model";
+  struct Emit {
+    gi_net* net; int nd; std::vector<std::string>& prefix; std::vector<std::pair<std::string, BN*>>& bns;
+    void run(int k) {
+      const std::string& p = prefix[k];
+      const bool outer = (k == 1), inner = (k == nd);
+      const std::string down = p + (outer ? ".0" : ".1");
+      const std::string upn = p + ((outer || inner) ? ".3" : ".5");
+      Conv& cv = net->conv[k];
+      cv.ca = net->ch[k]; cv.cb = outer ? 1 : net->ch[k - 1];
+      add_tensor(net, down + ".weight", 0, {cv.ca, cv.cb, 4, 4}, &cv.w_off);
+      if (!outer && !inner) add_bn(net, p + ".2", net->dnorm[k], net->ch[k], bns);
+      if (!inner) {
+        prefix[k + 1] = p + (outer ? ".1" : ".3") + ".model";
+        run(k + 1);
+      }
+      Conv& uv = net->up[k];
+      uv.ca = inner ? net->ch[k] : 2 * net->ch[k];
+      uv.cb = outer ? 1 : net->ch[k - 1];
+      add_tensor(net, upn + ".weight", 0, {uv.ca, uv.cb, 4, 4}, &uv.w_off);
+      if (outer) add_tensor(net, upn + ".bias", 1, {1}, &uv.bias_off);
+      if (!outer) add_bn(net, p + (inner ? ".4" : ".6"), net->unorm[k], net->ch[k - 1], bns);
+    }
+  } emit{net, nd, prefix, bns};
+  emit.run(1);
+  for (auto& pb : bns) {
+    add_tensor(net, pb.first + ".running_mean", 2, {pb.second->c}, &pb.second->rmean_off);
+    add_tensor(net, pb.first + ".running_var", 3, {pb.second->c}, &pb.second->rvar_off);
+  }
+
+  // ---- workspace layout
+  const int64_t T = (int64_t)net->tsz();
+  Arena& A = net->arena;
+  for (int k = 2; k <= nd; ++k) {
+    for (Conv* c : {&net->conv[k], &net->up[k]}) {
+      const int64_t cnt = (int64_t)c->ca * 16 * c->cb;
+      c->packed_off = (dtype == GI_F32) ? -2 : A.take(cnt * T);  // fp32: the master itself is [a][16*b]
+      c->phase_off = A.take(cnt * T);
+    }
+  }
+  const int64_t N = max_n;
+  net->ogC.assign(nd + 1, -1); net->ogA.assign(nd + 1, -1);
+  int64_t maxD = 0, maxPart = 0, maxSplit = 0, maxc = 0;
+  for (int k = 1; k <= nd - 1; ++k) {
+    const int64_t pix = N * net->Hk[k] * net->Wk[k];
+    net->ogC[k] = A.take(pix * 2 * net->ch[k] * T);
+    net->ogA[k] = A.take(pix * net->ch[k] * T);
+    maxD = max64(maxD, pix * net->ch[k] * T);
+    maxPart = max64(maxPart, part_rows(pix) * 2 * 2 * net->ch[k]);
+    maxc = max64(maxc, 2 * net->ch[k]);
+    if (pix <= 32768) maxSplit = max64(maxSplit, pix * 2 * net->ch[k] * 4);
+  }
+  {
+    const int64_t pix = N * net->Hk[nd] * net->Wk[nd];
+    net->ogE = A.take(pix * net->ch[nd] * T);
+    maxD = max64(maxD, pix * net->ch[nd] * T);
+    maxSplit = max64(maxSplit, pix * net->ch[nd] * 4);
+  }
+  net->oD = A.take(maxD);
+  net->oG0 = A.take(N * H * W * 4);
+  net->part_floats = maxPart;
+  net->oPart = A.take(maxPart * 4);
+  net->oSums = A.take(2 * maxc * 4);
+  net->split_bytes = maxSplit;
+  net->oSplit = A.take(maxSplit);
+  // per-slot
+  Arena S;
+  net->oC.assign(nd + 1, -1); net->oR.assign(nd + 1, -1); net->oU.assign(nd + 1, -1); net->oMask.assign(nd + 1, -1);
+  for (int k = 1; k <= nd - 1; ++k) net->oC[k] = S.take(N * net->Hk[k] * net->Wk[k] * 2 * net->ch[k] * T);
+  for (int k = 2; k <= nd - 1; ++k) net->oR[k] = S.take(N * net->Hk[k] * net->Wk[k] * net->ch[k] * T);
+  net->oE = S.take(N * net->Hk[nd] * net->Wk[nd] * net->ch[nd] * T);
+  for (int k = 2; k <= nd; ++k) net->oU[k] = S.take(N * net->Hk[k - 1] * net->Wk[k - 1] * net->ch[k - 1] * T);
+  for (int k = 5; k <= nd - 1; ++k) net->oMask[k] = S.take(N * net->Hk[k - 1] * net->Wk[k - 1] * net->ch[k - 1]);
+  net->oOut = S.take(N * H * W * 4);
+  net->oX = S.take(N * H * W * 4);
+  int64_t stat_floats = 0;
+  for (int k = 1; k <= nd; ++k)
+    for (BN* b : {&net->dnorm[k], &net->unorm[k]})
+      if (b->c) { b->stat_off = stat_floats; stat_floats += 4 * b->c; }
+  net->oStats = S.take(stat_floats * 4);
+  net->slot_bytes = S.size;
+  net->slot_base = A.take(S.size * n_slots);
+  net->slot_n.assign(n_slots, 0);
+  net->slot_train.assign(n_slots, 0);
+  net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
+  *out = net;
+  return GI_OK;
+}
+
+extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots, gi_net** out) {
+  GI_REQUIRE(out, "patchgan_create: null argument");  // ctx may be null: inventory-only handle
+  GI_REQUIRE(dtype == GI_F16 || dtype == GI_F32, "patchgan_create: dtype=%d", dtype);
+  GI_REQUIRE(gi_is_pow2(H) && gi_is_pow2(W) && H >= 64 && W >= 64, "patchgan_create: H=%d W=%d must be powers of two >= 64", H, W);
+  GI_REQUIRE(max_n >= 1 && n_slots >= 1 && n_slots <= 8, "patchgan_create: max_n=%d n_slots=%d", max_n, n_slots);
+  gi_net* net = new gi_net();
+  net->ctx = ctx; net->kind = 1; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
+  net->sigmoid = sigmoid;
+  net->loss_scale = dtype == GI_F16 ? 1024.f : 1.f;
+  net->Hh = H / 16; net->Wh = W / 16;
+  net->P = (net->Hh - 3) * (net->Wh - 3);
+  const int chans[5] = {1, 64, 128, 256, 512};
+  const int conv_idx[5] = {0, 0, 2, 5, 8};
+  const int bn_idx[5] = {0, 0, 3, 6, 9};
+  std::vector<std::pair<std::string, BN*>> bns;
+  for (int i = 1; i <= 4; ++i) {
+    Conv& c = net->dconv[i];
+    c.ca = chans[i]; c.cb = chans[i - 1];
+    add_tensor(net, "model." + std::to_string(conv_idx[i]) + ".weight", 0, {c.ca, c.cb, 4, 4}, &c.w_off);
+    if (i >= 2) add_bn(net, "model." + std::to_string(bn_idx[i]), net->dbn[i], chans[i], bns);
+  }
+  add_tensor(net, "model.11.weight", 0, {1, 512, 4, 4}, &net->w5_off);
+  add_tensor(net, "model.13.weight", 1, {1, net->P}, &net->wl_off);
+  add_tensor(net, "model.13.bias", 1, {1}, &net->bl_off);
+  for (auto& pb : bns) {
+    add_tensor(net, pb.first + ".running_mean", 2, {pb.second->c}, &pb.second->rmean_off);
+    add_tensor(net, pb.first + ".running_var", 3, {pb.second->c}, &pb.second->rvar_off);
+  }
+  const int64_t T = (int64_t)net->tsz();
+  Arena& A = net->arena;
+  for (int i = 2; i <= 4; ++i) {
+    Conv& c = net->dconv[i];
+    const int64_t cnt = (int64_t)c.ca * 16 * c.cb;
+    c.packed_off = (dtype == GI_F32) ? -2 : A.take(cnt * T);
+    c.phase_off = A.take(cnt * T);
+  }
+  const int64_t N = max_n;
+  int64_t maxD = 0, maxPart = 0, maxSplit = 0;
+  net->ogA.assign(5, -1);
+  for (int i = 1; i <= 4; ++i) {
+    const int64_t pix = N * (H >> i) * (W >> i);
+    net->ogA[i] = A.take(pix * chans[i] * T);
+    maxD = max64(maxD, pix * chans[i] * T);
+    maxPart = max64(maxPart, part_rows(pix) * 2 * chans[i]);
+    if (pix <= 32768) maxSplit = max64(maxSplit, pix * chans[i] * 4);
+  }
+  net->oD = A.take(maxD);
+  net->part_floats = maxPart;
+  net->oPart = A.take(maxPart * 4);
+  net->oSums = A.take(2 * 512 * 4);
+  net->split_bytes = maxSplit;
+  net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
+  net->oDh = A.take(N * net->P * 4);
+  Arena S;
+  for (int i = 1; i <= 4; ++i) net->oA[i] = S.take(N * (H >> i) * (W >> i) * chans[i] * T);
+  for (int i = 2; i <= 4; ++i) net->oRd[i] = S.take(N * (H >> i) * (W >> i) * chans[i] * T);
+  net->oHh = S.take(N * net->P * 4);
+  net->oOut = S.take(N * 4);
+  net->oX = S.take(N * H * W * 4);
+  int64_t stat_floats = 0;
+  for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 4 * net->dbn[i].c; }
+  net->oStats = S.take(stat_floats * 4);
+  net->slot_bytes = S.size;
+  net->slot_base = A.take(S.size * n_slots);
+  net->slot_n.assign(n_slots, 0);
+  net->slot_train.assign(n_slots, 0);
+  *out = net;
+  return GI_OK;
+}
+
+extern "C" int gi_net_destroy(gi_net* net) {
+  delete net;
+  return GI_OK;
+}
+
+// =================================================================================================
+// inventory / binding
+// =================================================================================================
+extern "C" int gi_net_tensor_count(gi_net* net) { return net ? (int)net->tensors.size() : GI_ERR_INVALID; }
+
+extern "C" int gi_net_tensor_desc(gi_net* net, int index, char* name, int name_cap, int* kind, int64_t* shape4, int* ndim,
+                                  int64_t* offset, int64_t* numel) {
+  GI_REQUIRE(net && index >= 0 && index < (int)net->tensors.size(), "tensor_desc: index %d out of range", index);
+  const TensorDesc& t = net->tensors[index];
+  if (name && name_cap > 0) {
+    strncpy(name, t.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (kind) *kind = t.kind;
+  if (shape4) for (int i = 0; i < 4; ++i) shape4[i] = t.shape[i];
+  if (ndim) *ndim = t.ndim;
+  if (offset) *offset = t.offset;
+  if (numel) *numel = t.numel;
+  return GI_OK;
+}
+extern "C" int64_t gi_net_param_floats(gi_net* net) { return net ? net->n_params : GI_ERR_INVALID; }
+extern "C" int64_t gi_net_buffer_floats(gi_net* net) { return net ? net->n_buffers : GI_ERR_INVALID; }
+extern "C" int64_t gi_net_workspace_bytes(gi_net* net) { return net ? net->arena.size : GI_ERR_INVALID; }
+
+extern "C" int gi_net_bind(gi_net* net, float* params, float* grads, float* buffers, void* workspace, int64_t workspace_bytes) {
+  GI_REQUIRE(net && params && grads && buffers && workspace, "net_bind: null pointer");
+  GI_REQUIRE(net->ctx != nullptr, "net_bind: handle was created without a context (inventory only)");
+  GI_REQUIRE(workspace_bytes >= net->arena.size, "net_bind: workspace %lld < required %lld", (long long)workspace_bytes,
+             (long long)net->arena.size);
+  GI_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "net_bind: workspace must be 256-byte aligned");
+  net->params = params; net->grads = grads; net->buffers = buffers; net->ws = (char*)workspace;
+  net->bound = true;
+  return GI_OK;
+}
+
+namespace {
+const void* packed_ptr(const gi_net* net, const Conv& c) {
+  return c.packed_off == -2 ? (const void*)(net->params + c.w_off) : (const void*)net->shared(c.packed_off);
+}
+const void* phase_ptr(const gi_net* net, const Conv& c) { return net->shared(c.phase_off); }
+
+int sync_conv(gi_net* net, const Conv& c) {
+  void* packed = c.packed_off >= 0 ? (void*)net->shared(c.packed_off) : nullptr;
+  return op_pack_weights(net->ctx->stream, net->dtype, net->params + c.w_off, c.ca, c.cb, packed, net->shared(c.phase_off));
+}
+}  // namespace
+
+extern "C" int gi_net_sync_weights(gi_net* net) {
+  GI_REQUIRE(net && net->bound, "sync_weights: net not bound");
+  if (net->kind == 0) {
+    for (int k = 2; k <= net->nd; ++k) {
+      GI_TRY(sync_conv(net, net->conv[k]));
+      GI_TRY(sync_conv(net, net->up[k]));
+    }
+  } else {
+    for (int i = 2; i <= 4; ++i) GI_TRY(sync_conv(net, net->dconv[i]));
+  }
+  return GI_OK;
+}
+extern "C" int gi_net_set_train(gi_net* net, int train) {
+  GI_REQUIRE(net, "set_train: null");
+  net->train = train ? 1 : 0;
+  return GI_OK;
+}
+extern "C" int gi_net_set_loss_scale(gi_net* net, float scale) {
+  GI_REQUIRE(net && scale > 0.f, "set_loss_scale: scale must be > 0");
+  net->loss_scale = scale;
+  return GI_OK;
+}
+extern "C" int gi_net_set_dropout_seed(gi_net* net, uint64_t seed) {
+  GI_REQUIRE(net, "set_dropout_seed: null");
+  net->drop_seed = seed;
+  net->drop_counter = 0;
+  return GI_OK;
+}
+extern "C" int gi_net_dropout_mask(gi_net* net, int slot, int level, uint8_t* out_nchw, int64_t count) {
+  GI_REQUIRE(net && net->kind == 0 && net->bound, "dropout_mask: generator handle required");
+  GI_REQUIRE(slot >= 0 && slot < net->n_slots && level >= 5 && level <= net->nd - 1, "dropout_mask: slot=%d level=%d", slot, level);
+  const int n = net->slot_n[slot], c = net->ch[level - 1], hw = net->Hk[level - 1] * net->Wk[level - 1];
+  GI_REQUIRE(count == (int64_t)n * c * hw, "dropout_mask: count %lld != %lld", (long long)count, (long long)n * c * hw);
+  return op_mask_nchw_to_nhwc(net->ctx->stream, (const uint8_t*)net->slot(slot, net->oMask[level]), out_nchw, n, c, hw, 0);
+}
+extern "C" int gi_net_set_dropout_mask(gi_net* net, int slot, int level, const uint8_t* mask_nchw) {
+  GI_REQUIRE(net && net->kind == 0, "set_dropout_mask: generator handle required");
+  GI_REQUIRE(slot >= 0 && slot < net->n_slots && level >= 5 && level <= net->nd - 1, "set_dropout_mask: slot=%d level=%d", slot, level);
+  net->ext_mask[slot][level] = mask_nchw;
+  return GI_OK;
+}
+
+// =================================================================================================
+// forward / backward
+// =================================================================================================
+namespace {
+
+struct BNPtrs { float *scale, *shift, *mean, *inv; };
+BNPtrs bn_ptrs(const gi_net* net, int slot, const BN& b) {
+  float* base = (float*)net->slot(slot, net->oStats) + b.stat_off;
+  return {base, base + b.c, base + 2 * b.c, base + 3 * b.c};
+}
+
+// raw (pixels,c) conv output with per-tile partial statistics -> normalise + activation into dst
+int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixels, int ntiles, void* dst, int ldy,
+               int coffy, int act, const uint8_t* drop, float drop_scale, int train) {
+  hipStream_t st = net->ctx->stream;
+  BNPtrs p = bn_ptrs(net, slot, b);
+  GI_TRY(op_bn_finalize(st, (const float*)net->shared(net->oPart), ntiles, b.c, pixels, net->params + b.gamma_off,
+                        net->params + b.beta_off, net->buffers + b.rmean_off, net->buffers + b.rvar_off, p.scale, p.shift,
+                        p.mean, p.inv, train, 0.1f, 1e-5f));
+  return op_bn_apply(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, p.scale, p.shift, act, drop, drop_scale);
+}
+
+int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
+          int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles) {
+  IgemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.w = w; a.out = out; a.bias = nullptr;
+  a.partials = stats ? (float*)net->shared(net->oPart) : nullptr;
+  a.ws = net->split_bytes > 0 ? (float*)net->shared(net->oSplit) : nullptr;
+  a.ws_bytes = net->split_bytes;
+  a.n = n; a.Hs = Hs; a.Ws = Ws;
+  a.cin = cin; a.ldin = ldin; a.coffin = coffin;
+  a.cout = cout; a.ldout = ldout; a.coffout = coffout;
+  a.relu_in = relu_in; a.act_out = act_out;
+  GI_TRY(op_igemm(net->ctx->stream, net->dtype, phase, a));
+  if (ntiles) *ntiles = a.ntiles_out;
+  if (stats) GI_REQUIRE((int64_t)a.ntiles_out * 2 * cout <= net->part_floats, "internal: partials buffer too small");
+  return GI_OK;
+}
+
+int wgrad(gi_net* net, const void* S, int ca, int ldS, int coffS, int relu_S, const void* L, int cb, int ldL, int coffL,
+          int n, int Hs, int Ws, float* dW) {
+  WgradArgs a;
+  a.S = S; a.L = L; a.dW = dW; a.n = n; a.Hs = Hs; a.Ws = Ws;
+  a.ca = ca; a.ldS = ldS; a.coffS = coffS; a.cb = cb; a.ldL = ldL; a.coffL = coffL;
+  a.relu_S = relu_S; a.scale = 1.f / net->loss_scale;
+  return op_wgrad(net->ctx->stream, net->dtype, a);
+}
+
+int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, const void* g2, int ldg2, int coffg2,
+               const void* y, int ldy, int coffy, const void* x, void* dx, int64_t pixels, int c, int act, float drop_scale,
+               const BN* bn, int need_wgrad) {
+  ActBnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g1 = g1; a.ldg1 = ldg1; a.coffg1 = coffg1;
+  a.g2 = g2; a.ldg2 = ldg2; a.coffg2 = coffg2;
+  a.y = y; a.ldy = ldy; a.coffy = coffy;
+  a.x = x; a.dx = dx; a.pixels = pixels; a.c = c; a.act = act; a.drop_scale = drop_scale;
+  a.has_bn = bn ? 1 : 0;
+  if (bn) {
+    BNPtrs p = bn_ptrs(net, slot, *bn);
+    a.gamma = net->params + bn->gamma_off; a.save_mean = p.mean; a.save_invstd = p.inv;
+    a.dgamma = need_wgrad ? net->grads + bn->gamma_off : nullptr;
+    a.dbeta = need_wgrad ? net->grads + bn->beta_off : nullptr;
+  }
+  a.inv_loss_scale = 1.f / net->loss_scale;
+  a.partials = (float*)net->shared(net->oPart);
+  a.sums = (float*)net->shared(net->oSums);
+  return op_act_bn_bwd(net->ctx->stream, net->dtype, a);
+}
+
+__global__ void __launch_bounds__(256) sum_acc_kernel(const float* src, int64_t count, float* dst, float scale) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) s += src[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dst, (float)((sh[0] + sh[1] + sh[2] + sh[3]) * scale));
+}
+
+// ---------------------------------------------------------------------------------------------
+int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
+  hipStream_t st = net->ctx->stream;
+  const int nd = net->nd, dt = net->dtype, train = net->train;
+  const int H = net->H, W = net->W;
+  net->slot_n[s] = n;
+  net->slot_train[s] = train;
+  auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
+  GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
+  // d1: Conv2d(1->ngf) then the next block's in-place LeakyReLU (networks.py:287): the skip IS lrelu(x)
+  GI_TRY(op_c1_gather(st, dt, x, net->params + net->conv[1].w_off, C(1), n, net->Hk[1], net->Wk[1], net->ch[1], 2 * net->ch[1], 0,
+                      GI_ACT_LRELU, 1.f));
+  for (int k = 2; k <= nd; ++k) {
+    const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
+    int nt = 0;
+    if (k < nd) {
+      void* R = net->slot(s, net->oR[k]);
+      GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), R, net->ch[k],
+                   net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt));
+      GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train));
+    } else {  // innermost: no down-norm; uprelu follows directly (networks.py:299-305)
+      GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), net->slot(s, net->oE),
+                   net->ch[k], net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_RELU, false, nullptr));
+    }
+  }
+  for (int k = nd; k >= 2; --k) {
+    const void* in = (k == nd) ? (const void*)net->slot(s, net->oE) : C(k);
+    const int cin = net->up[k].ca;
+    const int64_t opix = (int64_t)n * net->Hk[k - 1] * net->Wk[k - 1];
+    const int co = net->ch[k - 1];
+    void* U = net->slot(s, net->oU[k]);
+    int nt = 0;
+    GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
+                 GI_ACT_NONE, true, &nt));
+    const uint8_t* drop = nullptr;
+    if (train && net->dropout_p > 0.f && k >= 5 && k <= nd - 1) {
+      uint8_t* m = (uint8_t*)net->slot(s, net->oMask[k]);
+      if (net->ext_mask[s][k]) {
+        GI_TRY(op_mask_nchw_to_nhwc(st, net->ext_mask[s][k], m, n, co, net->Hk[k - 1] * net->Wk[k - 1], 1));
+      } else {
+        GI_TRY(op_fill_dropout(st, m, opix * co, net->drop_seed + 0x1000003ull * (++net->drop_counter), net->dropout_p));
+      }
+      drop = m;
+    }
+    GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_NONE, drop,
+                      drop ? 1.f / (1.f - net->dropout_p) : 1.f, train));
+  }
+  float* osave = (float*)net->slot(s, net->oOut);
+  GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
+                       net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f));
+  GI_HIP(hipMemcpyAsync(y, osave, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
+  return GI_OK;
+}
+
+int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad) {
+  hipStream_t st = net->ctx->stream;
+  const int nd = net->nd, dt = net->dtype;
+  const int H = net->H, W = net->W, n = net->slot_n[s];
+  GI_REQUIRE(n > 0 && net->slot_train[s], "unet_backward: slot %d holds no train-mode forward", s);
+  const float LS = net->loss_scale, iLS = 1.f / LS;
+  auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
+  auto gC = [&](int k) { return (void*)net->shared(net->ogC[k]); };
+  auto gA = [&](int k) { return (void*)net->shared(net->ogA[k]); };
+  void* D = net->shared(net->oD);
+  float* G0 = (float*)net->shared(net->oG0);
+  const int64_t npx = (int64_t)n * H * W;
+  // tanh' and loss scaling
+  GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx, LS));
+  // u1: ConvTranspose2d(2ngf -> 1) + bias
+  const int c1 = 2 * net->ch[1];
+  if (need_wgrad) {
+    hipLaunchKernelGGL(sum_acc_kernel, dim3(256), dim3(256), 0, st, G0, npx, net->grads + net->up[1].bias_off, iLS);
+    GI_LAUNCH_CHECK();
+    GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f));
+  }
+  GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
+  // decoder, outermost -> innermost: level k's concat gradient feeds up[k+1]
+  for (int k = 1; k <= nd - 1; ++k) {
+    const int kk = k + 1;
+    const int ck = net->ch[k];
+    const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
+    const float ds = (net->dropout_p > 0.f && kk >= 5 && kk <= nd - 1) ? 1.f / (1.f - net->dropout_p) : 1.f;
+    GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, gC(k), 2 * ck, ck, C(k), 2 * ck, ck, net->slot(s, net->oU[kk]), D, pix, ck,
+                      GI_ACT_NONE, ds, &net->unorm[kk], need_wgrad));
+    const void* Sin = (kk == nd) ? (const void*)net->slot(s, net->oE) : C(kk);
+    const int ca = net->up[kk].ca;
+    if (need_wgrad)
+      GI_TRY(wgrad(net, Sin, ca, ca, 0, kk < nd ? 1 : 0, D, ck, ck, 0, n, net->Hk[kk], net->Wk[kk], net->grads + net->up[kk].w_off));
+    void* gout = (kk == nd) ? (void*)net->shared(net->ogE) : gC(kk);
+    GI_TRY(igemm(net, 0, D, ck, ck, 0, packed_ptr(net, net->up[kk]), gout, ca, ca, 0, n, net->Hk[kk], net->Wk[kk], 0, GI_ACT_NONE,
+                 false, nullptr));
+  }
+  // innermost conv (no norm): dz = gE * [E > 0]
+  {
+    const int c = net->ch[nd];
+    const int64_t pix = (int64_t)n * net->Hk[nd] * net->Wk[nd];
+    GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, net->shared(net->ogE), c, 0, net->slot(s, net->oE), c, 0, nullptr, D, pix, c, GI_ACT_NONE,
+                      1.f, nullptr, need_wgrad));
+    const int cb = net->ch[nd - 1];
+    if (need_wgrad)
+      GI_TRY(wgrad(net, D, c, c, 0, 0, C(nd - 1), cb, 2 * cb, 0, n, net->Hk[nd], net->Wk[nd], net->grads + net->conv[nd].w_off));
+    GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[nd]), gA(nd - 1), cb, cb, 0, n, net->Hk[nd], net->Wk[nd], 0, GI_ACT_NONE,
+                 false, nullptr));
+  }
+  // encoder, innermost -> outermost
+  for (int k = nd - 1; k >= 2; --k) {
+    const int c = net->ch[k];
+    const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
+    GI_TRY(act_bn_bwd(net, s, gA(k), c, 0, gC(k), 2 * c, 0, C(k), 2 * c, 0, net->slot(s, net->oR[k]), D, pix, c, GI_ACT_LRELU, 1.f,
+                      &net->dnorm[k], need_wgrad));
+    const int cb = net->ch[k - 1];
+    if (need_wgrad)
+      GI_TRY(wgrad(net, D, c, c, 0, 0, C(k - 1), cb, 2 * cb, 0, n, net->Hk[k], net->Wk[k], net->grads + net->conv[k].w_off));
+    GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[k]), gA(k - 1), cb, cb, 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE,
+                 false, nullptr));
+  }
+  {
+    const int c = net->ch[1];
+    const int64_t pix = (int64_t)n * net->Hk[1] * net->Wk[1];
+    GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
+    if (need_wgrad)
+      GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c,
+                         0, 0, iLS, 1.f));
+    if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS));
+  }
+  return GI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
+  hipStream_t st = net->ctx->stream;
+  const int dt = net->dtype, train = net->train, H = net->H, W = net->W;
+  net->slot_n[s] = n;
+  net->slot_train[s] = train;
+  GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
+  GI_TRY(op_c1_gather(st, dt, x, net->params + net->dconv[1].w_off, net->slot(s, net->oA[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_LRELU, 1.f));
+  for (int i = 2; i <= 4; ++i) {
+    const Conv& c = net->dconv[i];
+    const int Hs = H >> i, Ws = W >> i;
+    int nt = 0;
+    void* R = net->slot(s, net->oRd[i]);
+    GI_TRY(igemm(net, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, packed_ptr(net, c), R, c.ca, c.ca, 0, n, Hs, Ws, 0, GI_ACT_NONE,
+                 true, &nt));
+    GI_TRY(bn_forward(net, s, net->dbn[i], R, (int64_t)n * Hs * Ws, nt, net->slot(s, net->oA[i]), c.ca, 0, GI_ACT_LRELU, nullptr, 1.f, train));
+  }
+  HeadArgs h;
+  h.a4 = net->slot(s, net->oA[4]); h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;
+  h.h = (float*)net->slot(s, net->oHh); h.out = (float*)net->slot(s, net->oOut);
+  h.n = n; h.Hh = net->Hh; h.Wh = net->Wh; h.c = 512; h.sigmoid = net->sigmoid;
+  GI_TRY(op_head_forward(st, dt, h));
+  GI_HIP(hipMemcpyAsync(y, h.out, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+  return GI_OK;
+}
+
+int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad) {
+  hipStream_t st = net->ctx->stream;
+  const int dt = net->dtype, H = net->H, W = net->W, n = net->slot_n[s];
+  GI_REQUIRE(n > 0 && net->slot_train[s], "patchgan_backward: slot %d holds no train-mode forward", s);
+  const float LS = net->loss_scale, iLS = 1.f / LS;
+  void* D = net->shared(net->oD);
+  HeadBwdArgs hb;
+  hb.a4 = net->slot(s, net->oA[4]); hb.w5 = net->params + net->w5_off; hb.wl = net->params + net->wl_off;
+  hb.h = (const float*)net->slot(s, net->oHh); hb.out = (const float*)net->slot(s, net->oOut);
+  hb.dy = dy; hb.da4 = net->shared(net->ogA[4]);
+  hb.dw5 = need_wgrad ? net->grads + net->w5_off : nullptr;
+  hb.dwl = need_wgrad ? net->grads + net->wl_off : nullptr;
+  hb.dbl = need_wgrad ? net->grads + net->bl_off : nullptr;
+  hb.dh = (float*)net->shared(net->oDh);
+  hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = net->sigmoid; hb.loss_scale = LS;
+  GI_TRY(op_head_backward(st, dt, hb));
+  for (int i = 4; i >= 2; --i) {
+    const Conv& c = net->dconv[i];
+    const int Hs = H >> i, Ws = W >> i;
+    const int64_t pix = (int64_t)n * Hs * Ws;
+    GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[i]), c.ca, 0, nullptr, 0, 0, net->slot(s, net->oA[i]), c.ca, 0, net->slot(s, net->oRd[i]),
+                      D, pix, c.ca, GI_ACT_LRELU, 1.f, &net->dbn[i], need_wgrad));
+    if (need_wgrad)
+      GI_TRY(wgrad(net, D, c.ca, c.ca, 0, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, net->grads + c.w_off));
+    GI_TRY(igemm(net, 1, D, c.ca, c.ca, 0, phase_ptr(net, c), net->shared(net->ogA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, 0, GI_ACT_NONE, false,
+                 nullptr));
+  }
+  const int64_t pix = (int64_t)n * (H / 2) * (W / 2);
+  GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[1]), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D, pix, 64, GI_ACT_LRELU,
+                    1.f, nullptr, need_wgrad));
+  if (need_wgrad)
+    GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f));
+  if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS));
+  return GI_OK;
+}
+
+}  // namespace
+
+extern "C" int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n) {
+  GI_REQUIRE(net && net->bound, "net_forward: net not bound");
+  GI_REQUIRE(x && y && n >= 1 && n <= net->max_n, "net_forward: n=%d (max %d)", n, net->max_n);
+  GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_forward: slot=%d", slot);
+  return net->kind == 0 ? unet_forward(net, slot, x, y, n) : patchgan_forward(net, slot, x, y, n);
+}
+
+extern "C" int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad) {
+  GI_REQUIRE(net && net->bound, "net_backward: net not bound");
+  GI_REQUIRE(dy, "net_backward: dy is null");
+  GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_backward: slot=%d", slot);
+  return net->kind == 0 ? unet_backward(net, slot, dy, dx, need_wgrad) : patchgan_backward(net, slot, dy, dx, need_wgrad);
+}

@@ -1,0 +1,167 @@
+/*
+ * libganinpaint — C-ABI of the MI355X (gfx950) backend for the GAN-inpainting hot path.
+ *
+ * The reference (abeytheo/gan-inpainting) is pure Python and has NO FFI of its own; the
+ * interfaces this library stands behind are the Python ones cited next to each group below
+ * (paths are relative to the upstream repository). INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success, a negative gi_status otherwise; the message of the
+ *     last error on the calling thread is returned by gi_last_error(); nothing throws.
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
+ *     buffer (it hands device memory to the handle with the *_bind calls, sizes come from the
+ *     matching *_bytes / *_count queries); the handle owns no device memory.
+ *   - calls are asynchronous on the hipStream_t given to gi_ctx_create (passed as void*);
+ *     a handle is bound to one device and one stream and is not thread-safe.
+ *   - public image tensors are fp32 (N,1,H,W) contiguous (NCHW == NHWC for one channel).
+ *   - conv / transposed-conv weights are fp32 in physical order [a][ky][kx][b] where
+ *     a = Conv2d out-channels (resp. ConvTranspose2d in-channels) and b the other channel
+ *     axis, i.e. the torch "channels_last" image of the reference's [a,b,4,4] tensors
+ *     (lib/models/networks.py:285, :293-309, :337-352), so state_dict() values are zero-copy.
+ */
+#ifndef GANINPAINT_H
+#define GANINPAINT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GI_OK = 0,
+  GI_ERR_INVALID = -1,      /* bad argument / unsupported shape */
+  GI_ERR_HIP = -2,          /* a HIP runtime call or kernel launch failed */
+  GI_ERR_STATE = -3,        /* call order violated (e.g. backward without forward) */
+  GI_ERR_UNSUPPORTED = -4
+} gi_status;
+
+typedef enum { GI_F32 = 0, GI_F16 = 1 } gi_dtype;      /* internal compute/storage type */
+typedef enum { GI_ACT_NONE = 0, GI_ACT_RELU = 1, GI_ACT_LRELU = 2 } gi_act;
+
+typedef struct gi_ctx gi_ctx;
+typedef struct gi_net gi_net;
+
+const char* gi_last_error(void);
+int gi_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+int gi_ctx_create(int device_id, void* hip_stream, gi_ctx** out);
+int gi_ctx_destroy(gi_ctx* ctx);
+int gi_ctx_sync(gi_ctx* ctx);
+
+/* ---- networks: lib/models/networks.py:13-28 get_network, :216-253 UnetGenerator,
+ *      :331-363 PatchGANDiscriminator ------------------------------------------------------- */
+/* UnetGenerator(in_c=1,out_c=1,num_downs,ngf,BatchNorm2d,use_dropout truthy): dropout_p is 0.5
+ * for the reference's get_network (networks.py:18-19), 0 disables it. n_slots = number of
+ * independent activation sets (forward calls that may be live before their backward). */
+int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, int W, int max_n,
+                   int dtype, int n_slots, gi_net** out);
+/* PatchGANDiscriminator(c=1, sigmoid): Linear(25,1) generalised to ((H/16-3)*(W/16-3),1). */
+int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots,
+                       gi_net** out);
+int gi_net_destroy(gi_net* net);
+
+/* parameter / buffer inventory, in the reference's named_parameters() order, then buffers.
+ * kind: 0 conv weight (shape [a,b,4,4], physical [a][ky][kx][b]), 1 bias / BN affine / Linear
+ * (contiguous), 2 BN running_mean, 3 BN running_var. offset is in floats into the flat param
+ * (kind 0,1) or flat buffer (kind 2,3) allocation. */
+int gi_net_tensor_count(gi_net* net);
+int gi_net_tensor_desc(gi_net* net, int index, char* name, int name_cap, int* kind, int64_t* shape4,
+                       int* ndim, int64_t* offset, int64_t* numel);
+int64_t gi_net_param_floats(gi_net* net);      /* flat fp32 params (and grads, optimizer states) */
+int64_t gi_net_buffer_floats(gi_net* net);     /* flat fp32 BN running stats */
+int64_t gi_net_workspace_bytes(gi_net* net);   /* activations, packed weights, scratch */
+int gi_net_bind(gi_net* net, float* params, float* grads, float* buffers, void* workspace,
+                int64_t workspace_bytes);
+/* re-derive the packed (fp16 / transposed) weight copies after params were written by the caller */
+int gi_net_sync_weights(gi_net* net);
+int gi_net_set_train(gi_net* net, int train);
+int gi_net_set_loss_scale(gi_net* net, float scale);   /* fp16 backward scaling, default 1024 */
+int gi_net_set_dropout_seed(gi_net* net, uint64_t seed);
+/* keep-mask of dropout level `level` used by the last train-mode forward of `slot`,
+ * as uint8 in (N,C,H,W) order (what the oracle consumes); count = N*C*H*W */
+int gi_net_dropout_mask(gi_net* net, int slot, int level, uint8_t* out_nchw, int64_t count);
+/* impose external keep-masks (uint8 NCHW, device) for the next forward of slot; null clears */
+int gi_net_set_dropout_mask(gi_net* net, int slot, int level, const uint8_t* mask_nchw);
+
+/* forward: x (n,1,H,W) fp32 -> y: generator (n,1,H,W) fp32, discriminator (n,1) fp32 */
+int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n);
+/* backward of the forward held in `slot`: dy like y; dx like x or NULL; need_wgrad=0 is the
+ * frozen-net case of util.set_requires_grad(nets, False) (lib/models/util.py:19-22): only input
+ * gradients are produced. Parameter gradients ACCUMULATE into the bound grads. */
+int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad);
+
+/* ---- mask pipeline: experiment_list/minimaxgan_l1.py:113-122 ------------------------------ */
+/* mask_c = do_ceil ? ceil(mask) : mask ; masked = ground * (1 - mask_c) */
+int gi_mask_apply(gi_ctx* ctx, const float* ground, const float* mask, float* mask_c, float* masked,
+                  int64_t count, int do_ceil);
+/* inpainted = masked + gen * mask_c */
+int gi_mask_composite(gi_ctx* ctx, const float* masked, const float* gen, const float* mask_c,
+                      float* inpainted, int64_t count);
+/* out = a * b (the composite backward d_gen = d_inpainted * mask_c, and mask*x products) */
+int gi_mul(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count);
+
+/* ---- losses. Each writes the scalar loss to loss_out[0] (device) and, when grad_a != NULL, the
+ *      gradient w.r.t. `a` multiplied by gscale. nn.L1Loss (minimaxgan_l1.py:62,166);
+ *      RMSELoss sqrt(mse+1e-16) (lib/models/loss.py:11-19); LocalLoss (loss.py:24-47,
+ *      kind 0 = L1, 1 = MSE, 2 = sqrt extension); scratch: >= 4096 floats ---------------------- */
+int gi_loss_l1(gi_ctx* ctx, const float* a, const float* b, int64_t count, float* loss_out,
+               float* grad_a, float gscale, float* scratch);
+int gi_loss_rmse(gi_ctx* ctx, const float* a, const float* b, int64_t count, float eps, float* loss_out,
+                 float* grad_a, float gscale, float* scratch);
+int gi_loss_mse(gi_ctx* ctx, const float* a, const float* b, int64_t count, float* loss_out,
+                float* grad_a, float gscale, float* scratch);
+int gi_loss_local(gi_ctx* ctx, const float* yhat, const float* y, const float* mask, int64_t count,
+                  int kind, float* loss_out, float* grad_yhat, float gscale, float* scratch);
+/* adversarial scalar losses on (n,) predictions: kind 0 BCE vs constant target
+ * (minimaxgan_l1.py:135,141,162), 1 MSE vs constant target (experiment1_global_local_D.py:162),
+ * 2 mean (wgan_l1.py:137-143,177; gscale carries the +1/-1 of backward(one/mone)) */
+int gi_loss_adv(gi_ctx* ctx, const float* pred, int n, int kind, float target, float* loss_out,
+                float* grad_pred, float gscale);
+
+/* ---- optimizers over flat fp32 buffers: optim.Adam(lr=2e-4,betas=(.5,.999))
+ *      (minimaxgan_l1.py:64-65), optim.RMSprop(lr=5e-5) + p.data.clamp_(-c,c)
+ *      (wgan_l1.py:64-65,151-153; clamp<=0 disables) ---------------------------------------- */
+int gi_adam_step(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
+                 float beta1, float beta2, float eps, int step, float grad_scale);
+int gi_rmsprop_step(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr,
+                    float alpha, float eps, float clamp, float grad_scale);
+int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi);
+/* mean(|g|) of `nseg` segments [off[i], off[i]+len[i]) of g -> out[i]
+ * (gradient-flow statistics, minimaxgan_l1.py:180-182); offsets/lengths are device int64 */
+int gi_grad_absmean(gi_ctx* ctx, const float* g, const int64_t* seg_off, const int64_t* seg_len,
+                    int nseg, float* out);
+
+/* ---- single-layer entry points (unit parity tests and kernel roofline measurements) -------- */
+/* out[n,y,x,a] = act( sum_{ky,kx,b} in[n,2y-1+ky,2x-1+kx,b] * w[a][ky][kx][b] ), NHWC, dtype T.
+ * in: (n,H,W,cb) ld=ldin; out: (n,H/2,W/2,ca) ld=ldout. w_packed is T [ca][16*cb].
+ * partials (may be NULL) receives per-tile column sum / sum of squares; ws: split-K scratch */
+int gi_conv_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out,
+                       int n, int H, int W, int cb, int ldin, int ca, int ldout, int relu_in,
+                       int act_out, float* ws, int64_t ws_bytes);
+/* out[n,2y-1+ky,2x-1+kx,b] += in[n,y,x,a]*w[a][ky][kx][b] (transposed conv k4 s2 p1) as four
+ * sub-pixel 2x2 convolutions. in: (n,H,W,ca); out: (n,2H,2W,cb); w_phase is T [4][cb][4*ca]
+ * produced by gi_pack_weights */
+int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_phase, void* out,
+                        int n, int H, int W, int ca, int ldin, int cb, int ldout, int relu_in,
+                        int act_out, float* ws, int64_t ws_bytes);
+/* dW[a][ky][kx][b] += scale * sum_{n,y,x} S[n,y,x,a] * L[n,2y-1+ky,2x-1+kx,b] */
+int gi_wgrad_s2(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW, int n, int Hs, int Ws,
+                int ca, int ldS, int cb, int ldL, int relu_S, float scale);
+/* fp32 master [a][16][b] -> T [a][16*b] (w_packed) and T [4][b][4*a] (w_phase); either may be NULL */
+int gi_pack_weights(gi_ctx* ctx, int dtype, const float* w, int ca, int cb, void* w_packed, void* w_phase);
+int gi_convert(gi_ctx* ctx, int dtype, const float* src, void* dst, int64_t count);      /* fp32 -> T */
+int gi_convert_back(gi_ctx* ctx, int dtype, const void* src, float* dst, int64_t count); /* T -> fp32 */
+
+/* time the dominant kernel `iters` times with hipEvents on the context stream; returns average
+ * milliseconds per launch in *ms_out (used by bench.py for the roofline object) */
+int gi_time_convT_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_phase, void* out, int n, int H,
+                     int W, int ca, int ldin, int cb, int ldout, int iters, float* ms_out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANINPAINT_H */
