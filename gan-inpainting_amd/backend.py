@@ -1,0 +1,132 @@
+"""ctypes binding of libganinpaint.so (include/ganinpaint.h). Torch tensors are containers only:
+device memory + streams; every pointer handed over is `tensor.data_ptr()`."""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libganinpaint.so")
+
+GI_F32, GI_F16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+_vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes). This table is also what tests/test_abi.py checks against the header.
+PROTOTYPES = {
+    "gi_last_error": (C.c_char_p, []),
+    "gi_version": (_i, []),
+    "gi_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
+    "gi_ctx_destroy": (_i, [_vp]),
+    "gi_ctx_sync": (_i, [_vp]),
+    "gi_unet_create": (_i, [_vp, _i, _i, _f, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "gi_patchgan_create": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "gi_net_destroy": (_i, [_vp]),
+    "gi_net_tensor_count": (_i, [_vp]),
+    "gi_net_tensor_desc": (_i, [_vp, _i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(_i64), C.POINTER(_i),
+                                C.POINTER(_i64), C.POINTER(_i64)]),
+    "gi_net_param_floats": (_i64, [_vp]),
+    "gi_net_buffer_floats": (_i64, [_vp]),
+    "gi_net_workspace_bytes": (_i64, [_vp]),
+    "gi_net_bind": (_i, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "gi_net_sync_weights": (_i, [_vp]),
+    "gi_net_set_train": (_i, [_vp, _i]),
+    "gi_net_set_loss_scale": (_i, [_vp, _f]),
+    "gi_net_set_dropout_seed": (_i, [_vp, _u64]),
+    "gi_net_dropout_mask": (_i, [_vp, _i, _i, _vp, _i64]),
+    "gi_net_set_dropout_mask": (_i, [_vp, _i, _i, _vp]),
+    "gi_net_forward": (_i, [_vp, _i, _vp, _vp, _i]),
+    "gi_net_backward": (_i, [_vp, _i, _vp, _vp, _i]),
+    "gi_net_backward_phase": (_i, [_vp, _i, _vp, _vp, _i, _i]),
+    "gi_net_phase_split": (_i64, [_vp]),
+    "gi_mask_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i]),
+    "gi_mask_composite": (_i, [_vp, _vp, _vp, _vp, _vp, _i64]),
+    "gi_mul": (_i, [_vp, _vp, _vp, _vp, _i64]),
+    "gi_add": (_i, [_vp, _vp, _vp, _vp, _i64, _f]),
+    "gi_loss_l1": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _f, _vp]),
+    "gi_loss_rmse": (_i, [_vp, _vp, _vp, _i64, _f, _vp, _vp, _f, _vp]),
+    "gi_loss_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _f, _vp]),
+    "gi_loss_local": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _f, _vp]),
+    "gi_loss_adv": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _f]),
+    "gi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f]),
+    "gi_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f]),
+    "gi_clamp": (_i, [_vp, _vp, _i64, _f, _f]),
+    "gi_grad_absmean": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
+    "gi_convT_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
+    "gi_wgrad_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f]),
+    "gi_pack_weights": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "gi_convert": (_i, [_vp, _i, _vp, _vp, _i64]),
+    "gi_convert_back": (_i, [_vp, _i, _vp, _vp, _i64]),
+    "gi_time_convT_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library. Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise BackendError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(gan-inpainting_amd/csrc/build.sh). There is no CPU fallback.")
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in PROTOTYPES.items():
+                    fn = getattr(handle, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise BackendError(f"libganinpaint error {status}: {lib().gi_last_error().decode(errors='replace')}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+_ctx_cache = {}
+
+
+def get_ctx(device=None):
+    """One gi_ctx per (device, current torch stream)."""
+    if not torch.cuda.is_available():
+        raise BackendError("no MI355X visible (torch.cuda.is_available() is False); the HIP backend has no CPU fallback")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(idx).cuda_stream
+    key = (idx, stream)
+    if key not in _ctx_cache:
+        h = _vp()
+        check(lib().gi_ctx_create(idx, _vp(stream), C.byref(h)))
+        _ctx_cache[key] = h
+    return _ctx_cache[key]
+
+
+def dtype_code(dtype):
+    if dtype in (GI_F16, "fp16", "f16", torch.float16):
+        return GI_F16
+    if dtype in (GI_F32, "fp32", "f32", torch.float32):
+        return GI_F32
+    raise ValueError(f"unsupported compute dtype {dtype!r} (fp16 or fp32)")
+
+
+def torch_dtype(code):
+    return torch.float16 if code == GI_F16 else torch.float32

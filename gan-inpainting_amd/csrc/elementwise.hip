@@ -269,6 +269,9 @@ __global__ void __launch_bounds__(256) mask_composite_kernel(const float* masked
 __global__ void __launch_bounds__(256) mul_kernel(const float* a, const float* b, float* out, int64_t count) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) out[i] = a[i] * b[i];
 }
+__global__ void __launch_bounds__(256) add_kernel(const float* a, const float* b, float* out, int64_t count, float alpha) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) out[i] = a[i] + alpha * b[i];
+}
 __global__ void __launch_bounds__(256) tanh_bwd_kernel(const float* dy, const float* y, float* dx, int64_t count, float scale) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
     dx[i] = dy[i] * (1.f - y[i] * y[i]) * scale;
@@ -596,6 +599,12 @@ int gi_mask_composite(gi_ctx* ctx, const float* masked, const float* gen, const 
 }
 int gi_mul(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count) {
   hipLaunchKernelGGL(mul_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, a, b, out, count);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int gi_add(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count, float alpha) {
+  hipLaunchKernelGGL(add_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, a, b, out, count, alpha);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

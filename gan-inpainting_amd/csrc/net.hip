@@ -539,7 +539,10 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   return GI_OK;
 }
 
-int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad) {
+// phase: 0 = whole backward; 1 = decoder half (u1 .. u_nd: their parameter gradients occupy the tail
+// of the flat gradient buffer and are complete when this returns); 2 = encoder half (d_nd .. d1).
+// Splitting lets the host start the decoder gradients' all-reduce while the encoder half runs.
+int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad, int phase) {
   hipStream_t st = net->ctx->stream;
   const int nd = net->nd, dt = net->dtype;
   const int H = net->H, W = net->W, n = net->slot_n[s];
@@ -551,6 +554,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   void* D = net->shared(net->oD);
   float* G0 = (float*)net->shared(net->oG0);
   const int64_t npx = (int64_t)n * H * W;
+  if (phase != 2) {
   // tanh' and loss scaling
   GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx, LS));
   // u1: ConvTranspose2d(2ngf -> 1) + bias
@@ -577,6 +581,8 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     GI_TRY(igemm(net, 0, D, ck, ck, 0, packed_ptr(net, net->up[kk]), gout, ca, ca, 0, n, net->Hk[kk], net->Wk[kk], 0, GI_ACT_NONE,
                  false, nullptr));
   }
+  }  // decoder half
+  if (phase == 1) return GI_OK;
   // innermost conv (no norm): dz = gE * [E > 0]
   {
     const int c = net->ch[nd];
@@ -688,5 +694,24 @@ extern "C" int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx
   GI_REQUIRE(net && net->bound, "net_backward: net not bound");
   GI_REQUIRE(dy, "net_backward: dy is null");
   GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_backward: slot=%d", slot);
-  return net->kind == 0 ? unet_backward(net, slot, dy, dx, need_wgrad) : patchgan_backward(net, slot, dy, dx, need_wgrad);
+  return net->kind == 0 ? unet_backward(net, slot, dy, dx, need_wgrad, 0) : patchgan_backward(net, slot, dy, dx, need_wgrad);
+}
+
+extern "C" int gi_net_backward_phase(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad, int phase) {
+  GI_REQUIRE(net && net->bound, "net_backward_phase: net not bound");
+  GI_REQUIRE(dy, "net_backward_phase: dy is null");
+  GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_backward_phase: slot=%d", slot);
+  GI_REQUIRE(phase >= 0 && phase <= 2, "net_backward_phase: phase=%d", phase);
+  if (net->kind != 0) {
+    if (phase == 2) return GI_OK;   // discriminator: everything happens in phase 0/1
+    return patchgan_backward(net, slot, dy, dx, need_wgrad);
+  }
+  return unet_backward(net, slot, dy, dx, need_wgrad, phase);
+}
+
+// first float of the gradient region completed by phase 1 (generator: the innermost up-conv weight)
+extern "C" int64_t gi_net_phase_split(gi_net* net) {
+  if (!net) return GI_ERR_INVALID;
+  if (net->kind != 0) return 0;
+  return net->up[net->nd].w_off;
 }

@@ -1,0 +1,482 @@
+"""Drop-in for the reference's lib/models/networks.py (get_network :13-28, UnetGenerator :216-253,
+PatchGANDiscriminator :331-363) on the HIP backend.
+
+The classes are torch.nn.Modules whose parameters/buffers are zero-copy views into flat fp32
+device buffers owned by the module and bound to a libganinpaint handle:
+  * state_dict() keys, shapes, dtypes and named_parameters() order equal the reference's
+    (conv weights are logical [a,b,4,4] tensors with channels_last strides);
+  * `.grad` of every parameter is a view into the flat gradient buffer the kernels accumulate into;
+  * __call__ takes/returns fp32 (N,1,H,W) / (N,1) tensors and takes part in torch autograd through
+    one autograd.Function per network (whole-net forward / backward in the library).
+Nothing here computes on the CPU: calling a module that is not on a gfx950 device raises.
+"""
+import ctypes as C
+import functools
+import math
+
+import torch
+from torch import nn
+
+from ... import backend as B
+
+DEFAULT_DTYPE = "fp16"
+
+
+def set_default_dtype(dtype):
+    """Compute/storage type of networks created afterwards: 'fp16' (MFMA f16, fp32 accumulate,
+    fp32 master weights, loss-scaled backward) or 'fp32' (exact-fp32 MFMA)."""
+    global DEFAULT_DTYPE
+    B.dtype_code(dtype)
+    DEFAULT_DTYPE = dtype
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+def get_norm_layer(norm_type="instance"):
+    """networks.py:30-45. Only 'batch' is executed by the HIP backend (it is the only one
+    get_network ever builds, networks.py:18)."""
+    if norm_type == "batch":
+        return functools.partial(nn.BatchNorm2d, affine=True, track_running_stats=True)
+    if norm_type == "instance":
+        return functools.partial(nn.InstanceNorm2d, affine=False, track_running_stats=False)
+    if norm_type == "none":
+        return lambda x: Identity()
+    raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+
+
+def get_network(type, name, **kw):
+    """networks.py:13-28. vgg19 / dcgan are not on the accelerated path."""
+    if type == "generator":
+        if name == "unet":
+            return UnetGenerator(1, 1, 7, ngf=64, norm_layer=get_norm_layer(norm_type="batch"),
+                                 use_dropout="False", **kw)
+        if name == "vgg19":
+            raise NotImplementedError("VGG19Generator is outside the HIP backend's hot path")
+        raise Exception("Invalid generator network name")
+    if type == "discriminator":
+        if name == "patchgan":
+            return PatchGANDiscriminator(**kw)
+        if name == "dcgan":
+            raise NotImplementedError("DCGANDiscriminator is outside the HIP backend's hot path")
+        raise Exception("Invalid discriminator network name")
+    raise Exception("Invalid network type")
+
+
+class _Holder(nn.Module):
+    """Structural node: reproduces the reference's module nesting so state_dict keys match."""
+
+
+class _NetFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, net):
+        need_wgrad = any(p.requires_grad for p in net.parameters())
+        y, slot, gen = net._forward_raw(x)
+        ctx.net, ctx.slot, ctx.gen = net, slot, gen
+        ctx.need_dx = x.requires_grad
+        ctx.need_wgrad = need_wgrad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        net = ctx.net
+        dx = net._backward_raw(ctx.slot, ctx.gen, dy, ctx.need_dx, ctx.need_wgrad)
+        return dx, None, None
+
+
+class HipNet(nn.Module):
+    """Common machinery: inventory, flat buffers, handle (re)creation, raw forward/backward."""
+
+    n_slots = 3
+
+    def __init__(self, dtype=None):
+        super().__init__()
+        self._dtype = B.dtype_code(dtype or DEFAULT_DTYPE)
+        self._handle = None          # sized handle (device)
+        self._geom = None            # (H, W, max_n)
+        self._flat = None            # dict of flat device tensors
+        self._dirty = True
+        self._next_slot = 0
+        self._slot_gen = [0] * self.n_slots
+        self._bn_count_buffers = []
+        self._anchor = None
+        self._loss_scale = 1024.0 if self._dtype == B.GI_F16 else 1.0
+        self.always_sync = False
+
+    # ---- subclass hooks ----------------------------------------------------------------------
+    def _create_handle(self, ctx, H, W, max_n):
+        raise NotImplementedError
+
+    def _output_shape(self, n, H, W):
+        raise NotImplementedError
+
+    # ---- inventory ---------------------------------------------------------------------------
+    def _inventory(self, handle):
+        lib = B.lib()
+        out = []
+        name = C.create_string_buffer(256)
+        kind, ndim = C.c_int(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        off, numel = C.c_int64(), C.c_int64()
+        for i in range(lib.gi_net_tensor_count(handle)):
+            B.check(lib.gi_net_tensor_desc(handle, i, name, 256, C.byref(kind), shape, C.byref(ndim), C.byref(off),
+                                           C.byref(numel)))
+            out.append(dict(name=name.value.decode(), kind=kind.value, shape=tuple(shape[j] for j in range(ndim.value)),
+                            offset=off.value, numel=numel.value))
+        return out
+
+    def _build_tree(self, inv, n_params, n_buffers):
+        """Create the nested holders and register parameters/buffers as views of CPU flat buffers."""
+        self._inv = inv
+        self._n_params, self._n_buffers = n_params, n_buffers
+        flat = dict(params=torch.zeros(n_params), grads=None, buffers=torch.zeros(n_buffers))
+        self._flat = flat
+        self._tensor_refs = {}
+        for t in inv:
+            parts = t["name"].split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, _Holder())
+                mod = mod._modules[p]
+            view = self._view(flat["params" if t["kind"] <= 1 else "buffers"], t)
+            if t["kind"] <= 1:
+                prm = nn.Parameter(view, requires_grad=True)
+                mod.register_parameter(parts[-1], prm)
+                self._tensor_refs[t["name"]] = (mod, parts[-1], True)
+            else:
+                mod.register_buffer(parts[-1], view)
+                self._tensor_refs[t["name"]] = (mod, parts[-1], False)
+                if t["kind"] == 3:  # after running_var: the reference's num_batches_tracked buffer
+                    mod.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+                    self._bn_count_buffers.append(mod)
+
+    @staticmethod
+    def _view(flat, t):
+        v = flat[t["offset"]: t["offset"] + t["numel"]]
+        if t["kind"] == 0:  # physical [a][ky][kx][b] -> logical [a,b,4,4] (channels_last strides)
+            a, b = t["shape"][0], t["shape"][1]
+            return v.view(a, 4, 4, b).permute(0, 3, 1, 2)
+        return v.view(*t["shape"])
+
+    def _reset_batchnorm(self):
+        for t in self._inv:
+            if t["kind"] == 2:
+                prefix = t["name"][:-len("running_mean")]
+                self._tensor(prefix + "weight").fill_(1.0)
+                self._tensor(prefix + "bias").zero_()
+                self._tensor(prefix + "running_mean").zero_()
+                self._tensor(prefix + "running_var").fill_(1.0)
+        for mod in self._bn_count_buffers:
+            mod._buffers["num_batches_tracked"].zero_()
+
+    def _tensor(self, name):
+        mod, leaf, is_param = self._tensor_refs[name]
+        return mod._parameters[leaf] if is_param else mod._buffers[leaf]
+
+    # ---- device placement --------------------------------------------------------------------
+    def _apply(self, fn, recurse=True):
+        # .to()/.cuda()/.cpu()/.float(): move the FLAT buffers and re-point every view at them
+        old = self._flat
+        new_params = fn(old["params"])
+        new_buffers = fn(old["buffers"])
+        if new_params.dtype != torch.float32:
+            raise TypeError("HIP backend keeps fp32 master weights; choose the compute type with dtype='fp16'")
+        moved = new_params.device != old["params"].device
+        self._flat = dict(params=new_params.contiguous(), buffers=new_buffers.contiguous(), grads=None)
+        with torch.no_grad():
+            for t in self._inv:
+                mod, leaf, is_param = self._tensor_refs[t["name"]]
+                view = self._view(self._flat["params" if t["kind"] <= 1 else "buffers"], t)
+                if is_param:
+                    mod._parameters[leaf].data = view
+                    mod._parameters[leaf].grad = None
+                else:
+                    mod._buffers[leaf] = view
+            for mod in self._bn_count_buffers:
+                mod._buffers["num_batches_tracked"] = fn(mod._buffers["num_batches_tracked"])
+        if moved:
+            self._release_handle()
+        self._dirty = True
+        if self._flat["params"].is_cuda:
+            self._attach_grads()
+            self._anchor = torch.zeros(1, device=self._flat["params"].device, requires_grad=True)
+        return self
+
+    def _attach_grads(self):
+        if self._flat["grads"] is None:
+            self._flat["grads"] = torch.zeros_like(self._flat["params"])
+        for t in self._inv:
+            if t["kind"] <= 1:
+                p = self._tensor(t["name"])
+                g = self._view(self._flat["grads"], t)
+                if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                    p.grad = g
+                p._gi_owner = self
+
+    def _release_handle(self):
+        if self._handle is not None:
+            B.lib().gi_net_destroy(self._handle)
+            self._handle = None
+            self._geom = None
+            self._ws = None
+
+    def __del__(self):
+        try:
+            self._release_handle()
+        except Exception:
+            pass
+
+    @property
+    def device(self):
+        return self._flat["params"].device
+
+    def flat_params(self):
+        return self._flat["params"]
+
+    def flat_grads(self):
+        self._attach_grads()
+        return self._flat["grads"]
+
+    def mark_dirty(self):
+        """Parameters were written outside the library: packed fp16/phase copies are stale."""
+        self._dirty = True
+
+    def set_loss_scale(self, scale):
+        self._loss_scale = float(scale)
+        if self._handle is not None:
+            B.check(B.lib().gi_net_set_loss_scale(self._handle, self._loss_scale))
+
+    def zero_grad(self, set_to_none=False):
+        if self._flat["grads"] is not None:
+            self._flat["grads"].zero_()
+        self._attach_grads() if self._flat["params"].is_cuda else None
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._dirty = True
+        return res
+
+    # ---- handle -------------------------------------------------------------------------------
+    def _ensure_handle(self, n, H, W):
+        if not self._flat["params"].is_cuda:
+            raise B.BackendError(f"{type(self).__name__} lives on {self.device}: the HIP backend runs on a gfx950 "
+                                 "device only (no CPU fallback). Call .to('cuda') first.")
+        if self._handle is not None and self._geom[0] == H and self._geom[1] == W and n <= self._geom[2]:
+            return
+        self._release_handle()
+        ctx = B.get_ctx(self.device)
+        h = self._create_handle(ctx, H, W, n)
+        lib = B.lib()
+        assert lib.gi_net_param_floats(h) == self._n_params, "parameter inventory changed with geometry"
+        nbytes = lib.gi_net_workspace_bytes(h)
+        self._ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self._ws.data_ptr()) % 256
+        self._attach_grads()
+        B.check(lib.gi_net_bind(h, B.ptr(self._flat["params"]), B.ptr(self._flat["grads"]), B.ptr(self._flat["buffers"]),
+                                self._ws.data_ptr() + off, nbytes))
+        B.check(lib.gi_net_set_loss_scale(h, self._loss_scale))
+        self._handle, self._geom = h, (H, W, n)
+        self._dirty = True
+
+    def _forward_raw(self, x):
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"expected (N,1,H,W) input, got {tuple(x.shape)}")
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise B.BackendError("input must be a float32 tensor on the module's gfx950 device")
+        x = x.contiguous()
+        n, _, H, W = x.shape
+        self._ensure_handle(n, H, W)
+        lib = B.lib()
+        if self._dirty or self.always_sync:
+            B.check(lib.gi_net_sync_weights(self._handle))
+            self._dirty = False
+        B.check(lib.gi_net_set_train(self._handle, 1 if self.training else 0))
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self.n_slots
+        self._slot_gen[slot] += 1
+        y = torch.empty(self._output_shape(n, H, W), dtype=torch.float32, device=x.device)
+        B.check(lib.gi_net_forward(self._handle, slot, B.ptr(x), B.ptr(y), n))
+        if self.training:
+            for mod in self._bn_count_buffers:
+                mod._buffers["num_batches_tracked"] += 1
+        self._last_slot = slot
+        return y, slot, self._slot_gen[slot]
+
+    def _backward_raw(self, slot, gen, dy, need_dx, need_wgrad):
+        if self._slot_gen[slot] != gen:
+            raise B.BackendError(f"activations of this forward were overwritten: more than {self.n_slots} forwards of "
+                                 f"{type(self).__name__} were live before their backward")
+        dy = dy.contiguous().float()
+        n = dy.shape[0]
+        dx = torch.empty((n, 1, self._geom[0], self._geom[1]), dtype=torch.float32, device=dy.device) if need_dx else None
+        self._attach_grads()
+        B.check(B.lib().gi_net_backward(self._handle, slot, B.ptr(dy), B.ptr(dx), 1 if need_wgrad else 0))
+        return dx
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and self.training:
+            return _NetFunction.apply(x, self._anchor, self)
+        return self._forward_raw(x)[0]
+
+
+def _init_conv(cout, cin, transposed=False, bias=False):
+    """Draw from torch's global RNG exactly as the reference's constructors do
+    (nn.Conv2d / nn.ConvTranspose2d default init: kaiming_uniform(a=sqrt(5)), then bias)."""
+    m = (nn.ConvTranspose2d(cin, cout, 4, 2, 1, bias=bias) if transposed else nn.Conv2d(cin, cout, 4, 2, 1, bias=bias))
+    return m.weight.detach(), (m.bias.detach() if bias else None)
+
+
+class UnetGenerator(HipNet):
+    """networks.py:216-253 (+ UnetSkipConnectionBlock :255-324). input_nc = output_nc = 1."""
+
+    def __init__(self, input_nc=1, output_nc=1, num_downs=7, ngf=64, norm_layer=nn.BatchNorm2d, use_dropout=False,
+                 use_sigmoid_output=False, dtype=None):
+        super().__init__(dtype)
+        if input_nc != 1 or output_nc != 1:
+            raise NotImplementedError("HIP backend: UnetGenerator is built for 1-channel images (input_nc=output_nc=1)")
+        fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+        if fn is not nn.BatchNorm2d:
+            raise NotImplementedError("HIP backend: only BatchNorm2d generators (the get_network default) are built")
+        if use_sigmoid_output:
+            raise NotImplementedError("use_sigmoid_output is never enabled by the reference (networks.py:250)")
+        self.num_downs, self.ngf = num_downs, ngf
+        # any truthy value enables dropout, including the string 'False' (networks.py:18-19, :313)
+        self.dropout_p = 0.5 if use_dropout else 0.0
+        lib = B.lib()
+        h = C.c_void_p()
+        size0 = 1 << max(num_downs, 7)
+        B.check(lib.gi_unet_create(None, num_downs, ngf, self.dropout_p, size0, size0, 1, self._dtype, 1, C.byref(h)))
+        self._build_tree(self._inventory(h), lib.gi_net_param_floats(h), lib.gi_net_buffer_floats(h))
+        lib.gi_net_destroy(h)
+        self.reset_parameters()
+
+    def _level_names(self):
+        """(down conv, up conv) weight names per level 1..num_downs (nesting of networks.py:296-318)."""
+        out, p = [], "model.model"
+        for k in range(1, self.num_downs + 1):
+            outer, inner = k == 1, k == self.num_downs
+            out.append((p + (".0" if outer else ".1") + ".weight", p + (".3" if (outer or inner) else ".5") + ".weight"))
+            p = p + (".1" if outer else ".3") + ".model"
+        return out
+
+    def reset_parameters(self):
+        """Same RNG consumption order as the reference constructor: blocks are built innermost
+        first (networks.py:236-243), each drawing downconv then upconv(+bias) (:285-309);
+        BatchNorm draws nothing (weight 1, bias 0, running stats 0/1)."""
+        with torch.no_grad():
+            for down, up in reversed(self._level_names()):
+                a, b = self._tensor(down).shape[:2]
+                w, _ = _init_conv(a, b)                                   # Conv2d weight [out=a, in=b, 4, 4]
+                self._tensor(down).copy_(w)
+                a, b = self._tensor(up).shape[:2]
+                bias_name = up[:-len("weight")] + "bias"
+                has_bias = bias_name in self._tensor_refs
+                w, bias = _init_conv(b, a, transposed=True, bias=has_bias)  # ConvTranspose2d weight [in=a, out=b, 4, 4]
+                self._tensor(up).copy_(w)
+                if has_bias:
+                    self._tensor(bias_name).copy_(bias)
+            self._reset_batchnorm()
+        self._dirty = True
+
+    def _create_handle(self, ctx, H, W, max_n):
+        h = C.c_void_p()
+        B.check(B.lib().gi_unet_create(ctx, self.num_downs, self.ngf, self.dropout_p, H, W, max_n, self._dtype,
+                                       self.n_slots, C.byref(h)))
+        return h
+
+    def _output_shape(self, n, H, W):
+        return (n, 1, H, W)
+
+    # dropout control (parity tests feed the device-generated masks to the oracle, or impose masks)
+    def set_dropout_seed(self, seed):
+        self._drop_seed = int(seed)
+        if self._handle is not None:
+            B.check(B.lib().gi_net_set_dropout_seed(self._handle, self._drop_seed))
+
+    def dropout_masks(self, slot=None):
+        """{level: uint8 keep-mask (N,C,H,W)} used by the last train-mode forward."""
+        slot = self._last_slot if slot is None else slot
+        out = {}
+        H, W, _ = self._geom
+        n = None
+        for lvl in range(5, self.num_downs):
+            c = self.ngf * min(2 ** (lvl - 2), 8)
+            h, w = H >> (lvl - 1), W >> (lvl - 1)
+            n = self._last_n if n is None else n
+            m = torch.empty((n, c, h, w), dtype=torch.uint8, device=self.device)
+            B.check(B.lib().gi_net_dropout_mask(self._handle, slot, lvl, B.ptr(m), m.numel()))
+            out[lvl] = m
+        return out
+
+    def _forward_raw(self, x):
+        self._last_n = x.shape[0]
+        if getattr(self, "_pending_masks", None):
+            self._ensure_handle(x.shape[0], x.shape[2], x.shape[3])
+            slot = self._next_slot
+            self._mask_keep = {k: v.to(self.device).contiguous() for k, v in self._pending_masks.items()}
+            for lvl, m in self._mask_keep.items():
+                B.check(B.lib().gi_net_set_dropout_mask(self._handle, slot, lvl, B.ptr(m)))
+            out = super()._forward_raw(x)
+            for lvl in self._mask_keep:
+                B.check(B.lib().gi_net_set_dropout_mask(self._handle, slot, lvl, None))
+            self._pending_masks = None
+            return out
+        return super()._forward_raw(x)
+
+    def impose_dropout_masks(self, masks):
+        """Use these keep-masks ({level: uint8 (N,C,H,W)}) in the NEXT forward (parity tests)."""
+        self._pending_masks = dict(masks)
+
+
+class Flatten(nn.Module):
+    def forward(self, input):
+        return input.view(input.size(0), -1)
+
+
+class PatchGANDiscriminator(HipNet):
+    """networks.py:331-363. `image_size` generalises the hard-coded Linear(25,1) (valid for
+    128x128 only) to Linear((H/16-3)*(W/16-3), 1); n_d_channel is ignored as in the reference."""
+
+    def __init__(self, c=1, n_d_channel=64, sigmoid=True, image_size=128, dtype=None):
+        super().__init__(dtype)
+        if c != 1:
+            raise NotImplementedError("HIP backend: PatchGANDiscriminator is built for 1-channel images")
+        self.sigmoid = bool(sigmoid)
+        self.image_size = (image_size, image_size) if isinstance(image_size, int) else tuple(image_size)
+        lib = B.lib()
+        h = C.c_void_p()
+        B.check(lib.gi_patchgan_create(None, self.image_size[0], self.image_size[1], int(self.sigmoid), 1, self._dtype, 1,
+                                       C.byref(h)))
+        self._build_tree(self._inventory(h), lib.gi_net_param_floats(h), lib.gi_net_buffer_floats(h))
+        lib.gi_net_destroy(h)
+        self.always_sync = True   # 2.8 M params: re-deriving the packed copies costs microseconds and makes
+        #                           raw `p.data.clamp_()` loops (wgan_l1.py:151-153) safe
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            chans = [1, 64, 128, 256, 512]
+            for i, idx in enumerate((0, 2, 5, 8)):
+                w, _ = _init_conv(chans[i + 1], chans[i])
+                self._tensor(f"model.{idx}.weight").copy_(w)
+            m = nn.Conv2d(512, 1, 4, 1, 0, bias=False)
+            self._tensor("model.11.weight").copy_(m.weight.detach())
+            lin = nn.Linear(self._tensor("model.13.weight").shape[1], 1)
+            self._tensor("model.13.weight").copy_(lin.weight.detach())
+            self._tensor("model.13.bias").copy_(lin.bias.detach())
+            self._reset_batchnorm()
+        self._dirty = True
+
+    def _create_handle(self, ctx, H, W, max_n):
+        if (H, W) != self.image_size:
+            raise ValueError(f"PatchGANDiscriminator was built for {self.image_size} images (its Linear head has "
+                             f"{self._tensor('model.13.weight').shape[1]} inputs), got {(H, W)}")
+        h = C.c_void_p()
+        B.check(B.lib().gi_patchgan_create(ctx, H, W, int(self.sigmoid), max_n, self._dtype, self.n_slots, C.byref(h)))
+        return h
+
+    def _output_shape(self, n, H, W):
+        return (n, 1)

@@ -1,0 +1,80 @@
+"""Fused optimizers with the torch.optim call surface the plugins use:
+    optim.Adam(net.parameters(), lr=0.0002, betas=(0.5, 0.999))     minimaxgan_l1.py:64-65
+    optim.RMSprop(net.parameters(), lr=0.00005)                     wgan_l1.py:64-65
+One kernel per network over its flat fp32 parameter / gradient / state buffers."""
+import itertools
+
+import torch
+
+from . import backend as B
+
+
+class _FlatOptimizer:
+    def __init__(self, params):
+        params = list(params)
+        if not params:
+            raise ValueError("optimizer got an empty parameter list")
+        owners = []
+        for p in params:
+            owner = getattr(p, "_gi_owner", None)
+            if owner is None:
+                raise B.BackendError("parameter does not belong to a HIP-backend network on a gfx950 device "
+                                     "(move the network with .to('cuda') before building the optimizer)")
+            if all(owner is not o for o in owners):
+                owners.append(owner)
+        for o in owners:
+            mine = sum(1 for p in params if getattr(p, "_gi_owner", None) is o)
+            if mine != sum(1 for _ in o.parameters()):
+                raise B.BackendError("the fused optimizers update whole networks: pass all of net.parameters()")
+        self.nets = owners
+        self.param_groups = [dict(params=params)]
+        self.grad_scale = 1.0   # multiplies every gradient (e.g. 1/world_size after a SUM all-reduce)
+
+    def zero_grad(self, set_to_none=False):
+        for n in self.nets:
+            n.zero_grad()
+
+    def _done(self):
+        for n in self.nets:
+            n.mark_dirty()
+
+
+class Adam(_FlatOptimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.state = [dict(m=torch.zeros_like(n.flat_params()), v=torch.zeros_like(n.flat_params())) for n in self.nets]
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        lib = B.lib()
+        for n, st in zip(self.nets, self.state):
+            p, g = n.flat_params(), n.flat_grads()
+            B.check(lib.gi_adam_step(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
+                                     self.lr, self.betas[0], self.betas[1], self.eps, self.t, self.grad_scale))
+        self._done()
+
+
+class RMSprop(_FlatOptimizer):
+    """torch.optim.RMSprop defaults (alpha=0.99, eps=1e-8, no momentum, not centered). `clamp` > 0
+    fuses the WGAN weight clipping p.data.clamp_(-clamp, clamp) into the same pass."""
+
+    def __init__(self, params, lr=1e-2, alpha=0.99, eps=1e-8, clamp=0.0):
+        super().__init__(params)
+        self.lr, self.alpha, self.eps, self.clamp = lr, alpha, eps, clamp
+        self.state = [dict(sq=torch.zeros_like(n.flat_params())) for n in self.nets]
+
+    @torch.no_grad()
+    def step(self):
+        lib = B.lib()
+        for n, st in zip(self.nets, self.state):
+            p, g = n.flat_params(), n.flat_grads()
+            B.check(lib.gi_rmsprop_step(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["sq"]), p.numel(), self.lr,
+                                        self.alpha, self.eps, self.clamp, self.grad_scale))
+        self._done()
+
+
+def chain(*its):
+    return itertools.chain(*its)

@@ -1,0 +1,251 @@
+"""Per-batch step schedules of the reference's training loops, driven straight through the C-ABI
+(no autograd graph, preallocated buffers, no host synchronisation inside a step):
+
+    MinimaxStep   experiment_list/minimaxgan_l1.py:110-173 (recon='rmse': minimaxgan_rmse.py)
+    WGANStep      experiment_list/wgan_l1.py:110-186 / wgan_rmse.py  (weight clipping :151-153)
+    DualDStep     experiment_list/experiment1_global_local_D.py:139-200
+
+Scalar losses stay on the device (1-element tensors); the plugins read them back at their own
+logging cadence. With a GradSync (parallel.py) every optimizer step is preceded by a bucketed
+all-reduce of that network's flat gradient buffer.
+"""
+import torch
+
+from . import backend as B
+from . import optim
+from .lib.models import util
+
+
+class _Ops:
+    """Thin allocation-free wrappers over the elementwise / loss entry points."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        self.scratch = torch.empty(4096, dtype=torch.float32, device=self.dev)
+
+    @property
+    def ctx(self):
+        return B.get_ctx(self.dev)
+
+    def mask_apply(self, ground, mask, mask_c, masked, do_ceil):
+        B.check(B.lib().gi_mask_apply(self.ctx, B.ptr(ground), B.ptr(mask), B.ptr(mask_c), B.ptr(masked), ground.numel(),
+                                      1 if do_ceil else 0))
+
+    def composite(self, masked, gen, mask_c, out):
+        B.check(B.lib().gi_mask_composite(self.ctx, B.ptr(masked), B.ptr(gen), B.ptr(mask_c), B.ptr(out), out.numel()))
+
+    def mul(self, a, b, out):
+        B.check(B.lib().gi_mul(self.ctx, B.ptr(a), B.ptr(b), B.ptr(out), out.numel()))
+
+    def add(self, a, b, out, alpha=1.0):
+        B.check(B.lib().gi_add(self.ctx, B.ptr(a), B.ptr(b), B.ptr(out), out.numel(), float(alpha)))
+
+    def adv(self, pred, kind, target, loss_out, grad, gscale=1.0):
+        B.check(B.lib().gi_loss_adv(self.ctx, B.ptr(pred), pred.numel(), kind, float(target), B.ptr(loss_out), B.ptr(grad),
+                                    float(gscale)))
+
+    def recon(self, kind, a, b, loss_out, grad, gscale=1.0):
+        lib = B.lib()
+        if kind == "l1":
+            B.check(lib.gi_loss_l1(self.ctx, B.ptr(a), B.ptr(b), a.numel(), B.ptr(loss_out), B.ptr(grad), float(gscale), B.ptr(self.scratch)))
+        elif kind == "rmse":
+            B.check(lib.gi_loss_rmse(self.ctx, B.ptr(a), B.ptr(b), a.numel(), 1e-16, B.ptr(loss_out), B.ptr(grad), float(gscale),
+                                     B.ptr(self.scratch)))
+        else:
+            raise ValueError(kind)
+
+
+BCE, LSGAN, MEAN = 0, 1, 2
+
+
+class _StepBase:
+    def __init__(self, net_G, nets_D, device, sync=None):
+        self.G, self.Ds = net_G, list(nets_D)
+        self.ops = _Ops(device)
+        self.sync = sync
+        self._shape = None
+        for n in [net_G] + self.Ds:
+            n.train()
+
+    def _bind_optimizers(self, *opts):
+        if self.sync is not None:
+            for o in opts:
+                o.grad_scale = self.sync.grad_scale()   # SUM all-reduce -> mean gradient
+
+    def _buffers(self, ground):
+        if self._shape != tuple(ground.shape):
+            self._shape = tuple(ground.shape)
+            mk = lambda: torch.empty_like(ground)  # noqa: E731
+            self.mask_c, self.masked, self.inpainted = mk(), mk(), mk()
+            self.g_adv, self.g_rec, self.g_gen, self.tmp1, self.tmp2 = mk(), mk(), mk(), mk(), mk()
+            n = ground.shape[0]
+            self.dpred = torch.empty((n, 1), dtype=torch.float32, device=ground.device)
+            self.L = {}
+
+    def _loss(self, name):
+        if name not in self.L:
+            self.L[name] = torch.zeros(1, dtype=torch.float32, device=self.ops.dev)
+        return self.L[name]
+
+    def _reduce(self, net):
+        if self.sync is not None:
+            self.sync.all_reduce(net)
+
+    def _bwd_G(self, gtok, dy):
+        """Generator backward; with a GradSync the decoder half's gradients start their all-reduce
+        while the encoder half is still being computed."""
+        if self.sync is None or self.sync.world == 1:
+            return self._bwd(self.G, gtok, dy, False, True)
+        G, lib = self.G, B.lib()
+        if G._slot_gen[gtok[0]] != gtok[1]:
+            raise B.BackendError("generator activations were overwritten before their backward")
+        flat = G.flat_grads()
+        split = lib.gi_net_phase_split(G._handle)
+        B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 1))
+        self.sync.launch(flat, split, flat.numel())
+        B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 2))
+        self.sync.launch(flat, 0, split)
+        self.sync.wait(flat.device)
+
+    @staticmethod
+    def _fwd(net, x):
+        y, slot, gen = net._forward_raw(x)
+        return y, (slot, gen)
+
+    @staticmethod
+    def _bwd(net, tok, dy, need_dx, need_wgrad):
+        return net._backward_raw(tok[0], tok[1], dy, need_dx, need_wgrad)
+
+
+class MinimaxStep(_StepBase):
+    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", sync=None):
+        super().__init__(net_G, [net_D], net_G.device, sync)
+        self.D, self.optG, self.optD, self.recon = net_D, opt_G, opt_D, recon
+        self._bind_optimizers(opt_G, opt_D)
+
+    @torch.no_grad()
+    def __call__(self, ground, mask):
+        o = self.ops
+        self._buffers(ground)
+        o.mask_apply(ground, mask, self.mask_c, self.masked, True)             # :114-117
+        gen, gtok = self._fwd(self.G, self.masked)                              # :119
+        o.composite(self.masked, gen, self.mask_c, self.inpainted)             # :122
+        # ---- D step :129-148
+        self.optD.zero_grad()
+        p, t = self._fwd(self.D, ground)
+        o.adv(p, BCE, 1.0, self._loss("d_loss_real"), self.dpred)
+        self._bwd(self.D, t, self.dpred, False, True)
+        p, t = self._fwd(self.D, self.inpainted)
+        o.adv(p, BCE, 0.0, self._loss("d_loss_fake"), self.dpred)
+        self._bwd(self.D, t, self.dpred, False, True)
+        self._reduce(self.D)
+        self.optD.step()
+        # ---- G step :154-173 (D frozen: input gradient only)
+        self.optG.zero_grad()
+        p, t = self._fwd(self.D, self.inpainted)
+        o.adv(p, BCE, 1.0, self._loss("g_adv"), self.dpred)
+        d_adv = self._bwd(self.D, t, self.dpred, True, False)
+        o.recon(self.recon, self.inpainted, ground, self._loss("recon"), self.g_rec)
+        o.add(d_adv, self.g_rec, self.tmp1)
+        o.mul(self.tmp1, self.mask_c, self.g_gen)                              # d(inpainted)/d(gen) = mask
+        self._bwd_G(gtok, self.g_gen)
+        self.optG.step()
+        return self.L
+
+
+class WGANStep(_StepBase):
+    """clip > 0 applies the reference's weight clipping after the critic update. If opt_D is this
+    package's RMSprop its `clamp` is set so the clip is fused into the optimizer kernel."""
+
+    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None):
+        super().__init__(net_G, [net_D], net_G.device, sync)
+        self.D, self.optG, self.optD, self.recon, self.clip = net_D, opt_G, opt_D, recon, clip
+        self._fused_clip = isinstance(opt_D, optim.RMSprop)
+        if self._fused_clip:
+            opt_D.clamp = clip
+        self._bind_optimizers(opt_G, opt_D)
+
+    @torch.no_grad()
+    def __call__(self, ground, mask, update_g):
+        o = self.ops
+        self._buffers(ground)
+        o.mask_apply(ground, mask, self.mask_c, self.masked, True)
+        gen, gtok = self._fwd(self.G, self.masked)                              # every batch, :119
+        o.composite(self.masked, gen, self.mask_c, self.inpainted)
+        self.optD.zero_grad()
+        pr, tr = self._fwd(self.D, ground)                                      # :134
+        pf, tf = self._fwd(self.D, self.inpainted)                              # :135
+        o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)       # backward(one)  :137-138
+        self._bwd(self.D, tr, self.dpred, False, True)
+        o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)       # backward(mone) :140-141
+        self._bwd(self.D, tf, self.dpred, False, True)
+        self._reduce(self.D)
+        self.optD.step()                                                        # :147
+        if self.clip > 0 and not self._fused_clip:
+            util.clamp_parameters(self.D, -self.clip, self.clip)                # :151-153
+        if update_g:                                                            # cadence :157-163 is the caller's
+            self.optG.zero_grad()
+            p, t = self._fwd(self.D, self.inpainted)
+            o.adv(p, MEAN, 0.0, self._loss("g_adv"), self.dpred, +1.0)
+            d_adv = self._bwd(self.D, t, self.dpred, True, False)
+            o.recon(self.recon, self.inpainted, ground, self._loss("recon"), self.g_rec)
+            o.add(d_adv, self.g_rec, self.tmp1)
+            o.mul(self.tmp1, self.mask_c, self.g_gen)
+            self._bwd_G(gtok, self.g_gen)
+            self.optG.step()
+        return self.L
+
+
+def wgan_update_g(batch_index, g_iter_count, update_g_every=5):
+    """G-update cadence of wgan_l1.py:157-163."""
+    period = 140 if (g_iter_count < 25 or g_iter_count % 500 == 0) else update_g_every
+    return batch_index % period == 0 and batch_index > 0
+
+
+class DualDStep(_StepBase):
+    """G step first, LSGAN losses, global + local (mask * x) discriminators, mask not ceil-ed,
+    output not composited, one optimizer over both discriminators (:123)."""
+
+    def __init__(self, net_G, net_Dg, net_Dl, opt_G, opt_D, lam1=300.0, lam2=300.0, sync=None):
+        super().__init__(net_G, [net_Dg, net_Dl], net_G.device, sync)
+        self.Dg, self.Dl, self.optG, self.optD, self.lam1, self.lam2 = net_Dg, net_Dl, opt_G, opt_D, lam1, lam2
+        self._bind_optimizers(opt_G, opt_D)
+
+    @torch.no_grad()
+    def __call__(self, ground, mask):
+        o = self.ops
+        self._buffers(ground)
+        o.mask_apply(ground, mask, None, self.masked, False)                    # :144
+        self.optG.zero_grad()
+        gen, gtok = self._fwd(self.G, self.masked)                              # :154
+        # D_global(inpainted), D_local(mask*inpainted) with frozen Ds :156-157
+        p, t = self._fwd(self.Dg, gen)
+        o.adv(p, LSGAN, 1.0, self._loss("g_adv_global"), self.dpred)
+        d1 = self._bwd(self.Dg, t, self.dpred, True, False)
+        o.mul(mask, gen, self.inpainted)                                        # inpainted buffer = mask*gen
+        p, t = self._fwd(self.Dl, self.inpainted)
+        o.adv(p, LSGAN, 1.0, self._loss("g_adv_local"), self.dpred)
+        d2 = self._bwd(self.Dl, t, self.dpred, True, False)
+        o.mul(d2, mask, self.tmp1)
+        o.add(d1, self.tmp1, self.g_adv)
+        o.recon("rmse", gen, ground, self._loss("rmse_global"), self.g_rec, self.lam1)        # :166
+        o.add(self.g_adv, self.g_rec, self.g_adv)
+        o.mul(mask, ground, self.tmp2)
+        o.recon("rmse", self.inpainted, self.tmp2, self._loss("rmse_local"), self.g_rec, self.lam2)  # :167
+        o.mul(self.g_rec, mask, self.tmp1)
+        o.add(self.g_adv, self.tmp1, self.g_gen)
+        self._bwd_G(gtok, self.g_gen)
+        self.optG.step()                                                        # :172
+        # ---- D step :178-200
+        self.optD.zero_grad()
+        for net, real, fake, tag in ((self.Dg, ground, gen, "global"), (self.Dl, self.tmp2, self.inpainted, "local")):
+            p, t = self._fwd(net, real)
+            o.adv(p, LSGAN, 1.0, self._loss(f"d_real_{tag}"), self.dpred)
+            self._bwd(net, t, self.dpred, False, True)
+            p, t = self._fwd(net, fake)
+            o.adv(p, LSGAN, 0.0, self._loss(f"d_fake_{tag}"), self.dpred)
+            self._bwd(net, t, self.dpred, False, True)
+        self._reduce(self.Dg)
+        self._reduce(self.Dl)
+        self.optD.step()
+        return self.L

@@ -94,6 +94,13 @@ int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n);
  * gradients are produced. Parameter gradients ACCUMULATE into the bound grads. */
 int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad);
 
+/* generator backward in two halves so the host can overlap a gradient all-reduce with compute:
+ * phase 1 = decoder (its parameter gradients are the flat range [gi_net_phase_split(), end) and are
+ * complete on return), phase 2 = encoder (range [0, split)); phase 0 = both. Discriminators run
+ * entirely in phase 1 (split = 0). */
+int gi_net_backward_phase(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad, int phase);
+int64_t gi_net_phase_split(gi_net* net);
+
 /* ---- mask pipeline: experiment_list/minimaxgan_l1.py:113-122 ------------------------------ */
 /* mask_c = do_ceil ? ceil(mask) : mask ; masked = ground * (1 - mask_c) */
 int gi_mask_apply(gi_ctx* ctx, const float* ground, const float* mask, float* mask_c, float* masked,
@@ -103,6 +110,8 @@ int gi_mask_composite(gi_ctx* ctx, const float* masked, const float* gen, const 
                       float* inpainted, int64_t count);
 /* out = a * b (the composite backward d_gen = d_inpainted * mask_c, and mask*x products) */
 int gi_mul(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count);
+/* out = a + alpha * b (sums the adversarial and reconstruction gradients of g_loss, minimaxgan_l1.py:168) */
+int gi_add(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count, float alpha);
 
 /* ---- losses. Each writes the scalar loss to loss_out[0] (device) and, when grad_a != NULL, the
  *      gradient w.r.t. `a` multiplied by gscale. nn.L1Loss (minimaxgan_l1.py:62,166);

@@ -1,0 +1,156 @@
+"""GPU tier: single-layer C-ABI entry points against torch-CPU fp32 references of the same op
+(F.conv2d / F.conv_transpose2d / conv2d_weight), both compute types, split-K and direct paths."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import B, from_nhwc, nhwc_dev, pack, quant, report, tdt  # noqa: E402
+
+TOL = {B.GI_F32: 2e-5, B.GI_F16: 2e-3}   # relative to max|ref|; fp16: fp16 output rounding, fp32 accumulate
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CONV_CASES = [
+    # n, H, W, cb(in), ca(out), use_ws
+    (2, 16, 16, 64, 128, True),
+    (2, 16, 16, 64, 128, False),
+    (1, 64, 64, 64, 128, False),
+    (2, 32, 32, 128, 64, False),     # 256x64 tile config
+    (3, 8, 8, 256, 512, True),
+    (2, 4, 4, 512, 512, True),       # 2x2 output, heavy padding
+    (5, 2, 2, 512, 512, True),       # 1x1 output (bottleneck)
+]
+
+
+@pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_s2_forward(code, case):
+    n, H, W, cb, ca, use_ws = case
+    x = quant(_rand((n, cb, H, W), 1), code)
+    w = quant(_rand((ca, cb, 4, 4), 2, 0.05), code)
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    packed, _ = pack(w, code)
+    xd = nhwc_dev(x, code)
+    out = torch.full((n, H // 2, W // 2, ca), float("nan"), dtype=tdt(code), device="cuda")
+    ws = torch.zeros(n * (H // 2) * (W // 2) * ca, dtype=torch.float32, device="cuda") if use_ws else None
+    B.check(B.lib().gi_conv_s2_forward(B.get_ctx(), code, B.ptr(xd), B.ptr(packed), B.ptr(out), n, H, W, cb, cb, ca, ca,
+                                       0, 0, B.ptr(ws), ws.numel() * 4 if use_ws else 0))
+    torch.cuda.synchronize()
+    ok, msg = report(f"conv_s2 {case} dt={code}", from_nhwc(out), ref, TOL[code])
+    assert ok, msg
+
+
+@pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
+def test_conv_s2_relu_in_lrelu_out_strided(code):
+    """relu on the input, LeakyReLU on the output, input read from / output written into wider
+    buffers at channel offset 0 (the concat-buffer case)."""
+    n, H, W, cb, ca = 2, 16, 16, 64, 128
+    x = quant(_rand((n, cb, H, W), 3), code)
+    w = quant(_rand((ca, cb, 4, 4), 4, 0.05), code)
+    ref = F.leaky_relu(F.conv2d(F.relu(x), w, None, stride=2, padding=1), 0.2)
+    packed, _ = pack(w, code)
+    wide = torch.zeros((n, H, W, 2 * cb), dtype=tdt(code), device="cuda")
+    wide[..., :cb] = nhwc_dev(x, code)
+    wide[..., cb:] = 7.0   # must not be read
+    out = torch.zeros((n, H // 2, W // 2, 2 * ca), dtype=tdt(code), device="cuda")
+    B.check(B.lib().gi_conv_s2_forward(B.get_ctx(), code, B.ptr(wide), B.ptr(packed), B.ptr(out), n, H, W, cb, 2 * cb, ca,
+                                       2 * ca, 1, B.ACT_LRELU, None, 0))
+    torch.cuda.synchronize()
+    ok, msg = report(f"conv_s2 relu/lrelu dt={code}", from_nhwc(out[..., :ca].contiguous()), ref, TOL[code])
+    assert ok, msg
+    assert float(out[..., ca:].abs().max()) == 0.0
+
+
+CONVT_CASES = [
+    # n, H, W, ca(in), cb(out), use_ws
+    (2, 8, 8, 128, 64, False),      # 256x64 tile config
+    (2, 8, 8, 256, 128, True),
+    (1, 32, 32, 256, 128, False),
+    (3, 1, 1, 512, 512, True),      # bottleneck 1x1 -> 2x2
+    (2, 2, 2, 1024, 512, True),
+]
+
+
+@pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_convT_s2_forward(code, case):
+    n, H, W, ca, cb, use_ws = case
+    x = quant(_rand((n, ca, H, W), 5), code)
+    w = quant(_rand((ca, cb, 4, 4), 6, 0.05), code)   # ConvTranspose2d weight [in, out, 4, 4]
+    ref = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    _, phase = pack(w, code)
+    xd = nhwc_dev(x, code)
+    out = torch.full((n, 2 * H, 2 * W, cb), float("nan"), dtype=tdt(code), device="cuda")
+    ws = torch.zeros(n * 4 * H * W * cb, dtype=torch.float32, device="cuda") if use_ws else None
+    B.check(B.lib().gi_convT_s2_forward(B.get_ctx(), code, B.ptr(xd), B.ptr(phase), B.ptr(out), n, H, W, ca, ca, cb, cb,
+                                        0, 0, B.ptr(ws), ws.numel() * 4 if use_ws else 0))
+    torch.cuda.synchronize()
+    ok, msg = report(f"convT_s2 {case} dt={code}", from_nhwc(out), ref, TOL[code])
+    assert ok, msg
+
+
+WGRAD_CASES = [
+    # n, Hs, Ws, ca, cb, relu_S
+    (2, 8, 8, 128, 64, 0),
+    (2, 8, 8, 128, 64, 1),
+    (1, 16, 16, 256, 128, 0),
+    (3, 2, 2, 512, 256, 0),
+    (2, 1, 1, 512, 512, 1),
+    (4, 32, 32, 128, 64, 0),     # many K tiles -> split over pixel ranges
+]
+
+
+@pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_wgrad_s2(code, case):
+    n, Hs, Ws, ca, cb, relu_S = case
+    S = quant(_rand((n, ca, Hs, Ws), 7), code)
+    L = quant(_rand((n, cb, 2 * Hs, 2 * Ws), 8), code)
+    ref = torch.nn.grad.conv2d_weight(L, (ca, cb, 4, 4), F.relu(S) if relu_S else S, stride=2, padding=1)
+    Sd, Ld = nhwc_dev(S, code), nhwc_dev(L, code)
+    dW = torch.zeros((ca, 4, 4, cb), dtype=torch.float32, device="cuda")
+    B.check(B.lib().gi_wgrad_s2(B.get_ctx(), code, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), n, Hs, Ws, ca, ca, cb, cb, relu_S, 0.5))
+    # accumulate semantic: a second call adds again
+    B.check(B.lib().gi_wgrad_s2(B.get_ctx(), code, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), n, Hs, Ws, ca, ca, cb, cb, relu_S, 0.5))
+    torch.cuda.synchronize()
+    got = dW.cpu().permute(0, 3, 1, 2)
+    ok, msg = report(f"wgrad {case} dt={code}", got, ref, 5e-5 if code == B.GI_F32 else 2e-3)
+    assert ok, msg
+
+
+def test_mfma_layout_exact_integers():
+    """Asymmetric small-integer data: every product and sum is exact in fp16/fp32, so any fragment
+    or C-layout mix-up shows as a non-zero error (cdna guide: 'A=I-check with asymmetric B')."""
+    n, H, W, cb, ca = 1, 8, 8, 64, 128
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(-2, 3, (n, cb, H, W), generator=g).float()
+    w = torch.randint(-2, 3, (ca, cb, 4, 4), generator=g).float()
+    for code in (B.GI_F32, B.GI_F16):
+        ref = F.conv2d(x, w, None, stride=2, padding=1)
+        packed, phase = pack(w, code)
+        out = torch.zeros((n, H // 2, W // 2, ca), dtype=tdt(code), device="cuda")
+        xd = nhwc_dev(x, code)
+        B.check(B.lib().gi_conv_s2_forward(B.get_ctx(), code, B.ptr(xd), B.ptr(packed), B.ptr(out), n, H, W, cb, cb, ca, ca, 0, 0,
+                                           None, 0))
+        assert torch.equal(from_nhwc(out), ref), f"conv exact-int mismatch dt={code}"
+        xs = torch.randint(-2, 3, (n, ca, 4, 4), generator=g).float()
+        refT = F.conv_transpose2d(xs, w, None, stride=2, padding=1)
+        outT = torch.zeros((n, 8, 8, cb), dtype=tdt(code), device="cuda")
+        xsd = nhwc_dev(xs, code)
+        B.check(B.lib().gi_convT_s2_forward(B.get_ctx(), code, B.ptr(xsd), B.ptr(phase), B.ptr(outT), n, 4, 4, ca, ca, cb, cb, 0, 0,
+                                            None, 0))
+        assert torch.equal(from_nhwc(outT), refT), f"convT exact-int mismatch dt={code}"
+        S = torch.randint(-2, 3, (2, ca, 4, 4), generator=g).float()
+        L = torch.randint(-2, 3, (2, cb, 8, 8), generator=g).float()
+        refW = torch.nn.grad.conv2d_weight(L, (ca, cb, 4, 4), S, stride=2, padding=1)
+        dW = torch.zeros((ca, 4, 4, cb), dtype=torch.float32, device="cuda")
+        Sd, Ld = nhwc_dev(S, code), nhwc_dev(L, code)   # keep alive until the kernel has run
+        B.check(B.lib().gi_wgrad_s2(B.get_ctx(), code, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), 2, 4, 4, ca, ca, cb, cb, 0, 1.0))
+        assert torch.equal(dW.cpu().permute(0, 3, 1, 2), refW), f"wgrad exact-int mismatch dt={code}"

@@ -1,0 +1,204 @@
+"""GPU tier: whole-network parity of the HIP path (through the Python mirror of lib.models, i.e.
+through the C-ABI) against the CPU oracle on identical weights / inputs / dropout masks, and against
+the golden fixtures recorded from the reference itself."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gan_inpainting_amd  # noqa: F401,E402
+from gan_inpainting_amd.lib.models import networks  # noqa: E402
+from oracle import params as op  # noqa: E402
+from oracle import torch_ref as orc  # noqa: E402
+from gpu_util import close_to_either, rel_l2, report  # noqa: E402
+from util_golden import load, unpack_masks  # noqa: E402
+
+# north_star: <= 1e-3 relative in fp32. fp16 storage/MFMA inputs (11-bit mantissa) through 14-28
+# layers: tolerances below are relative to max|ref| of each tensor.
+TOL_OUT = {"fp32": 1e-4, "fp16": 2e-2}
+TOL_GRAD = {"fp32": 1e-3, "fp16": 6e-2}      # max-norm (fp32) ...
+TOL_GRAD_L2 = {"fp32": None, "fp16": 3e-2}   # ... / relative L2 vs the fp64 evaluation (fp16)
+
+
+def sd(P):
+    return {k: torch.from_numpy(np.array(v)) for k, v in P.items()}
+
+
+def make_unet(P, nd, dtype):
+    net = networks.UnetGenerator(1, 1, nd, ngf=64, use_dropout="False", dtype=dtype)
+    net.load_state_dict(sd(P))
+    net.set_loss_scale(1.0)   # these tests back-propagate O(1) synthetic gradients, not a mean-reduced loss
+    return net.to("cuda").train()
+
+
+def make_d(P, HW, sigmoid, dtype):
+    net = networks.PatchGANDiscriminator(sigmoid=sigmoid, image_size=HW, dtype=dtype)
+    net.load_state_dict(sd(P))
+    net.set_loss_scale(1.0)
+    return net.to("cuda").train()
+
+
+def compare_grads(net, OP, OP64, dtype, what):
+    bad = []
+    for name, p in net.named_parameters():
+        ok, msg = close_to_either(f"{what} grad {name}", p.grad.detach().cpu(), OP[name].grad, OP64[name].grad,
+                                  TOL_GRAD[dtype], TOL_GRAD_L2[dtype])
+        if not ok:
+            bad.append(msg)
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", [(6, 2, 64), (7, 2, 128), (7, 1, 256)])
+def test_unet_forward_backward_vs_oracle(dtype, cfg):
+    nd, N, HW = cfg
+    seed = 100 + nd + HW
+    P = op.make_unet_params(seed, num_downs=nd)
+    net = make_unet(P, nd, dtype)
+    ground, mask = op.synth_batch(seed + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask))
+    R = torch.from_numpy(np.random.Generator(np.random.PCG64(seed)).standard_normal(size=(N, 1, HW, HW), dtype=np.float32))
+    xd = x.cuda().requires_grad_(True)
+    y = net(xd)
+    (y * R.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    masks = {k: v.cpu() for k, v in net.dropout_masks().items()}
+    for lvl, m in masks.items():
+        keep = float(m.float().mean())
+        assert 0.35 < keep < 0.65, f"dropout level {lvl}: keep fraction {keep}"
+    OP, OP64 = orc.to_torch(P), orc.to_torch(P, dtype=torch.float64)
+    xo = x.clone().requires_grad_(True)
+    yo = orc.unet_forward(OP, xo, nd, True, masks)
+    (yo * R).sum().backward()
+    xo64 = x.double().requires_grad_(True)
+    yo64 = orc.unet_forward(OP64, xo64, nd, True, masks)
+    (yo64 * R.double()).sum().backward()
+    ok, msg = report(f"unet{cfg} {dtype} out", y.detach().cpu(), yo.detach(), TOL_OUT[dtype])
+    assert ok, msg
+    compare_grads(net, OP, OP64, dtype, f"unet{cfg} {dtype}")
+    ok, msg = close_to_either(f"unet{cfg} {dtype} dx", xd.grad.cpu(), xo.grad, xo64.grad, TOL_GRAD[dtype], TOL_GRAD_L2[dtype])
+    assert ok, msg
+    # BatchNorm running statistics (momentum 0.1, unbiased variance)
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            ok, msg = report(f"unet{cfg} {dtype} {k}", v.cpu(), OP[k], 1e-4 if dtype == "fp32" else 2e-2)
+            assert ok, msg
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 1
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_unet_eval_forward(dtype):
+    nd, N, HW = 7, 2, 128
+    P = op.make_unet_params(12, num_downs=nd)
+    net = make_unet(P, nd, dtype).eval()
+    fx = load("unet128_eval")
+    ground, mask = op.synth_batch(12 + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask))
+    with torch.no_grad():
+        y = net(x.cuda())
+    ok, msg = report(f"unet eval {dtype} vs golden(reference)", y.cpu(), torch.from_numpy(fx["out"]), TOL_OUT[dtype])
+    assert ok, msg
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_unet_train_vs_golden_with_imposed_masks(dtype):
+    """Directly against the numbers recorded from the reference (tests/golden/unet128_train.npz):
+    the reference's own dropout masks are imposed on the HIP path."""
+    fx = load("unet128_train")
+    seed, N, HW, nd = int(fx["seed"]), int(fx["N"]), int(fx["HW"]), int(fx["num_downs"])
+    net = make_unet(op.make_unet_params(seed, num_downs=nd), nd, dtype)
+    net.impose_dropout_masks(unpack_masks(fx))
+    ground, mask = op.synth_batch(seed + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask)).cuda()
+    R = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 99)).standard_normal(size=(N, 1, HW, HW), dtype=np.float32))
+    y = net(x)
+    (y * R.cuda()).sum().backward()
+    ok, msg = report(f"unet128_train {dtype} out vs reference", y.detach().cpu(), torch.from_numpy(fx["out"]), TOL_OUT[dtype])
+    assert ok, msg
+    names = [str(s) for s in fx["grad_names"]]
+    prm = dict(net.named_parameters())
+    assert names == list(prm.keys()), "named_parameters() order differs from the reference"
+    bad = []
+    for i, n in enumerate(names):
+        got = float(prm[n].grad.abs().mean())
+        ref = float(fx["grad_absmean"][i])
+        if abs(got - ref) > TOL_GRAD[dtype] * abs(ref) + 1e-9:
+            bad.append(f"{n}: absmean {got:.6g} vs {ref:.6g}")
+        head = prm[n].grad.reshape(-1)[:32].cpu()
+        ref_head = torch.from_numpy(fx[f"ghead_{i}"])
+        if float(ref_head.abs().max()) > 1e-6 and rel_l2(head, ref_head) > (5e-3 if dtype == "fp32" else 8e-2):
+            bad.append(f"{n}: first-32 gradient entries relL2 {rel_l2(head, ref_head):.3e}")
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("cfg", [(128, 3, True), (128, 3, False), (64, 2, True), (256, 2, False)])
+def test_patchgan_vs_oracle(dtype, cfg):
+    HW, N, sig = cfg
+    seed = 200 + HW
+    P = op.make_patchgan_params(seed, HW, HW)
+    net = make_d(P, HW, sig, dtype)
+    ground, _ = op.synth_batch(seed + 3, N, HW, HW)
+    r = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 5)).standard_normal(size=(N, 1), dtype=np.float32))
+    xd = torch.from_numpy(ground).cuda().requires_grad_(True)
+    y = net(xd)
+    (y * r.cuda()).sum().backward()
+    OP, OP64 = orc.to_torch(P), orc.to_torch(P, dtype=torch.float64)
+    xo = torch.from_numpy(ground).clone().requires_grad_(True)
+    yo = orc.patchgan_forward(OP, xo, sig, True)
+    (yo * r).sum().backward()
+    xo64 = torch.from_numpy(ground).double().requires_grad_(True)
+    yo64 = orc.patchgan_forward(OP64, xo64, sig, True)
+    (yo64 * r.double()).sum().backward()
+    ok, msg = report(f"patchgan{cfg} {dtype} out", y.detach().cpu(), yo.detach(), TOL_OUT[dtype])
+    assert ok, msg
+    compare_grads(net, OP, OP64, dtype, f"patchgan{cfg} {dtype}")
+    ok, msg = close_to_either(f"patchgan{cfg} {dtype} dx", xd.grad.cpu(), xo.grad, xo64.grad, TOL_GRAD[dtype], TOL_GRAD_L2[dtype])
+    assert ok, msg
+    if HW == 128:
+        fx = load("patchgan128")   # recorded from the reference with seed 21; only check shape contract here
+        assert fx["out_sig"].shape[1] == 1
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_patchgan_vs_golden(dtype):
+    fx = load("patchgan128")
+    seed, N = int(fx["seed"]), int(fx["N"])
+    ground, _ = op.synth_batch(seed + 3, N, 128, 128)
+    r = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 5)).standard_normal(size=(N, 1), dtype=np.float32))
+    for sig, tag in ((True, "sig"), (False, "lin")):
+        net = make_d(op.make_patchgan_params(seed, 128, 128), 128, sig, dtype)
+        xd = torch.from_numpy(ground).cuda().requires_grad_(True)
+        y = net(xd)
+        (y * r.cuda()).sum().backward()
+        ok, msg = report(f"patchgan128 {tag} {dtype} out vs reference", y.detach().cpu(), torch.from_numpy(fx[f"out_{tag}"]), TOL_OUT[dtype])
+        assert ok, msg
+        l2 = rel_l2(xd.grad.reshape(-1)[:256].cpu(), torch.from_numpy(fx[f"dx_head_{tag}"]))
+        assert l2 <= (2e-2 if dtype == "fp32" else 8e-2), f"patchgan128 {tag} {dtype} dx head relL2 {l2:.3e}"
+        names = [str(s) for s in fx["grad_names"]]
+        prm = dict(net.named_parameters())
+        assert names == list(prm.keys())
+        for i, n in enumerate(names):
+            got, ref = float(prm[n].grad.abs().mean()), float(fx[f"grad_absmean_{tag}"][i])
+            assert abs(got - ref) <= (2e-3 if dtype == "fp32" else 3e-2) * abs(ref) + 1e-9, f"{tag} {n}: {got} vs {ref}"
+        net.eval()
+        with torch.no_grad():
+            ye = net(torch.from_numpy(ground).cuda())
+        ok, msg = report(f"patchgan128 {tag} {dtype} eval", ye.cpu(), torch.from_numpy(fx[f"out_eval_{tag}"]), TOL_OUT[dtype] * 2)
+        assert ok, msg
+
+
+def test_frozen_discriminator_gives_dx_only():
+    """util.set_requires_grad([D], False) (lib/models/util.py:19-22): input gradient flows, no
+    parameter gradient is touched."""
+    from gan_inpainting_amd.lib.models import util
+    P = op.make_patchgan_params(5, 128, 128)
+    net = make_d(P, 128, True, "fp32")
+    util.set_requires_grad([net], False)
+    net.zero_grad()
+    x = torch.rand(2, 1, 128, 128, device="cuda", requires_grad=True)
+    net(x).sum().backward()
+    assert float(net.flat_grads().abs().max()) == 0.0
+    assert float(x.grad.abs().max()) > 0.0

@@ -1,0 +1,56 @@
+"""CPU tier: the N>1 gradient exchange (gan_inpainting_amd/parallel.py) with world_size 2 on gloo.
+Each rank fills a flat 'gradient' with rank-dependent values; after GradSync the buffers hold the
+SUM and the optimizer scale 1/world turns it into the mean of the per-rank gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import parallel
+    r, w = parallel.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    sync = parallel.GradSync(bucket_floats=1000, use_side_stream=False)
+    n = 4567
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    split = 3000
+    sync.launch(flat, split, n)      # "decoder half" first, as the generator backward does
+    sync.launch(flat, 0, split)
+    sync.wait()
+    expect = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
+    ok = bool(torch.equal(flat, expect)) and abs(sync.grad_scale() - 1.0 / world) < 1e-12
+    assert len(sync.buckets(0, n)) == 5
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
