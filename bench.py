@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the WGAN inpainting loop at 256x256, bs=32 per GPU
+(BASELINE.json configs[3], `wgan_rmse`: U-Net generator + PatchGAN critic, RMSprop, weight clipping,
+RMSE reconstruction, G updated every 5th batch as in wgan_l1.py:157-163 steady state), fp16 MFMA
+compute with fp32 master weights, synthetic masked-image batches resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0. Extra objects:
+  roofline      dominant kernel (the fp16 MFMA implicit-GEMM transposed conv on the u3 shape), timed live
+                with HIP events on the kernel's stream: algorithmic FLOP / average launch time vs 2.5 PFLOP/s
+  cpu_baseline  the CPU oracle (port of the reference's torch path) on this host's cores, bounded sample
+  --kernel-only runs just the dominant-kernel launches (what profiles/*kernel* summarises with rocprofv3).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H = W = 256
+BS = 32
+G_EVERY = 5            # wgan_l1.py:157-163 steady-state period (update_g_every)
+PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA (guides/MI355X_MICROARCH.md)
+# algorithmic work, SURVEY.md 8d: G forward 11.845 GFLOP/img, D forward 3.258 GFLOP/img at 256x256
+F_G, F_D = 11.845e9, 3.258e9
+
+
+def synth(n, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    ground = torch.rand((n, 1, H, W), generator=g)
+    mask = torch.zeros((n, 1, H, W))
+    for i in range(n):
+        h = int(torch.randint(H // 8, H // 2 + 1, (1,), generator=g))
+        w = int(torch.randint(W // 8, W // 2 + 1, (1,), generator=g))
+        y0 = int(torch.randint(0, H - h + 1, (1,), generator=g))
+        x0 = int(torch.randint(0, W - w + 1, (1,), generator=g))
+        mask[i, 0, y0:y0 + h, x0:x0 + w] = 1.0
+    return ground.to(device), mask.to(device)
+
+
+def dominant_kernel(iters):
+    """u3 of the generator at 256x256 / bs=32: ConvTranspose2d(512 -> 128) on 32x32 maps, i.e. four
+    sub-pixel GEMMs of M=32768, N=128, K=2048 (SURVEY.md 8a2 'u3')."""
+    from gan_inpainting_amd import backend as B
+    import ctypes as C
+    n, hs, ws, ca, cb = BS, 32, 32, 512, 128
+    x = (torch.rand((n, hs, ws, ca), device="cuda") - 0.3).half()
+    w = ((torch.rand((ca, 4, 4, cb), device="cuda") * 2 - 1) * 0.02)
+    phase = torch.empty(ca * 16 * cb, dtype=torch.float16, device="cuda")
+    B.check(B.lib().gi_pack_weights(B.get_ctx(), B.GI_F16, B.ptr(w), ca, cb, None, B.ptr(phase)))
+    out = torch.empty((n, 2 * hs, 2 * ws, cb), dtype=torch.float16, device="cuda")
+    ms = C.c_float()
+    B.check(B.lib().gi_time_convT_s2(B.get_ctx(), B.GI_F16, B.ptr(x), B.ptr(phase), B.ptr(out), n, hs, ws, ca, ca, cb, cb, iters,
+                                     C.byref(ms)))
+    flop = 2.0 * 4 * (n * hs * ws) * cb * (4 * ca)
+    return dict(name="igemm_kernel<f16,PHASE,128x128> (ConvTranspose2d 512->128, 32x32->64x64, bs=32)", ms=ms.value, flop=flop)
+
+
+def cpu_baseline():
+    """The oracle's WGAN schedule on the host cores: bs=8 at 256x256, one critic-only batch and one
+    batch with a generator update, combined 4:1 like the GPU cadence."""
+    import numpy as np
+    from oracle import params as op
+    from oracle import torch_ref as orc
+    n = 8
+    threads = torch.get_num_threads()
+    PG = orc.to_torch(op.make_unet_params(1234))
+    PD = orc.to_torch(op.make_patchgan_params(4321, H, W))
+    oG, oD = orc.RMSprop(orc.trainable(PG)), orc.RMSprop(orc.trainable(PD))
+    ground, mask = op.synth_batch(0x5EED, n, H, W)
+    ground, mask = torch.from_numpy(ground), torch.from_numpy(mask)
+    rng = np.random.Generator(np.random.PCG64(1))
+    masks = {5: torch.from_numpy((rng.random((n, 512, 16, 16)) < 0.5).astype(np.uint8)),
+             6: torch.from_numpy((rng.random((n, 512, 8, 8)) < 0.5).astype(np.uint8))}
+    orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, True, recon="rmse")   # warm-up
+    t = []
+    for upd in (False, True):
+        t0 = time.perf_counter()
+        orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, upd, recon="rmse")
+        t.append(time.perf_counter() - t0)
+    per_batch = ((G_EVERY - 1) * t[0] + t[1]) / G_EVERY
+    return dict(value=n / per_batch, unit="images/sec", cores=threads, kind="port",
+                sample=f"oracle/torch_ref.wgan_step fp32, bs={n} at {H}x{W}: 1 warm-up + 1 critic-only batch ({t[0]:.2f} s) "
+                       f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-only", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=50)
+    args = ap.parse_args()
+
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import optim, parallel, trainer
+    from gan_inpainting_amd.lib.models import networks
+
+    rank, world = parallel.init_from_env()
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    if args.kernel_only:
+        k = dominant_kernel(args.kernel_iters)
+        print(json.dumps(dict(kernel=k["name"], avg_ms=k["ms"], tflops=k["flop"] / k["ms"] / 1e9)))
+        return
+
+    torch.manual_seed(1234)
+    G = networks.get_network("generator", "unet", dtype=args.dtype).to(dev)
+    torch.manual_seed(4321)
+    D = networks.PatchGANDiscriminator(sigmoid=False, image_size=H, dtype=args.dtype).to(dev)
+    oG = optim.RMSprop(G.parameters(), lr=0.00005)
+    oD = optim.RMSprop(D.parameters(), lr=0.00005)
+    sync = parallel.GradSync() if world > 1 else None
+    if world > 1:   # identical replicas
+        torch.distributed.broadcast(G.flat_params(), 0)
+        torch.distributed.broadcast(D.flat_params(), 0)
+        G.mark_dirty(), D.mark_dirty()
+    step = trainer.WGANStep(G, D, oG, oD, recon="rmse", clip=0.01, sync=sync)
+    batches = [synth(BS, 0x5EED0000 + rank * 1000 + i, dev) for i in range(4)]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        g, m = batches[it % len(batches)]
+        step(g, m, it % G_EVERY == G_EVERY - 1)
+        it += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        g, m = batches[it % len(batches)]
+        step(g, m, it % G_EVERY == G_EVERY - 1)
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    losses = {k: float(v.item()) for k, v in step.L.items()}
+
+    if rank != 0:
+        return
+    # generator forward latency (train-mode forward as inside the loop), HIP events on the compute stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g, m = batches[0]
+    masked = g * (1 - m)
+    for _ in range(3):
+        G._forward_raw(masked)
+    e0.record()
+    reps = 20
+    for _ in range(reps):
+        G._forward_raw(masked)
+    e1.record()
+    torch.cuda.synchronize()
+    gen_fwd_ms = e0.elapsed_time(e1) / reps
+
+    k = dominant_kernel(args.kernel_iters)
+    achieved = k["flop"] / (k["ms"] * 1e-3) / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    # algorithmic FLOP of one batch: D-only = F_G + 6 F_D ; with G update + 2 F_G + 2 F_D
+    flop_batch = BS * ((F_G + 6 * F_D) + (2 * F_G + 2 * F_D) / G_EVERY)
+    out = {
+        "metric": "training images/sec at 256x256 bs=32/GPU",
+        "value": world * BS * args.steps / dt,
+        "unit": "images/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f16" if args.dtype == "fp16" else "f32",
+        "data": "synthetic",
+        "config": {"workload": "wgan_rmse 256x256 bs=32/GPU (BASELINE.json configs[3]): U-Net G (41.8M) + PatchGAN critic, "
+                               "RMSprop 5e-5, clip 0.01, RMSE recon, G update every 5th batch, random-init weights",
+                   "global_batch": world * BS, "parallelism": f"dp{world}",
+                   "compute": "fp16 MFMA, fp32 accumulate, fp32 master weights" if args.dtype == "fp16" else "fp32 MFMA"},
+        "generator_fwd_ms": gen_fwd_ms,
+        "generator_fwd_mfma_frac": BS * F_G / (gen_fwd_ms * 1e-3) / (PEAK_F16_TFLOPS * 1e12),
+        "step_algorithmic_tflops": flop_batch / (dt / args.steps) / 1e12,
+        "losses": losses,
+        "roofline": {"bound": "mfma", "kernel": k["name"], "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F16_TFLOPS, "avg_launch_ms": k["ms"], "flop_per_launch": k["flop"], "traffic": traffic},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

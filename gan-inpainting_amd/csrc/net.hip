@@ -136,7 +136,7 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
   gi_net* net = new gi_net();
   net->ctx = ctx; net->kind = 0; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
   net->nd = num_downs; net->ngf = ngf; net->dropout_p = dropout_p;
-  net->loss_scale = dtype == GI_F16 ? 1024.f : 1.f;
+  net->loss_scale = dtype == GI_F16 ? 65536.f : 1.f;
   const int nd = num_downs;
   net->ch.assign(nd + 1, 0); net->Hk.assign(nd + 1, 0); net->Wk.assign(nd + 1, 0);
   net->conv.assign(nd + 1, Conv()); net->up.assign(nd + 1, Conv());
@@ -248,7 +248,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   gi_net* net = new gi_net();
   net->ctx = ctx; net->kind = 1; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
   net->sigmoid = sigmoid;
-  net->loss_scale = dtype == GI_F16 ? 1024.f : 1.f;
+  net->loss_scale = dtype == GI_F16 ? 65536.f : 1.f;
   net->Hh = H / 16; net->Wh = W / 16;
   net->P = (net->Hh - 3) * (net->Wh - 3);
   const int chans[5] = {1, 64, 128, 256, 512};

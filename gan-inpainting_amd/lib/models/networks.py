@@ -102,7 +102,7 @@ class HipNet(nn.Module):
         self._slot_gen = [0] * self.n_slots
         self._bn_count_buffers = []
         self._anchor = None
-        self._loss_scale = 1024.0 if self._dtype == B.GI_F16 else 1.0
+        self._loss_scale = 65536.0 if self._dtype == B.GI_F16 else 1.0
         self.always_sync = False
 
     # ---- subclass hooks ----------------------------------------------------------------------

@@ -59,6 +59,9 @@ BCE, LSGAN, MEAN = 0, 1, 2
 
 
 class _StepBase:
+    recon_weight = 1.0      # largest multiplier on a mean-reduced reconstruction loss (lambda)
+    auto_loss_scale = True  # fp16 only: pick per-network loss scales from the batch geometry
+
     def __init__(self, net_G, nets_D, device, sync=None):
         self.G, self.Ds = net_G, list(nets_D)
         self.ops = _Ops(device)
@@ -81,6 +84,22 @@ class _StepBase:
             n = ground.shape[0]
             self.dpred = torch.empty((n, 1), dtype=torch.float32, device=ground.device)
             self.L = {}
+            if self.auto_loss_scale:
+                self._pick_loss_scales(ground)
+
+    def _pick_loss_scales(self, ground):
+        """fp16 backward: the gradient entering the generator is ~ lambda / (N*H*W) per pixel (mean-
+        reduced L1/RMSE), the one entering a discriminator ~ 1/N per sample. Scale each network so
+        these land around 2^-5 in fp16 (normal range 6e-5 .. 65504); the library removes the scale
+        when it writes the fp32 parameter gradients / the input gradient."""
+        import math
+        n, _, h, w = ground.shape
+        if self.G._dtype == B.GI_F16:
+            g0 = self.recon_weight / float(n * h * w)
+            self.G.set_loss_scale(min(65536.0, max(1.0, 2.0 ** round(math.log2(0.03 / g0)))))
+        for d in self.Ds:
+            if d._dtype == B.GI_F16:
+                d.set_loss_scale(min(65536.0, 64.0 * n))
 
     def _loss(self, name):
         if name not in self.L:
@@ -209,6 +228,7 @@ class DualDStep(_StepBase):
     def __init__(self, net_G, net_Dg, net_Dl, opt_G, opt_D, lam1=300.0, lam2=300.0, sync=None):
         super().__init__(net_G, [net_Dg, net_Dl], net_G.device, sync)
         self.Dg, self.Dl, self.optG, self.optD, self.lam1, self.lam2 = net_Dg, net_Dl, opt_G, opt_D, lam1, lam2
+        self.recon_weight = max(lam1, lam2)
         self._bind_optimizers(opt_G, opt_D)
 
     @torch.no_grad()
