@@ -17,41 +17,48 @@ __device__ __forceinline__ float act_f(float v, int act) {
 }
 
 // ---- gather: out[p][c] = act(sum_tap img[n,2y-1+ky,2x-1+kx] * w[c][tap]) ---------------------
+// One thread per (pixel, 8-channel group): 16 image taps (L1 broadcast among the pixel's threads),
+// weights staged TRANSPOSED in LDS (swT[tap][c]) so the 8 channels of a tap are two 16-byte reads and
+// the lanes of a wave (consecutive groups) hit consecutive LDS slots; one 16-byte store per thread.
 template <typename T>
 __global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         char* out, int n, int Hs, int Ws, int c, int ldout,
                                                         int coffout, int act, float in_scale) {
   constexpr int G = 8;  // channels per thread
-  extern __shared__ float sw[];  // [c][16]
-  for (int i = threadIdx.x; i < c * 16; i += 256) sw[i] = w[i];
+  extern __shared__ __attribute__((aligned(16))) float swT[];  // [16][c]
+  for (int i = threadIdx.x; i < c * 16; i += 256) swT[(i & 15) * c + (i >> 4)] = w[i];
   __syncthreads();
   const int groups = c / G;
+  const int lg = 31 - __builtin_clz(groups);   // groups is a power of two
   const int64_t total = (int64_t)n * Hs * Ws * groups;
   const int H = 2 * Hs, W = 2 * Ws;
   for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int grp = (int)(gid % groups);
-    const int64_t pix = gid / groups;
+    const int grp = (int)(gid & (groups - 1));
+    const int64_t pix = gid >> lg;
     const int x = (int)(pix % Ws);
     const int64_t t = pix / Ws;
     const int y = (int)(t % Hs);
     const int nn = (int)(t / Hs);
-    float v[16];
-#pragma unroll
-    for (int ky = 0; ky < 4; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 4; ++kx) {
-        const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
-        v[ky * 4 + kx] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[((int64_t)nn * H + iy) * W + ix] * in_scale : 0.f;
-      }
+    const float* ip = img + (int64_t)nn * H * W;
     float o[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) {
-      const float* wr = sw + (grp * G + j) * 16;
-      float s = 0.f;
+    for (int j = 0; j < G; ++j) o[j] = 0.f;
 #pragma unroll
-      for (int tt = 0; tt < 16; ++tt) s = fmaf(v[tt], wr[tt], s);
-      o[j] = act_f(s, act);
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = 2 * y - 1 + ky;
+      const bool yok = iy >= 0 && iy < H;
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int ix = 2 * x - 1 + kx;
+        const float v = (yok && ix >= 0 && ix < W) ? ip[(int64_t)iy * W + ix] * in_scale : 0.f;
+        const float* wr = swT + (ky * 4 + kx) * c + grp * G;
+        const f4_t w0 = *(const f4_t*)wr, w1 = *(const f4_t*)(wr + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = fmaf(v, w0[j], o[j]); o[4 + j] = fmaf(v, w1[j], o[4 + j]); }
+      }
     }
+#pragma unroll
+    for (int j = 0; j < G; ++j) o[j] = act_f(o[j], act);
     T* dst = (T*)(out + (pix * ldout + coffout + grp * G) * (int64_t)sizeof(T));
     if constexpr (std::is_same<T, half_t>::value) {
       h8_t h;
@@ -61,6 +68,83 @@ __global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict_
     } else {
       *(f4_t*)dst = f4_t{o[0], o[1], o[2], o[3]};
       *(f4_t*)(dst + 4) = f4_t{o[4], o[5], o[6], o[7]};
+    }
+  }
+}
+
+// ---- fp16 transposed conv to one channel on the matrix cores -------------------------------------
+// col[p][tap] = sum_c relu?(X[p][c]) * w[c][tap]: D[tap][pixel] = A[tap][c] * B[c][pixel] with
+// v_mfma_f32_16x16x32_f16; B fragments are 16-byte row loads of X straight from global memory (each
+// lane: 8 consecutive channels of its pixel), A fragments (the 16 x c weights) live in registers.
+// Each lane ends with 4 consecutive taps of one pixel -> one 8-byte store; a wave writes 512 B.
+template <int KS>   // KS = c / 32
+__global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float* __restrict__ w, half_t* col,
+                                                     int64_t P, int ldx, int coffx, int relu_in) {
+  const int lane = threadIdx.x & 63;
+  const int tapr = lane & 15, kq = lane >> 4;
+  h8_t af[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[ks][j] = (half_t)w[(ks * 32 + kq * 8 + j) * 16 + tapr];
+  const int64_t ngroups = (P + 15) / 16;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    const int64_t pix = g * 16 + tapr;   // this lane's B column = pixel
+    const bool live = pix < P;
+    h8_t bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
+      if (relu_in) bf[ks] = __builtin_elementwise_max(bf[ks], zero);
+    }
+    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf[ks], acc, 0, 0, 0);
+    if (live) {
+      h4_t o = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+      *(h4_t*)(col + pix * 16 + kq * 4) = o;   // taps 4kq..4kq+3 of this pixel
+    }
+  }
+}
+
+// overlap-add of the 16 taps: out(2j+py, 2i+px) = post(bias + sum_{ty,tx} col[(j+py-ty, i+px-tx)][(1-py+2ty)*4 + 1-px+2tx])
+__global__ void __launch_bounds__(256) c1_col2im_kernel(const half_t* __restrict__ col, const float* __restrict__ bias,
+                                                        float* img, int n, int Hs, int Ws, int post, float out_scale) {
+  const int64_t total = (int64_t)n * Hs * Ws;
+  const int H = 2 * Hs, W = 2 * Ws;
+  const float b = bias ? bias[0] : 0.f;
+  for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
+    const int i = (int)(pix % Ws);
+    const int64_t t = pix / Ws;
+    const int j = (int)(t % Hs);
+    const int nn = (int)(t / Hs);
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int sy = j + dy, sx = i + dx;
+        if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) continue;
+        const half_t* cp = col + (((int64_t)nn * Hs + sy) * Ws + sx) * 16;
+        const h8_t c0 = *(const h8_t*)cp, c1 = *(const h8_t*)(cp + 8);
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int ty = py - dy, tx = px - dx;
+            if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+            const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+            o[py * 2 + px] += tap < 8 ? (float)c0[tap & 7] : (float)c1[tap & 7];
+          }
+      }
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float v0 = o[py * 2] + b, v1 = o[py * 2 + 1] + b;
+      if (post == 1) { v0 = tanhf(v0); v1 = tanhf(v1); }
+      *(float2*)(img + ((int64_t)nn * H + 2 * j + py) * W + 2 * i) = make_float2(v0 * out_scale, v1 * out_scale);
     }
   }
 }
@@ -370,7 +454,20 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
 }
 
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img, int n, int Hs,
-                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale) {
+                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale, void* col_scratch) {
+  if (dtype == GI_F16 && col_scratch && (c == 64 || c == 128) && ldx % 8 == 0 && coffx % 8 == 0) {
+    const int64_t P = (int64_t)n * Hs * Ws;
+    const int grid = grid_for((P + 15) / 16, 4, 256 * 8);
+    if (c == 128)
+      hipLaunchKernelGGL(c1_col_kernel<4>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in);
+    else
+      hipLaunchKernelGGL(c1_col_kernel<2>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in);
+    GI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(c1_col2im_kernel, dim3(grid_for(P, 256, 256 * 8)), dim3(256), 0, st, (const half_t*)col_scratch, bias, img, n, Hs,
+                       Ws, post, out_scale);
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   const int epc = dtype == GI_F16 ? 8 : 4;
   const int lpp = c / epc;
   GI_REQUIRE(c % epc == 0 && gi_is_pow2(lpp) && lpp <= 64, "c1_scatter: c=%d unsupported", c);

@@ -119,8 +119,10 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
                  int Ws, int c, int ldout, int coffout, int act_out, float in_scale);
 // img[n,Y,X] = post( bias + sum_{c,tap} relu?(X[p][c]) * w[c][tap] ) (overlap-add of the 4x4 taps)
 // post: 0 none, 1 tanh. img fp32 (n,2Hs,2Ws); out_scale multiplies the result (loss-scale removal)
+// col_scratch (fp16 path): >= n*Hs*Ws*16 halves; null selects the register-reduction kernel
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img,
-                  int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale);
+                  int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale,
+                  void* col_scratch);
 // dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx]
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws,
                 int c, int ldx, int coffx, int relu_in, float scale, float img_scale);

@@ -79,25 +79,35 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials,
   sinv[ch] = inv;
 }
 
+// grid-stride is a multiple of the chunks-per-pixel (a power of two <= 256), so a thread's channel
+// chunk never changes: scale/shift live in registers, index math is shifts.
 template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, int64_t pixels, int c, int ldy, int coffy,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int act, const uint8_t* drop, float drop_scale) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpp = c / EPC;
+  const int lg = 31 - __builtin_clz(cpp);
   const int64_t total = pixels * cpp;
-  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(gid % cpp);
-    const int64_t pix = gid / cpp;
+  const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cc = (int)(gid0 & (cpp - 1));
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { sc[e] = scale ? scale[cc * EPC + e] : 1.f; sh[e] = scale ? shift[cc * EPC + e] : 0.f; }
+  for (int64_t gid = gid0; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int64_t pix = gid >> lg;
     float v[EPC];
     load_vec<T, EPC>(x, pix * c + cc * EPC, v);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float t = scale ? fmaf(v[e], scale[cc * EPC + e], shift[cc * EPC + e]) : v[e];
+      float t = fmaf(v[e], sc[e], sh[e]);
       if (act == GI_ACT_RELU) t = t > 0.f ? t : 0.f;
       else if (act == GI_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
-      if (drop) t = drop[pix * c + cc * EPC + e] ? t * drop_scale : 0.f;
       v[e] = t;
+    }
+    if (drop) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = drop[pix * c + cc * EPC + e] ? v[e] * drop_scale : 0.f;
     }
     store_vec<T, EPC>(y, pix * ldy + coffy + cc * EPC, v);
   }
@@ -479,8 +489,8 @@ int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
                 const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale) {
   const int epc = dtype == GI_F16 ? 8 : 4;
-  GI_REQUIRE(c % epc == 0, "bn_apply: c=%d", c);
-  const int grid = nblocks(pixels * (c / epc), 2);
+  GI_REQUIRE(c % epc == 0 && gi_is_pow2(c / epc) && c / epc <= 256, "bn_apply: c=%d", c);
+  const int grid = nblocks(pixels * (c / epc), 4);
   if (dtype == GI_F16)
     hipLaunchKernelGGL(bn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale);
   else

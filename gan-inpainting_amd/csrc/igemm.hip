@@ -449,7 +449,10 @@ int run(hipStream_t st, IgemmArgs& a) {
   else GI_TRY((launch_cfg<T, PHASE, 256, 64, 4, 1>(st, kp, grid)));
   a.ntiles_out = mt * phases;
   if (splitk > 1) {
-    const int rpb = 64;
+    const int RL = 256 / (a.cout / 4) > 0 ? 256 / (a.cout / 4) : 1;   // row lanes per block
+    int rpb = 64;
+    while (rpb > RL && (out_pixels + rpb - 1) / rpb < 256) rpb >>= 1;   // fill the chip on small tensors
+    if (rpb < RL) rpb = RL;
     const int blocks = (int)((out_pixels + rpb - 1) / rpb);
     GI_REQUIRE(a.cout <= 1024, "igemm split-K finish: cout=%d > 1024", a.cout);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, st, a.ws, a.bias, (char*)a.out,

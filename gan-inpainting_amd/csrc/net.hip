@@ -73,7 +73,7 @@ struct gi_net {
   int64_t oA[5] = {-1, -1, -1, -1, -1}, oRd[5] = {-1, -1, -1, -1, -1};
   // shared scratch
   std::vector<int64_t> ogC, ogA;
-  int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1;
+  int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1, oCol = -1;
   int64_t part_floats = 0, split_bytes = 0;
   std::vector<int> slot_n, slot_train;
   std::vector<std::vector<const uint8_t*>> ext_mask;  // [slot][level]
@@ -211,6 +211,7 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
   }
   net->oD = A.take(maxD);
   net->oG0 = A.take(N * H * W * 4);
+  net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
   net->oSums = A.take(2 * maxc * 4);
@@ -293,6 +294,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
   net->oDh = A.take(N * net->P * 4);
+  net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   Arena S;
   for (int i = 1; i <= 4; ++i) net->oA[i] = S.take(N * (H >> i) * (W >> i) * chans[i] * T);
   for (int i = 2; i <= 4; ++i) net->oRd[i] = S.take(N * (H >> i) * (W >> i) * chans[i] * T);
@@ -534,7 +536,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   }
   float* osave = (float*)net->slot(s, net->oOut);
   GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
-                       net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f));
+                       net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol)));
   GI_HIP(hipMemcpyAsync(y, osave, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   return GI_OK;
 }
@@ -614,7 +616,8 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     if (need_wgrad)
       GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c,
                          0, 0, iLS, 1.f));
-    if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS));
+    if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS,
+                                 net->shared(net->oCol)));
   }
   return GI_OK;
 }
@@ -677,7 +680,8 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
                     1.f, nullptr, need_wgrad));
   if (need_wgrad)
     GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f));
-  if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS));
+  if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS,
+                               net->shared(net->oCol)));
   return GI_OK;
 }
 

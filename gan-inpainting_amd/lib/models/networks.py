@@ -103,6 +103,7 @@ class HipNet(nn.Module):
         self._bn_count_buffers = []
         self._anchor = None
         self._loss_scale = 65536.0 if self._dtype == B.GI_F16 else 1.0
+        self._nbt_pending = 0
         self.always_sync = False
 
     # ---- subclass hooks ----------------------------------------------------------------------
@@ -254,7 +255,18 @@ class HipNet(nn.Module):
             self._flat["grads"].zero_()
         self._attach_grads() if self._flat["params"].is_cuda else None
 
+    def _flush_nbt(self):
+        if self._nbt_pending:
+            for mod in self._bn_count_buffers:
+                mod._buffers["num_batches_tracked"] += self._nbt_pending
+            self._nbt_pending = 0
+
+    def state_dict(self, *args, **kw):
+        self._flush_nbt()
+        return super().state_dict(*args, **kw)
+
     def load_state_dict(self, state_dict, strict=True, **kw):
+        self._nbt_pending = 0
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         self._dirty = True
         return res
@@ -300,8 +312,7 @@ class HipNet(nn.Module):
         y = torch.empty(self._output_shape(n, H, W), dtype=torch.float32, device=x.device)
         B.check(lib.gi_net_forward(self._handle, slot, B.ptr(x), B.ptr(y), n))
         if self.training:
-            for mod in self._bn_count_buffers:
-                mod._buffers["num_batches_tracked"] += 1
+            self._nbt_pending += 1   # num_batches_tracked is bookkeeping only: materialised lazily
         self._last_slot = slot
         return y, slot, self._slot_gen[slot]
 
