@@ -1,0 +1,124 @@
+"""Shared host logic of the experiment plugins: the epoch loop, logging, bookkeeping and
+checkpoint cadence of the reference plugins (experiment_list/minimaxgan_l1.py:83-261 and siblings)
+around a per-batch step object from gan_inpainting_amd.trainer.
+
+Differences to the reference, all host-side and listed in DESIGN.md:
+  * save directory / log file come from state['outdir'] (the reference hard-codes
+    /home/s2125048/thesis/model/<title>/ and log/<title>.log, minimaxgan_l1.py:27,34);
+  * losses are read back once per `logevery` batches instead of ~45 blocking .item() calls per batch;
+  * the gradient-flow histogram (one .item() per tensor per batch, :180-182,:195-197) is one kernel +
+    one copy per batch (util.GradFlow), accumulated on the device;
+  * evaluation metrics that need FID / the segmentation model (evaluate.calculate_metric) are outside
+    this backend's scope: `state['eval_fn']`, if given, is called with (net_G, loader, epoch).
+"""
+import logging
+import os
+import pickle
+import time
+
+import torch
+
+from .. import optim, trainer
+from ..lib.models import networks, util
+
+
+def setup(state, title):
+    state = state.copy()
+    state.update({"title": title})
+    outdir = state.get("outdir") or os.path.join(os.getcwd(), "runs")
+    exp_dir = os.path.join(outdir, "model", title)
+    os.makedirs(exp_dir, exist_ok=True)
+    os.makedirs(os.path.join(outdir, "log"), exist_ok=True)
+    logger = logging.getLogger(title)
+    if not logger.handlers:
+        h = logging.FileHandler(os.path.join(outdir, "log", f"{title}.log"))
+        h.setFormatter(logging.Formatter("%(asctime)s %(message)s"))
+        logger.addHandler(h)
+    logger.setLevel(logging.INFO)
+    if not torch.cuda.is_available():
+        raise RuntimeError("the HIP backend needs a gfx950 device (there is no CPU fallback)")
+    device = torch.device("cuda", torch.cuda.current_device())
+    logger.info("using device %s", device)
+    return state, exp_dir, logger, device
+
+
+def build_networks(state, device, n_disc=1, sigmoid=True):
+    size = state["imagedim"]
+    dtype = state.get("dtype", "fp16")
+    if state.get("generator", "unet") != "unet" or state.get("discriminator", "patchgan") != "patchgan":
+        raise NotImplementedError("HIP backend accelerates -g unet -d patchgan (the reference defaults, train.py:27-28)")
+    num_downs = state.get("num_downs", 7 if size >= 128 else 6)
+    if num_downs == 7:
+        G = networks.get_network("generator", "unet", dtype=dtype)
+    else:
+        G = networks.UnetGenerator(1, 1, num_downs, ngf=64, use_dropout="False", dtype=dtype)
+    Ds = [networks.PatchGANDiscriminator(sigmoid=sigmoid, image_size=size, dtype=dtype).to(device) for _ in range(n_disc)]
+    return G.to(device), Ds
+
+
+def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn, d_names):
+    """batch_fn(batch_index, ground, mask) -> (loss dict of device scalars, g_updated: bool)."""
+    num_epochs, save_every, evaluate_every = state["numepoch"], state["saveevery"], state["evalevery"]
+    log_every = state.get("logevery", 50)
+    flow_G = util.GradFlow(net_G)
+    flows_D = [util.GradFlow(d) for d in nets_D]
+    history, eval_hist = [], []
+    for epoch in range(num_epochs + 1):
+        start = time.time()
+        sums, g_updates, batches = {}, 0, 0
+        acc_g = torch.zeros(len(flow_G.names), device=device)
+        acc_d = [torch.zeros(len(f.names), device=device) for f in flows_D]
+        for bi, (ground, mask, _) in enumerate(loaders["train"]):
+            ground = ground.to(device, non_blocking=True).float().contiguous()
+            mask = mask.to(device, non_blocking=True).float().contiguous()
+            L, g_updated = batch_fn(bi, ground, mask)
+            for k, v in L.items():
+                sums[k] = sums.get(k, 0) + v.detach().clone()
+            batches += 1
+            for f, a in zip(flows_D, acc_d):
+                a += f.measure()
+            if g_updated:
+                g_updates += 1
+                acc_g += flow_G.measure()
+            if bi % log_every == 0:
+                logger.info("[epoch %d/%d][batch %d/%d] %s", epoch, num_epochs, bi, len(loaders["train"]),
+                            " ".join(f"{k}: {float(v):.4f}" for k, v in L.items()))
+        rec = {k: float(v) / max(batches, 1) for k, v in sums.items()}
+        grads = {"avg_g": dict(zip(flow_G.names, (acc_g / g_updates).tolist())) if g_updates
+                 else {n: -7777 for n in flow_G.names}}     # -7777 sentinel: minimaxgan_l1.py:209-218
+        for name, f, a in zip(d_names, flows_D, acc_d):
+            grads[name] = dict(zip(f.names, (a / max(batches, 1)).tolist()))
+        history.append({"losses": rec, "g_updates": g_updates, "gradients": grads})
+        if epoch % evaluate_every == 0 and epoch > 0:
+            if state.get("eval_fn"):
+                eval_hist.append(state["eval_fn"](net_G, loaders.get("test"), epoch))
+            with open(os.path.join(exp_dir, "training_epoch_history.obj"), "wb") as h:
+                pickle.dump(history, h, protocol=pickle.HIGHEST_PROTOCOL)
+            with open(os.path.join(exp_dir, "eval_history.obj"), "wb") as h:
+                pickle.dump(eval_hist, h, protocol=pickle.HIGHEST_PROTOCOL)
+        if epoch % save_every == 0 and epoch > 0:
+            # same contract as the reference: G only, plain state_dict (minimaxgan_l1.py:253-255)
+            torch.save({k: v.detach().cpu().contiguous() for k, v in net_G.state_dict().items()},
+                       os.path.join(exp_dir, "epoch{}_G.pt".format(epoch)))
+        logger.info("epoch: %d, time: %.3fs, %s", epoch, time.time() - start,
+                    ", ".join(f"{k}: {v:.6f}" for k, v in rec.items()))
+    return history
+
+
+def make_optimizers(kind, net_G, d_params):
+    if kind == "adam":    # minimaxgan_l1.py:64-65
+        return (optim.Adam(net_G.parameters(), lr=0.0002, betas=(0.5, 0.999)),
+                optim.Adam(d_params, lr=0.0002, betas=(0.5, 0.999)))
+    return (optim.RMSprop(net_G.parameters(), lr=0.00005),     # wgan_l1.py:64-65
+            optim.RMSprop(d_params, lr=0.00005))
+
+
+def make_sync():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        from .. import parallel
+        return parallel.GradSync()
+    return None
+
+
+__all__ = ["setup", "build_networks", "run_epochs", "make_optimizers", "make_sync", "trainer"]

@@ -1,0 +1,23 @@
+"""Plugin `wgan_rmse`: begin(state, loaders), the contract of the reference's train.py:183-186.
+Schedule: the reference's experiment_list/wgan_l1.py:110-186 (WGAN critic with weight clipping 0.01,
+RMSprop lr=5e-5, RMSE reconstruction; G every 140 batches while G_iter_count < 25 or % 500 == 0, else
+every 5, :157-163), with one=+1 / mone=-1 (the reference's torch.FloatTensor(1) is uninitialised memory).
+The reference's wgan_rmse.py does not parse (SyntaxError at :104); this is its evident intent: wgan_l1 with RMSELoss."""
+from . import _common as C
+
+
+def begin(state, loaders):
+    state, exp_dir, logger, device = C.setup(state, "wgan_rmse")
+    net_G, (net_D,) = C.build_networks(state, device, n_disc=1, sigmoid=False)    # wgan_l1.py:58
+    opt_G, opt_D = C.make_optimizers("rmsprop", net_G, net_D.parameters())
+    step = C.trainer.WGANStep(net_G, net_D, opt_G, opt_D, recon="rmse", clip=0.01, sync=C.make_sync())
+    counters = {"G_iter_count": 0}
+
+    def batch(bi, ground, mask):
+        upd = C.trainer.wgan_update_g(bi, counters["G_iter_count"], update_g_every=5)
+        L = step(ground, mask, upd)
+        if upd:
+            counters["G_iter_count"] += 1
+        return L, upd
+
+    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"])

