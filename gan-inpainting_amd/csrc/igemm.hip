@@ -14,6 +14,8 @@
 // Epilogue: optional bias + activation, per-tile column sum / sum-of-squares (BatchNorm batch
 // statistics, deterministic: no atomics), result staged through LDS and stored with 16-byte
 // coalesced rows. Small-M layers use split-K with fp32 atomics into a scratch + a finish kernel.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +33,7 @@ struct KP {
   int Ktot, nk, splitk, kt_per_split;
   int relu_in, act_out;
   int Hin, Win, Hout, Wout;
+  int64_t in_elems;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -42,8 +45,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 template <typename T>
 __device__ __forceinline__ u4_t relu16(u4_t v) {
   if constexpr (std::is_same<T, half_t>::value) {
-    h8_t h = __builtin_bit_cast(h8_t, v);
-    h8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    // max(x, 0) on packed halves as signed 16-bit integers: negative halves have the sign bit set
+    typedef short s8_t __attribute__((ext_vector_type(8)));
+    s8_t h = __builtin_bit_cast(s8_t, v);
+    const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
     h = __builtin_elementwise_max(h, z);
     return __builtin_bit_cast(u4_t, h);
   } else {
@@ -55,7 +60,7 @@ __device__ __forceinline__ u4_t relu16(u4_t v) {
 }
 
 template <typename T, int PHASE, int BM, int BN, int WGM, int WGN>
-__global__ void __launch_bounds__(256) igemm_kernel(KP p) {
+__global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
   constexpr bool F16 = std::is_same<T, half_t>::value;
   constexpr int EPC = 16 / (int)sizeof(T);  // elements per 16-byte chunk
   constexpr int BK = 8 * EPC;               // 128-byte K rows
@@ -122,62 +127,80 @@ __global__ void __launch_bounds__(256) igemm_kernel(KP p) {
   int tap = (kt_begin * BK) / p.cin;
   int c0 = (kt_begin * BK) % p.cin;
 
-  u4_t ra[AP], rb[BP];
-
-  auto gload = [&](int kt) {
-    int soff;
-    if (PHASE) soff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
-    else soff = ((tap >> 2) * p.Win + (tap & 3)) * p.ldin;
-    soff += c0 + chunk * EPC;
+  // ---- loop-invariant addressing ------------------------------------------------------------
+  // A: per-row byte offsets for the CURRENT tap (recomputed only when the tap changes); rows whose
+  //    tap falls into the padding get an out-of-range offset: the buffer load returns zeros.
+  // B: per-row byte offsets (constant); the K position lives in the scalar buffer base.
+  // LDS: write / fragment-read addresses are lane constants + immediates.
+  constexpr unsigned OOB = 0x7FFFFFF0u;
+  constexpr int ES = (int)sizeof(T);
+  const unsigned in_bytes = (unsigned)min((int64_t)0x7FFFFF00, (int64_t)p.in_elems * ES);
+  const unsigned w_bytes = (unsigned)min((int64_t)0x7FFFFF00, (int64_t)p.cout * p.Ktot * ES);
+  unsigned voffA[AP], voffB[BP];
+  auto set_tap = [&]() {
+    int toff;
+    if (PHASE) toff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
+    else toff = ((tap >> 2) * p.Win + (tap & 3)) * p.ldin;
     static_for<AP>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      u4_t v = u4_t{0u, 0u, 0u, 0u};
-      if ((amask[i] >> tap) & 1u) v = *(const u4_t*)(p.in + (int64_t)(abase[i] + soff) * (int64_t)sizeof(T));
-      ra[i] = v;
+      voffA[i] = ((amask[i] >> tap) & 1u) ? (unsigned)((abase[i] + toff) * ES + chunk * 16) : OOB;
     });
-    const int64_t koff = (int64_t)kt * BK + chunk * EPC;
+  };
+  static_for<BP>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    voffB[i] = (unsigned)(((n0 + rbase + 32 * i) * p.Ktot) * ES + chunk * 16);
+  });
+  set_tap();
+
+  u4_t ra[AP], rb[BP];
+  auto gload = [&](int kt) {
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in + (int64_t)c0 * ES), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(wptr + (int64_t)kt * (BK * ES)), 0, w_bytes, 0x00020000);
+    static_for<AP>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      ra[i] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rsA, voffA[i], 0, 0));
+    });
     static_for<BP>([&](auto I) {
       constexpr int i = decltype(I)::value;
-      const int row = n0 + rbase + 32 * i;
-      rb[i] = *(const u4_t*)(wptr + ((int64_t)row * p.Ktot + koff) * (int64_t)sizeof(T));
+      rb[i] = __builtin_bit_cast(u4_t, __builtin_amdgcn_raw_buffer_load_b128(rsB, voffB[i], 0, 0));
     });
     c0 += BK;
-    if (c0 >= p.cin) { c0 = 0; ++tap; }
+    if (c0 >= p.cin) { c0 = 0; ++tap; set_tap(); }
   };
 
-  auto lds_store = [&](int stage) {
+  // lane-constant LDS offsets
+  const int wrow = rbase;                                            // rows rbase + 32 i share rbase & 7
+  const int woff16 = wrow * 128 + ((chunk ^ (wrow & 7)) << 4);       // fp16 write offset (+ i*4096)
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rdA0 = (wm * WM + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);   // k2 = 0 (+ mt*2048)
+  const int rdA1 = (wm * WM + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);   // k2 = 1
+  const int rdB0 = (wn * WN + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdB1 = (wn * WN + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+
+  auto lds_store = [&](auto STG) {
+    constexpr int stage = decltype(STG)::value;
     char* sA = smem + stage * STAGE_BYTES;
     char* sB = sA + A_BYTES;
     if (p.relu_in) {
       static_for<AP>([&](auto I) { ra[decltype(I)::value] = relu16<T>(ra[decltype(I)::value]); });
     }
     if constexpr (F16) {
-      static_for<AP>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const int r = rbase + 32 * i;
-        *(u4_t*)(sA + r * 128 + ((chunk ^ (r & 7)) << 4)) = ra[i];
-      });
-      static_for<BP>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        const int r = rbase + 32 * i;
-        *(u4_t*)(sB + r * 128 + ((chunk ^ (r & 7)) << 4)) = rb[i];
-      });
+      static_for<AP>([&](auto I) { *(u4_t*)(sA + woff16 + decltype(I)::value * 4096) = ra[decltype(I)::value]; });
+      static_for<BP>([&](auto I) { *(u4_t*)(sB + woff16 + decltype(I)::value * 4096) = rb[decltype(I)::value]; });
     } else {
-      float* fA = (float*)sA;
-      float* fB = (float*)sB;
+      float* fA = (float*)sA + chunk * 4 * LDA32 + rbase;
+      float* fB = (float*)sB + chunk * 4 * LDB32 + rbase;
       static_for<AP>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        const int r = rbase + 32 * i;
         const f4_t v = __builtin_bit_cast(f4_t, ra[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fA[(chunk * 4 + j) * LDA32 + r] = v[j];
+        for (int j = 0; j < 4; ++j) fA[j * LDA32 + 32 * i] = v[j];
       });
       static_for<BP>([&](auto I) {
         constexpr int i = decltype(I)::value;
-        const int r = rbase + 32 * i;
         const f4_t v = __builtin_bit_cast(f4_t, rb[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fB[(chunk * 4 + j) * LDB32 + r] = v[j];
+        for (int j = 0; j < 4; ++j) fB[j * LDB32 + 32 * i] = v[j];
       });
     }
   };
@@ -191,24 +214,19 @@ __global__ void __launch_bounds__(256) igemm_kernel(KP p) {
 #pragma unroll
       for (int r = 0; r < (F16 ? 4 : 16); ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int stage) {
+  auto compute = [&](auto STG) {
+    constexpr int stage = decltype(STG)::value;
     const char* sA = smem + stage * STAGE_BYTES;
     const char* sB = sA + A_BYTES;
     if constexpr (F16) {
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
         h8_t af[MT], bf[NT];
-        const int ch = k2 * 4 + (lane >> 4);
+        const int oa = k2 ? rdA1 : rdA0, ob = k2 ? rdB1 : rdB0;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int r = wm * WM + mt * 16 + (lane & 15);
-          af[mt] = *(const h8_t*)(sA + r * 128 + ((ch ^ (r & 7)) << 4));
-        }
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(sA + oa + mt * 2048);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int r = wn * WN + nt * 16 + (lane & 15);
-          bf[nt] = *(const h8_t*)(sB + r * 128 + ((ch ^ (r & 7)) << 4));
-        }
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(sB + ob + nt * 2048);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -216,16 +234,15 @@ __global__ void __launch_bounds__(256) igemm_kernel(KP p) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
       }
     } else {
-      const float* fA = (const float*)sA;
-      const float* fB = (const float*)sB;
+      const float* fA = (const float*)sA + (lane >> 5) * LDA32 + wm * WM + (lane & 31);
+      const float* fB = (const float*)sB + (lane >> 5) * LDB32 + wn * WN + (lane & 31);
 #pragma unroll 4
       for (int kk = 0; kk < 16; ++kk) {
-        const int k = 2 * kk + (lane >> 5);
         float af[MT], bf[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = fA[k * LDA32 + wm * WM + mt * 32 + (lane & 31)];
+        for (int mt = 0; mt < MT; ++mt) af[mt] = fA[2 * kk * LDA32 + mt * 32];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = fB[k * LDB32 + wn * WN + nt * 32 + (lane & 31)];
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = fB[2 * kk * LDB32 + nt * 32];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -235,19 +252,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(KP p) {
     }
   };
 
-  // ---- main loop: one barrier per K tile, next tile's loads in flight during the MFMAs -----
+  // ---- main loop: one barrier per K tile, next tile's loads in flight during the MFMAs; the two
+  //      LDS stages are separate code copies so every LDS address is a lane constant + immediate -----
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (kt_begin < kt_end) {
     gload(kt_begin);
-    lds_store(0);
+    lds_store(S0{});
     __syncthreads();
-    int stage = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const bool more = (kt + 1 < kt_end);
-      if (more) gload(kt + 1);
-      compute(stage);
-      if (more) lds_store(stage ^ 1);
+    for (int kt = kt_begin; kt < kt_end; kt += 2) {
+      const bool more1 = (kt + 1 < kt_end);
+      if (more1) gload(kt + 1);
+      compute(S0{});
+      if (more1) lds_store(S1{});
       __syncthreads();
-      stage ^= 1;
+      if (!more1) break;
+      const bool more2 = (kt + 2 < kt_end);
+      if (more2) gload(kt + 2);
+      compute(S1{});
+      if (more2) lds_store(S0{});
+      __syncthreads();
     }
   }
 
@@ -420,6 +444,7 @@ int run(hipStream_t st, IgemmArgs& a) {
   if (PHASE) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
   else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
   const int64_t in_elems = (int64_t)a.n * kp.Hin * kp.Win * a.ldin;
+  kp.in_elems = in_elems;
   const int64_t out_pixels = (int64_t)a.n * kp.Hout * kp.Wout;
   GI_REQUIRE(in_elems < (1ll << 31) && out_pixels * a.ldout < (1ll << 31), "igemm: tensor too large for 32-bit offsets");
 
@@ -465,7 +490,13 @@ int run(hipStream_t st, IgemmArgs& a) {
 
 }  // namespace
 
+int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a);   // igemm3.hip
+
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a) {
+  if (dtype == GI_F16 && a.force_splitk == 0 && getenv("GI_NO_IGEMM3") == nullptr) {
+    const int rc = op_igemm3(st, phase_mode, a);
+    if (rc != GI_ERR_UNSUPPORTED) return rc;
+  }
   if (dtype == GI_F16) return phase_mode ? run<half_t, 1>(st, a) : run<half_t, 0>(st, a);
   if (dtype == GI_F32) return phase_mode ? run<float, 1>(st, a) : run<float, 0>(st, a);
   gi_set_error("igemm: bad dtype %d", dtype);

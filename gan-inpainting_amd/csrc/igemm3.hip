@@ -1,0 +1,302 @@
+// fp16 implicit-GEMM, second generation (gfx950): 256x128 output tile, 8 waves (4x2, 64x64 each),
+// K tile = 64 halves, THREE-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4: no VGPR
+// staging, no ds_write), counted vmcnt + one raw s_barrier per K tile, MFMA 16x16x32 f16.
+//
+// Same algebra and LDS image as igemm.hip (rows of 128 bytes, 16-byte chunk c stored at physical
+// chunk c ^ (row & 7)); because an LDS-DMA wave instruction writes 1 KiB linearly (lane l -> slot l)
+// the swizzle is applied to the per-lane SOURCE address: lane l fetches chunk (l&7)^((l>>3)&7) of row
+// l>>3 of its 8-row block. Padding taps read a zero page instead (the DMA cannot zero-fill), the
+// decoder's ReLU is applied to the A fragments after the LDS read (integer pk_max).
+// Block order is XCD-aware: the (N tile, phase) blocks that share an M tile run back to back on one
+// XCD so the gathered input rows are served by that XCD's L2.
+#include "common.h"
+
+namespace {
+
+struct KP3 {
+  const char* in;
+  const char* w;
+  char* out;
+  const char* zero;   // >= 4 KiB of zeros
+  const float* bias;
+  float* partials;
+  int M, Hs, Ws;
+  int cin, ldin, coffin;
+  int cout, ldout, coffout;
+  int Ktot, nk;
+  int relu_in, act_out;
+  int Hin, Win, Hout, Wout;
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ float act3(float v, int act) {
+  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+
+__device__ __forceinline__ h8_t relu_h8(h8_t v) {
+  typedef short s8_t __attribute__((ext_vector_type(8)));
+  s8_t h = __builtin_bit_cast(s8_t, v);
+  const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  h = __builtin_elementwise_max(h, z);
+  return __builtin_bit_cast(h8_t, h);
+}
+
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int PHASE>
+__global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
+  constexpr int BM = 256, BN = 128, BK = 64;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 KiB
+  constexpr int AJ = 4, BJ = 2;          // 8-row blocks per wave per tile
+  constexpr int MT = 4, NT = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile order ------------------------------------------------------------------
+  const int nyz = p.ntiles * (PHASE ? 4 : 1);
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int mt_idx = (local / nyz) * 8 + xcd;
+  if (mt_idx >= p.mtiles) return;
+  const int yz = local % nyz;
+  const int nt_idx = yz % p.ntiles;
+  const int ph = yz / p.ntiles;
+  const int py = ph >> 1, px = ph & 1;
+  const int m0 = mt_idx * BM, n0 = nt_idx * BN;
+  const char* wptr = p.w + (PHASE ? (int64_t)ph * p.cout * p.Ktot * 2 : 0);
+
+  // ---- per-lane gather rows ------------------------------------------------------------------
+  const int lrow = lane >> 3;                       // row inside the 8-row block
+  const int lchunk = (lane & 7) ^ (lrow & 7);       // logical 16-byte chunk this lane fetches
+  int abase[AJ];
+  unsigned amask[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + (wave * AJ + j) * 8 + lrow;
+    abase[j] = 0;
+    amask[j] = 0;
+    if (m < p.M) {
+      const int x = m % p.Ws;
+      const int t = m / p.Ws;
+      const int y = t % p.Hs;
+      const int n = t / p.Hs;
+      if (PHASE) {
+        const int y0 = y + py, x0 = x + px;
+        abase[j] = ((n * p.Hs + y0) * p.Ws + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int iy = y0 - (tt >> 1), ix = x0 - (tt & 1);
+          if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) amask[j] |= 1u << tt;
+        }
+      } else {
+        const int y0 = 2 * y - 1, x0 = 2 * x - 1;
+        abase[j] = ((n * p.Hin + y0) * p.Win + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+          const int iy = y0 + (tt >> 2), ix = x0 + (tt & 3);
+          if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) amask[j] |= 1u << tt;
+        }
+      }
+    }
+  }
+  const char* pa[AJ];
+  const char* pb[BJ];
+  int tap = 0, c0 = 0;
+  auto set_tap = [&]() {
+    int toff;
+    if (PHASE) toff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
+    else toff = ((tap >> 2) * p.Win + (tap & 3)) * p.ldin;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      pa[j] = ((amask[j] >> tap) & 1u) ? p.in + (int64_t)(abase[j] + toff) * 2 + lchunk * 16 : p.zero + lchunk * 16;
+  };
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) pb[j] = wptr + (int64_t)(n0 + (wave * BJ + j) * 8 + lrow) * p.Ktot * 2 + lchunk * 16;
+  set_tap();
+
+  int kt_issue = 0;
+  auto issue = [&](auto STG) {
+    constexpr int stage = decltype(STG)::value;
+    char* sA = smem + stage * STAGE + wave * (AJ * 1024);
+    char* sB = smem + stage * STAGE + A_BYTES + wave * (BJ * 1024);
+    const int koff = c0 * 2;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) glds16(pa[j] + koff, sA + j * 1024);
+    const int64_t kb = (int64_t)kt_issue * (BK * 2);
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) glds16(pb[j] + kb, sB + j * 1024);
+    ++kt_issue;
+    c0 += BK;
+    if (c0 >= p.cin) { c0 = 0; ++tap; set_tap(); }
+  };
+
+  f4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rdA0 = (wm * 64 + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdA1 = (wm * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+  const int rdB0 = A_BYTES + (wn * 64 + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdB1 = A_BYTES + (wn * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+  const int relu_in = p.relu_in;
+
+  auto compute = [&](auto STG) {
+    constexpr int stage = decltype(STG)::value;
+    const char* s = smem + stage * STAGE;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      h8_t af[MT], bf[NT];
+      const int oa = k2 ? rdA1 : rdA0, ob = k2 ? rdB1 : rdB0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(s + oa + mt * 2048);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(s + ob + nt * 2048);
+      if (relu_in) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = relu_h8(af[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+
+  // ---- 3-stage ring. Per tile each wave issues AJ+BJ = 6 LDS-DMA instructions; before computing tile
+  //      t its own 6 must have landed (vmcnt(6) leaves tile t+1 in flight), the barrier then makes every
+  //      wave's share visible and proves stage (t+2)%3 == (t-1)%3 is no longer being read. --------------
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  const int nk = p.nk;
+  issue(S0{});
+  if (nk > 1) issue(S1{});
+  auto step = [&](int t, auto CUR, auto NXT2) {
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + 2 < nk) issue(NXT2);
+    compute(CUR);
+  };
+  for (int t = 0; t < nk; t += 3) {
+    step(t, S0{}, S2{});
+    if (t + 1 < nk) step(t + 1, S1{}, S0{});
+    if (t + 2 < nk) step(t + 2, S2{}, S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue (same contract as igemm.hip) --------------------------------------------------------
+  auto out_pixel = [&](int m) -> int {
+    if (!PHASE) return m;
+    const int x = m % p.Ws;
+    const int t = m / p.Ws;
+    const int y = t % p.Hs;
+    const int n = t / p.Hs;
+    return (n * p.Hout + 2 * y + py) * p.Wout + 2 * x + px;
+  };
+  constexpr int SLD = BN + 8;
+  half_t* stg = (half_t*)smem;
+  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = wn * 64 + nt * 16 + lr;
+    const float b = p.bias ? p.bias[n0 + col] : 0.f;
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][nt][r] + b;
+        s += v;
+        q += v * v;
+        v = act3(v, p.act_out);
+        stg[(wm * 64 + mt * 16 + lq * 4 + r) * SLD + col] = (half_t)v;
+      }
+    if (p.partials) {
+      s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+      s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+      if (lane < 16) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+    }
+  }
+  __syncthreads();
+  if (p.partials && tid < BN) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
+    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
+    p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
+    p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+  }
+  const int oc = tid & 15;       // 16 chunks of 8 halves per 128-column row
+#pragma unroll 1
+  for (int r = tid >> 4; r < BM; r += 32) {
+    const int m = m0 + r;
+    if (m < p.M) {
+      const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
+      *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+    }
+  }
+}
+
+char* g_zero_page[16] = {nullptr};
+
+}  // namespace
+
+// returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
+int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
+  if (a.cin % 64 != 0 || a.cout % 128 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
+  const int M = a.n * a.Hs * a.Ws;
+  {   // too few tiles to fill 256 CUs: the split-K path of igemm.hip serves those layers
+    const int tiles = ((M + 255) / 256) * (a.cout / 128) * (phase_mode ? 4 : 1);
+    if (tiles < 128) return GI_ERR_UNSUPPORTED;
+  }
+  int dev = 0;
+  GI_HIP(hipGetDevice(&dev));
+  if (!g_zero_page[dev & 15]) {
+    GI_HIP(hipMalloc((void**)&g_zero_page[dev & 15], 8192));
+    GI_HIP(hipMemset(g_zero_page[dev & 15], 0, 8192));
+  }
+  KP3 kp;
+  kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = g_zero_page[dev & 15];
+  kp.bias = a.bias; kp.partials = a.partials;
+  kp.M = M; kp.Hs = a.Hs; kp.Ws = a.Ws;
+  kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
+  kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
+  kp.Ktot = (phase_mode ? 4 : 16) * a.cin;
+  kp.nk = kp.Ktot / 64;
+  kp.relu_in = a.relu_in; kp.act_out = a.act_out;
+  if (phase_mode) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
+  else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
+  GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
+             "igemm3: tensor too large for 32-bit offsets");
+  kp.mtiles = (M + 255) / 256;
+  kp.ntiles = a.cout / 128;
+  const int nyz = kp.ntiles * (phase_mode ? 4 : 1);
+  const int grid = ((kp.mtiles + 7) / 8) * 8 * nyz;
+  constexpr int LDS = 3 * (256 + 128) * 128;
+  static bool attr_set[2] = {false, false};
+  if (phase_mode) {
+    if (!attr_set[1]) { GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set[1] = true; }
+    hipLaunchKernelGGL(igemm3_kernel<1>, dim3(grid), dim3(512), LDS, st, kp);
+  } else {
+    if (!attr_set[0]) { GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set[0] = true; }
+    hipLaunchKernelGGL(igemm3_kernel<0>, dim3(grid), dim3(512), LDS, st, kp);
+  }
+  GI_LAUNCH_CHECK();
+  a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
+  return GI_OK;
+}

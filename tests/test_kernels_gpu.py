@@ -26,6 +26,8 @@ CONV_CASES = [
     (3, 8, 8, 256, 512, True),
     (2, 4, 4, 512, 512, True),       # 2x2 output, heavy padding
     (5, 2, 2, 512, 512, True),       # 1x1 output (bottleneck)
+    (8, 128, 128, 64, 128, False),   # >= 128 tiles: the 256x128 LDS-DMA kernel (igemm3.hip) in fp16
+    (7, 72, 72, 64, 512, False),     # igemm3 with a ragged last M tile (M = 9072) and non-power-of-two maps
 ]
 
 
@@ -75,6 +77,8 @@ CONVT_CASES = [
     (1, 32, 32, 256, 128, False),
     (3, 1, 1, 512, 512, True),      # bottleneck 1x1 -> 2x2
     (2, 2, 2, 1024, 512, True),
+    (8, 32, 32, 256, 128, False),   # igemm3 (fp16): 32 M tiles x 4 phases
+    (3, 40, 40, 128, 256, False),   # igemm3, ragged M (4800), two N tiles
 ]
 
 
@@ -123,6 +127,49 @@ def test_wgrad_s2(code, case):
     got = dW.cpu().permute(0, 3, 1, 2)
     ok, msg = report(f"wgrad {case} dt={code}", got, ref, 5e-5 if code == B.GI_F32 else 2e-3)
     assert ok, msg
+
+
+@pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
+def test_convT_s2_relu_strided_large(code):
+    """Decoder form at igemm3 size: ReLU on the input, input read from the first half of a wider
+    buffer (channel offset 0, ld = 2*ca), output written into a wider buffer."""
+    n, H, W, ca, cb = 8, 32, 32, 128, 128
+    x = quant(_rand((n, ca, H, W), 9), code)
+    w = quant(_rand((ca, cb, 4, 4), 10, 0.05), code)
+    ref = F.conv_transpose2d(F.relu(x), w, None, stride=2, padding=1)
+    _, phase = pack(w, code)
+    wide = torch.full((n, H, W, 2 * ca), 5.0, dtype=tdt(code), device="cuda")
+    wide[..., :ca] = nhwc_dev(x, code)
+    out = torch.zeros((n, 2 * H, 2 * W, 2 * cb), dtype=tdt(code), device="cuda")
+    B.check(B.lib().gi_convT_s2_forward(B.get_ctx(), code, B.ptr(wide), B.ptr(phase), B.ptr(out), n, H, W, ca, 2 * ca, cb, 2 * cb,
+                                        1, 0, None, 0))
+    torch.cuda.synchronize()
+    ok, msg = report(f"convT relu strided large dt={code}", from_nhwc(out[..., :cb].contiguous()), ref, TOL[code])
+    assert ok, msg
+    assert float(out[..., cb:].abs().max()) == 0.0
+
+
+def test_igemm3_exact_integers():
+    """Exact small-integer check at a size served by the LDS-DMA kernel (fragment / swizzle / ring order)."""
+    g = torch.Generator().manual_seed(12)
+    n, H, W, cb, ca = 8, 128, 128, 64, 128
+    x = torch.randint(-2, 3, (n, cb, H, W), generator=g).float()
+    w = torch.randint(-1, 2, (ca, cb, 4, 4), generator=g).float()
+    ref = F.conv2d(x, w, None, stride=2, padding=1)
+    packed, _ = pack(w, B.GI_F16)
+    xd = nhwc_dev(x, B.GI_F16)
+    out = torch.zeros((n, H // 2, W // 2, ca), dtype=torch.float16, device="cuda")
+    B.check(B.lib().gi_conv_s2_forward(B.get_ctx(), B.GI_F16, B.ptr(xd), B.ptr(packed), B.ptr(out), n, H, W, cb, cb, ca, ca, 0, 0, None, 0))
+    assert torch.equal(from_nhwc(out), ref)
+    xs = torch.randint(-2, 3, (8, 256, 32, 32), generator=g).float()
+    wt = torch.randint(-1, 2, (256, 128, 4, 4), generator=g).float()
+    refT = F.conv_transpose2d(xs, wt, None, stride=2, padding=1)
+    _, phase = pack(wt, B.GI_F16)
+    xsd = nhwc_dev(xs, B.GI_F16)
+    outT = torch.zeros((8, 64, 64, 128), dtype=torch.float16, device="cuda")
+    B.check(B.lib().gi_convT_s2_forward(B.get_ctx(), B.GI_F16, B.ptr(xsd), B.ptr(phase), B.ptr(outT), 8, 32, 32, 256, 256, 128, 128, 0, 0,
+                                        None, 0))
+    assert torch.equal(from_nhwc(outT), refT)
 
 
 def test_mfma_layout_exact_integers():

@@ -166,5 +166,7 @@ def test_autograd_surface_matches_fast_path():
     g_loss.backward()
     oG.step()
     torch.cuda.synchronize()
-    assert relerr(abs_sums(D2), abs_sums(D1)) <= 1e-6
-    assert relerr(abs_sums(G2), abs_sums(G1)) <= 1e-5
+    # (float atomics in the weight-gradient kernels make two runs differ in the last bits; Adam then
+    #  moves the rounding-level elements by +-lr)
+    assert relerr(abs_sums(D2), abs_sums(D1)) <= 1e-4
+    assert relerr(abs_sums(G2), abs_sums(G1)) <= 1e-4
