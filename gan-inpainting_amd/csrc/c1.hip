@@ -72,6 +72,76 @@ __global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict_
   }
 }
 
+// Strip form of the gather (used when a row of Ws pixels splits evenly into strips of 256/groups
+// pixels): a block walks strips; the 4 x (2S+2) image window of a strip is staged once in LDS
+// (double-buffered, one barrier per strip) instead of 16 bounds-checked global loads per thread.
+template <typename T>
+__global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                              char* out, int n, int Hs, int Ws, int c, int ldout,
+                                                              int coffout, int act, float in_scale) {
+  constexpr int G = 8;
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  const int groups = c / G;
+  const int S = 256 / groups;            // pixels per strip
+  const int TW = 2 * S + 2;              // staged columns
+  float* swT = smem_f;                   // [16][c]
+  float* tile = smem_f + 16 * c;         // [2][4][TW]
+  for (int i = threadIdx.x; i < c * 16; i += 256) swT[(i & 15) * c + (i >> 4)] = w[i];
+  const int H = 2 * Hs, W = 2 * Ws;
+  const int spr = Ws / S;                                  // strips per row
+  const int64_t nstrips = (int64_t)n * Hs * spr;
+  const int grp = threadIdx.x % groups, pi = threadIdx.x / groups;
+  auto stage = [&](int64_t strip, int buf) {
+    const int sx = (int)(strip % spr);
+    const int64_t t = strip / spr;
+    const int y = (int)(t % Hs);
+    const int nn = (int)(t / Hs);
+    const float* ip = img + (int64_t)nn * H * W;
+    for (int idx = threadIdx.x; idx < 4 * TW; idx += 256) {
+      const int r = idx / TW, cc = idx % TW;
+      const int iy = 2 * y - 1 + r, ix = 2 * sx * S - 1 + cc;
+      tile[(buf * 4 + r) * TW + cc] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ip[(int64_t)iy * W + ix] * in_scale : 0.f;
+    }
+  };
+  int buf = 0;
+  int64_t strip = blockIdx.x;
+  if (strip < nstrips) stage(strip, 0);
+  __syncthreads();
+  for (; strip < nstrips; strip += gridDim.x) {
+    const int64_t next = strip + gridDim.x;
+    if (next < nstrips) stage(next, buf ^ 1);
+    const float* tl = tile + buf * 4 * TW + 2 * pi;
+    float o[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const float v = tl[ky * TW + kx];
+        const float* wr = swT + (ky * 4 + kx) * c + grp * G;
+        const f4_t w0 = *(const f4_t*)wr, w1 = *(const f4_t*)(wr + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o[j] = fmaf(v, w0[j], o[j]); o[4 + j] = fmaf(v, w1[j], o[4 + j]); }
+      }
+#pragma unroll
+    for (int j = 0; j < G; ++j) o[j] = act_f(o[j], act);
+    const int64_t pix = strip * S + pi;      // strips enumerate pixels in (n, y, x) order
+    T* dst = (T*)(out + (pix * ldout + coffout + grp * G) * (int64_t)sizeof(T));
+    if constexpr (std::is_same<T, half_t>::value) {
+      h8_t h;
+#pragma unroll
+      for (int j = 0; j < G; ++j) h[j] = (half_t)o[j];
+      *(h8_t*)dst = h;
+    } else {
+      *(f4_t*)dst = f4_t{o[0], o[1], o[2], o[3]};
+      *(f4_t*)(dst + 4) = f4_t{o[4], o[5], o[6], o[7]};
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
 // ---- fp16 transposed conv to one channel on the matrix cores -------------------------------------
 // col[p][tap] = sum_c relu?(X[p][c]) * w[c][tap]: D[tap][pixel] = A[tap][c] * B[c][pixel] with
 // v_mfma_f32_16x16x32_f16; B fragments are 16-byte row loads of X straight from global memory (each
@@ -297,6 +367,90 @@ __global__ void __launch_bounds__(256) c1_wgrad_kernel(const char* X, const floa
   }
 }
 
+// ---- fp16 weight gradient of the single-channel layers on the matrix cores ------------------------
+// dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx]:  D[tap][c] = A[tap][p] * B[p][c],
+// K = pixels in tiles of 32 that lie in one image row (Ws % 32 == 0). Every wave works alone on its
+// own K tiles: A fragments (16 taps x 8 pixels per lane) are gathered from the fp32 image, the X tile
+// (32 pixels x c, pixel-major = K-major) is staged in a wave-private LDS slab and read with the
+// transposing ds_read_b64_tr_b16; no block barrier. One float atomic per (c, tap) per wave at the end.
+template <int NT>   // NT = c / 16
+__global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const float* __restrict__ img, float* dW,
+                                                            int n, int Hs, int Ws, int ldx, int coffx, int relu_in,
+                                                            float scale, float img_scale, int tiles_per_wave) {
+  constexpr int C = NT * 16;
+  constexpr int LROW = C * 2 + 32;                  // padded LDS row: conflict-free transposing reads
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  char* slab = smem + wave * (32 * LROW);
+  const int tap = lane & 15, kq = lane >> 4;
+  const int ky = tap >> 2, kx = tap & 3;
+  const int H = 2 * Hs, W = 2 * Ws;
+  const int64_t ntiles = (int64_t)n * Hs * Ws / 32;
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t0 = gw * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
+  constexpr int CPR = C * 2 / 16;                   // 16-byte chunks per X row
+  constexpr int RPP = 64 / CPR;                     // rows per load pass
+  constexpr int NP = 32 / RPP;
+  const int xr = lane / CPR, xc = lane % CPR;
+  f4_t acc[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[i] = f4_t{0.f, 0.f, 0.f, 0.f};
+  const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int g16 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  for (int64_t t = t0; t < t1; ++t) {
+    const int64_t p0 = t * 32;
+    const int x0 = (int)(p0 % Ws);
+    const int64_t rowi = p0 / Ws;
+    const int y = (int)(rowi % Hs);
+    const int nn = (int)(rowi / Hs);
+    // X tile -> registers (issued first so the image gathers overlap its latency)
+    u4_t xv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      xv[i] = *(const u4_t*)(X + (((p0 + xr + RPP * i) * ldx + coffx) << 1) + xc * 16);
+    // A fragment: pixels x0 + 8*kq + j of this row, tap (ky,kx)
+    const int iy = 2 * y - 1 + ky;
+    h8_t af = zero;
+    if (iy >= 0 && iy < H) {
+      const float* ip = img + ((int64_t)nn * H + iy) * W;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ix = 2 * (x0 + 8 * kq + j) - 1 + kx;
+        af[j] = (ix >= 0 && ix < W) ? (half_t)(ip[ix] * img_scale) : (half_t)0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      u4_t v = xv[i];
+      if (relu_in) {
+        typedef short s8_t __attribute__((ext_vector_type(8)));
+        s8_t hh = __builtin_bit_cast(s8_t, v);
+        const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        hh = __builtin_elementwise_max(hh, z);
+        v = __builtin_bit_cast(u4_t, hh);
+      }
+      *(u4_t*)(slab + (xr + RPP * i) * LROW + xc * 16) = v;
+    }
+    // (wave-private slab: the LDS unit executes one wave's accesses in program order)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = nt * 16 + 4 * tp;
+      const char* b_lo = slab + (8 * g16 + tq) * LROW + ch * 2;
+      const char* b_hi = slab + (8 * g16 + 4 + tq) * LROW + ch * 2;
+      fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)b_lo);
+      fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)b_hi);
+      h4_t l4 = __builtin_bit_cast(h4_t, lo), h4 = __builtin_bit_cast(h4_t, hi);
+      const h8_t bf = h8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nt], 0, 0, 0);
+    }
+  }
+  // D[row = tap][col = channel]: lane holds channel nt*16 + (lane&15), taps 4*(lane>>4) + r
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dW + (nt * 16 + (lane & 15)) * 16 + 4 * (lane >> 4) + r, acc[nt][r] * scale);
+}
+
 // ---- discriminator head ----------------------------------------------------------------------
 // h[n,py,px] = sum_{ky,kx,c} a4[n,py+ky,px+kx,c] * w5[ky*4+kx][c]     (Conv2d(512,1,4,1,0), networks.py:352)
 template <typename T>
@@ -442,6 +596,21 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
                  int ldout, int coffout, int act_out, float in_scale) {
   GI_REQUIRE(c % 8 == 0 && c <= 1024, "c1_gather: c=%d", c);
   const int64_t total = (int64_t)n * Hs * Ws * (c / 8);
+  const int groups = c / 8;
+  if (gi_is_pow2(groups) && groups <= 32 && Ws % (256 / groups) == 0) {
+    const int S = 256 / groups;
+    const int64_t nstrips = (int64_t)n * Hs * (Ws / S);
+    const int grid = (int)(nstrips < 256 * 8 ? nstrips : 256 * 8);
+    const size_t lds = (size_t)(16 * c + 2 * 4 * (2 * S + 2)) * 4;
+    if (dtype == GI_F16)
+      hipLaunchKernelGGL(c1_gather_strip_kernel<half_t>, dim3(grid), dim3(256), lds, st, img, w, (char*)out, n, Hs, Ws, c, ldout,
+                         coffout, act_out, in_scale);
+    else
+      hipLaunchKernelGGL(c1_gather_strip_kernel<float>, dim3(grid), dim3(256), lds, st, img, w, (char*)out, n, Hs, Ws, c, ldout,
+                         coffout, act_out, in_scale);
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   const int grid = grid_for(total, 256, 256 * 16);
   if (dtype == GI_F16)
     hipLaunchKernelGGL(c1_gather_kernel<half_t>, dim3(grid), dim3(256), c * 16 * 4, st, img, w, (char*)out, n, Hs, Ws, c,
@@ -485,6 +654,22 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
 
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws, int c,
                 int ldx, int coffx, int relu_in, float scale, float img_scale) {
+  if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 32 == 0 && ldx % 8 == 0 && coffx % 8 == 0) {
+    const int64_t ntiles = (int64_t)n * Hs * Ws / 32;
+    int tpw = (int)((ntiles + 4095) / 4096);          // ~4096 waves
+    if (tpw < 1) tpw = 1;
+    const int64_t nwaves = (ntiles + tpw - 1) / tpw;
+    const int grid = (int)((nwaves + 3) / 4);
+    const size_t lds = (size_t)4 * 32 * (c * 2 + 32);
+    if (c == 64)
+      hipLaunchKernelGGL(c1_wgrad_mfma_kernel<4>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
+                         scale, img_scale, tpw);
+    else
+      hipLaunchKernelGGL(c1_wgrad_mfma_kernel<8>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
+                         scale, img_scale, tpw);
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   const int epc = dtype == GI_F16 ? 8 : 4;
   const int lpp = c / epc;
   GI_REQUIRE(c % epc == 0 && gi_is_pow2(lpp) && lpp <= 64, "c1_wgrad: c=%d unsupported", c);

@@ -48,12 +48,13 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int PHASE>
+template <int PHASE, int BN>   // BN = 128, or 64 for the layers with 64 output channels
 __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
-  constexpr int BM = 256, BN = 128, BK = 64;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 KiB
-  constexpr int AJ = 4, BJ = 2;          // 8-row blocks per wave per tile
-  constexpr int MT = 4, NT = 4;
+  constexpr int BM = 256, BK = 64;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 / 40 KiB
+  constexpr int AJ = 4, BJ = BN / 64;    // 8-row blocks per wave per tile
+  constexpr int WN = BN / 2;             // columns per wave
+  constexpr int MT = 4, NT = WN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -147,8 +148,8 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   const int lr = lane & 15, lq = lane >> 4;
   const int rdA0 = (wm * 64 + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
   const int rdA1 = (wm * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
-  const int rdB0 = A_BYTES + (wn * 64 + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
-  const int rdB1 = A_BYTES + (wn * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+  const int rdB0 = A_BYTES + (wn * WN + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdB1 = A_BYTES + (wn * WN + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
   const int relu_in = p.relu_in;
 
   auto compute = [&](auto STG) {
@@ -184,8 +185,12 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   issue(S0{});
   if (nk > 1) issue(S1{});
   auto step = [&](int t, auto CUR, auto NXT2) {
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < nk) {
+      if constexpr (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (t + 2 < nk) issue(NXT2);
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col = wn * 64 + nt * 16 + lr;
+    const int col = wn * WN + nt * 16 + lr;
     const float b = p.bias ? p.bias[n0 + col] : 0.f;
     float s = 0.f, q = 0.f;
 #pragma unroll
@@ -241,9 +246,10 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
     p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
     p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
   }
-  const int oc = tid & 15;       // 16 chunks of 8 halves per 128-column row
+  constexpr int CPRO = BN / 8;   // 16-byte chunks per output row
+  const int oc = tid % CPRO;
 #pragma unroll 1
-  for (int r = tid >> 4; r < BM; r += 32) {
+  for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
     const int m = m0 + r;
     if (m < p.M) {
       const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
@@ -258,10 +264,11 @@ char* g_zero_page[16] = {nullptr};
 
 // returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
 int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
-  if (a.cin % 64 != 0 || a.cout % 128 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
+  if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
+  const int BN = (a.cout % 128 == 0) ? 128 : 64;
   const int M = a.n * a.Hs * a.Ws;
   {   // too few tiles to fill 256 CUs: the split-K path of igemm.hip serves those layers
-    const int tiles = ((M + 255) / 256) * (a.cout / 128) * (phase_mode ? 4 : 1);
+    const int tiles = ((M + 255) / 256) * (a.cout / BN) * (phase_mode ? 4 : 1);
     if (tiles < 128) return GI_ERR_UNSUPPORTED;
   }
   int dev = 0;
@@ -284,18 +291,19 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
   GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
              "igemm3: tensor too large for 32-bit offsets");
   kp.mtiles = (M + 255) / 256;
-  kp.ntiles = a.cout / 128;
+  kp.ntiles = a.cout / BN;
   const int nyz = kp.ntiles * (phase_mode ? 4 : 1);
   const int grid = ((kp.mtiles + 7) / 8) * 8 * nyz;
-  constexpr int LDS = 3 * (256 + 128) * 128;
-  static bool attr_set[2] = {false, false};
-  if (phase_mode) {
-    if (!attr_set[1]) { GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set[1] = true; }
-    hipLaunchKernelGGL(igemm3_kernel<1>, dim3(grid), dim3(512), LDS, st, kp);
-  } else {
-    if (!attr_set[0]) { GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr_set[0] = true; }
-    hipLaunchKernelGGL(igemm3_kernel<0>, dim3(grid), dim3(512), LDS, st, kp);
-  }
+  const int LDS = 3 * (256 + BN) * 128;
+  static bool attr_set[4] = {false, false, false, false};
+  const void* fn[4] = {(const void*)igemm3_kernel<0, 128>, (const void*)igemm3_kernel<1, 128>, (const void*)igemm3_kernel<0, 64>,
+                       (const void*)igemm3_kernel<1, 64>};
+  const int vi = (BN == 64 ? 2 : 0) + (phase_mode ? 1 : 0);
+  if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128)); attr_set[vi] = true; }
+  if (vi == 0) hipLaunchKernelGGL((igemm3_kernel<0, 128>), dim3(grid), dim3(512), LDS, st, kp);
+  else if (vi == 1) hipLaunchKernelGGL((igemm3_kernel<1, 128>), dim3(grid), dim3(512), LDS, st, kp);
+  else if (vi == 2) hipLaunchKernelGGL((igemm3_kernel<0, 64>), dim3(grid), dim3(512), LDS, st, kp);
+  else hipLaunchKernelGGL((igemm3_kernel<1, 64>), dim3(grid), dim3(512), LDS, st, kp);
   GI_LAUNCH_CHECK();
   a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
   return GI_OK;
