@@ -142,6 +142,72 @@ __global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __res
   }
 }
 
+// ---- fp16 gather on the matrix cores ---------------------------------------------------------------
+// out[p][c] = act(sum_tap G[p][tap] * w[c][tap]) as D[c][pixel] = A[c][tap] * B[tap][pixel], K = 16 taps
+// zero-padded to 32 (v_mfma_f32_16x16x32_f16): the weights (A) live in registers, each wave gathers
+// the 16 taps of 16 consecutive pixels of one image row (lanes with k-chunk 0/1: two image rows x 4
+// columns each), and every lane ends with 4 consecutive channels of its pixel per 16-channel tile.
+template <int MTC>   // MTC = c / 16
+__global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
+                                                             char* out, int n, int Hs, int Ws, int ldout, int coffout,
+                                                             int act, float in_scale) {
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  h8_t af[MTC];   // A[row = channel mt*16 + lr][k = tap 8*kq + j], zero for kq >= 2
+#pragma unroll
+  for (int mt = 0; mt < MTC; ++mt) {
+    af[mt] = zero;
+    if (kq < 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[mt][j] = (half_t)w[(mt * 16 + lr) * 16 + kq * 8 + j];
+    }
+  }
+  const int H = 2 * Hs, W = 2 * Ws;
+  const int64_t ngroups = (int64_t)n * Hs * Ws / 16;     // Ws % 16 == 0: a group lies in one image row
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  auto load_b = [&](int64_t g, float (&bv)[8]) {
+    const int64_t p0 = g * 16;
+    const int x = (int)(p0 % Ws) + lr;
+    const int64_t rowi = p0 / Ws;
+    const int y = (int)(rowi % Hs);
+    const int nn = (int)(rowi / Hs);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
+    if (kq < 2) {
+      const float* ip = img + (int64_t)nn * H * W;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int iy = 2 * y - 1 + 2 * kq + (j >> 2), ix = 2 * x - 1 + (j & 3);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) bv[j] = ip[(int64_t)iy * W + ix];
+      }
+    }
+  };
+  float bv[8], bn[8];
+  int64_t g = wave;
+  if (g < ngroups) load_b(g, bv);
+  for (; g < ngroups; g += nwaves) {
+    if (g + nwaves < ngroups) load_b(g + nwaves, bn);
+    h8_t bf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bf[j] = (half_t)(bv[j] * in_scale);
+    const int64_t pix = g * 16 + lr;
+    char* dst = out + ((pix * ldout + coffout) << 1);
+#pragma unroll
+    for (int mt = 0; mt < MTC; ++mt) {
+      f4_t acc = {0.f, 0.f, 0.f, 0.f};
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf, acc, 0, 0, 0);
+      h4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)act_f(acc[r], act);
+      *(h4_t*)(dst + ((mt * 16 + kq * 4) << 1)) = o;    // D[row = channel][col = pixel]: rows 4*kq + r
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = bn[j];
+  }
+}
+
 // ---- fp16 transposed conv to one channel on the matrix cores -------------------------------------
 // col[p][tap] = sum_c relu?(X[p][c]) * w[c][tap]: D[tap][pixel] = A[tap][c] * B[c][pixel] with
 // v_mfma_f32_16x16x32_f16; B fragments are 16-byte row loads of X straight from global memory (each
@@ -376,7 +442,7 @@ __global__ void __launch_bounds__(256) c1_wgrad_kernel(const char* X, const floa
 template <int NT>   // NT = c / 16
 __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const float* __restrict__ img, float* dW,
                                                             int n, int Hs, int Ws, int ldx, int coffx, int relu_in,
-                                                            float scale, float img_scale, int tiles_per_wave) {
+                                                            float scale, float img_scale) {
   constexpr int C = NT * 16;
   constexpr int LROW = C * 2 + 32;                  // padded LDS row: conflict-free transposing reads
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -386,8 +452,7 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
   const int ky = tap >> 2, kx = tap & 3;
   const int H = 2 * Hs, W = 2 * Ws;
   const int64_t ntiles = (int64_t)n * Hs * Ws / 32;
-  const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t t0 = gw * tiles_per_wave, t1 = min(ntiles, t0 + tiles_per_wave);
+  const int64_t gw = (int64_t)blockIdx.x * 4 + wave, nw = (int64_t)gridDim.x * 4;
   constexpr int CPR = C * 2 / 16;                   // 16-byte chunks per X row
   constexpr int RPP = 64 / CPR;                     // rows per load pass
   constexpr int NP = 32 / RPP;
@@ -397,28 +462,36 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
   for (int i = 0; i < NT; ++i) acc[i] = f4_t{0.f, 0.f, 0.f, 0.f};
   const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const int g16 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
-  for (int64_t t = t0; t < t1; ++t) {
+
+  auto load_x = [&](int64_t t, u4_t (&xv)[NP]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) xv[i] = *(const u4_t*)(X + (((t * 32 + xr + RPP * i) * ldx + coffx) << 1) + xc * 16);
+  };
+  auto load_a = [&](int64_t t, float (&av)[8]) {   // 8 pixels x0 + 8*kq + j of the tile's image row, tap (ky,kx)
     const int64_t p0 = t * 32;
     const int x0 = (int)(p0 % Ws);
     const int64_t rowi = p0 / Ws;
     const int y = (int)(rowi % Hs);
     const int nn = (int)(rowi / Hs);
-    // X tile -> registers (issued first so the image gathers overlap its latency)
-    u4_t xv[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      xv[i] = *(const u4_t*)(X + (((p0 + xr + RPP * i) * ldx + coffx) << 1) + xc * 16);
-    // A fragment: pixels x0 + 8*kq + j of this row, tap (ky,kx)
     const int iy = 2 * y - 1 + ky;
-    h8_t af = zero;
-    if (iy >= 0 && iy < H) {
-      const float* ip = img + ((int64_t)nn * H + iy) * W;
+    const bool yok = iy >= 0 && iy < H;
+    const float* ip = img + ((int64_t)nn * H + (yok ? iy : 0)) * W;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ix = 2 * (x0 + 8 * kq + j) - 1 + kx;
-        af[j] = (ix >= 0 && ix < W) ? (half_t)(ip[ix] * img_scale) : (half_t)0.f;
-      }
+    for (int j = 0; j < 8; ++j) {
+      const int ix = 2 * (x0 + 8 * kq + j) - 1 + kx;
+      av[j] = (yok && ix >= 0 && ix < W) ? ip[ix] : 0.f;
     }
+  };
+  u4_t xv[NP], xn[NP];
+  float av[8], an[8];
+  int64_t t = gw;
+  if (t < ntiles) { load_x(t, xv); load_a(t, av); }
+  for (; t < ntiles; t += nw) {
+    const int64_t tn = t + nw;
+    if (tn < ntiles) { load_x(tn, xn); load_a(tn, an); }   // next tile in flight during this one
+    h8_t af;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[j] = (half_t)(av[j] * img_scale);
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       u4_t v = xv[i];
@@ -443,12 +516,22 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
       const h8_t bf = h8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
       acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[nt], 0, 0, 0);
     }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) xv[i] = xn[i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) av[j] = an[j];
   }
+  // block reduction (4 waves) through LDS, then one float atomic per (c, tap) per block.
   // D[row = tap][col = channel]: lane holds channel nt*16 + (lane&15), taps 4*(lane>>4) + r
+  __syncthreads();
+  float* red = (float*)smem;   // [4][C*16]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dW + (nt * 16 + (lane & 15)) * 16 + 4 * (lane >> 4) + r, acc[nt][r] * scale);
+    for (int r = 0; r < 4; ++r) red[wave * (C * 16) + (nt * 16 + (lane & 15)) * 16 + 4 * (lane >> 4) + r] = acc[nt][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 16; i += 256)
+    atomicAdd(dW + i, (red[i] + red[C * 16 + i] + red[2 * C * 16 + i] + red[3 * C * 16 + i]) * scale);
 }
 
 // ---- discriminator head ----------------------------------------------------------------------
@@ -597,6 +680,16 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
   GI_REQUIRE(c % 8 == 0 && c <= 1024, "c1_gather: c=%d", c);
   const int64_t total = (int64_t)n * Hs * Ws * (c / 8);
   const int groups = c / 8;
+  if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 4 == 0 && coffout % 4 == 0) {
+    const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
+    const int grid = grid_for(ngroups, 4, 256 * 8);
+    if (c == 64)
+      hipLaunchKernelGGL(c1_gather_mfma_kernel<4>, dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, act_out, in_scale);
+    else
+      hipLaunchKernelGGL(c1_gather_mfma_kernel<8>, dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, act_out, in_scale);
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   if (gi_is_pow2(groups) && groups <= 32 && Ws % (256 / groups) == 0) {
     const int S = 256 / groups;
     const int64_t nstrips = (int64_t)n * Hs * (Ws / S);
@@ -656,17 +749,16 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
                 int ldx, int coffx, int relu_in, float scale, float img_scale) {
   if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 32 == 0 && ldx % 8 == 0 && coffx % 8 == 0) {
     const int64_t ntiles = (int64_t)n * Hs * Ws / 32;
-    int tpw = (int)((ntiles + 4095) / 4096);          // ~4096 waves
-    if (tpw < 1) tpw = 1;
-    const int64_t nwaves = (ntiles + tpw - 1) / tpw;
-    const int grid = (int)((nwaves + 3) / 4);
-    const size_t lds = (size_t)4 * 32 * (c * 2 + 32);
+    int grid = (int)((ntiles + 3) / 4);
+    if (grid > 512) grid = 512;                        // 512 blocks x 1024 atomics on the same 1-2K addresses
+    size_t lds = (size_t)4 * 32 * (c * 2 + 32);
+    if (lds < (size_t)4 * c * 16 * 4) lds = (size_t)4 * c * 16 * 4;
     if (c == 64)
       hipLaunchKernelGGL(c1_wgrad_mfma_kernel<4>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
-                         scale, img_scale, tpw);
+                         scale, img_scale);
     else
       hipLaunchKernelGGL(c1_wgrad_mfma_kernel<8>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
-                         scale, img_scale, tpw);
+                         scale, img_scale);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
