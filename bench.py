@@ -110,7 +110,7 @@ def main():
     rank, world = parallel.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = parallel.local_device()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -94,6 +94,8 @@ struct IgemmArgs {
   int cin, ldin, coffin;
   int cout, ldout, coffout;
   int relu_in;         // relu applied to `in` while staging
+  int relu_cend;       // 0: all input channels; > 0: only channels [0, relu_cend) need the relu (hint; relu is
+                       // idempotent, kernels may apply it to more channels)
   int act_out;         // gi_act on the result
   int force_splitk;    // 0 = heuristic, >0 forces that split
   int ntiles_out;      // (returned) number of partial rows written

@@ -490,10 +490,13 @@ int run(hipStream_t st, IgemmArgs& a) {
 
 }  // namespace
 
-int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a);   // igemm3.hip
+int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a);   // igemm3.hip: 256xBN tiles, LDS-DMA ring
 
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a) {
-  if (dtype == GI_F16 && a.force_splitk == 0 && getenv("GI_NO_IGEMM3") == nullptr) {
+  // GI_IGEMM_VARIANT (tools / A-B timing only): 3 = LDS-DMA kernel (default), 1 = register-staged kernel only
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("GI_IGEMM_VARIANT"); variant = e ? atoi(e) : 3; }
+  if (dtype == GI_F16 && a.force_splitk == 0 && variant >= 3) {
     const int rc = op_igemm3(st, phase_mode, a);
     if (rc != GI_ERR_UNSUPPORTED) return rc;
   }

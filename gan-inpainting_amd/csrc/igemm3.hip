@@ -9,6 +9,8 @@
 // decoder's ReLU is applied to the A fragments after the LDS read (integer pk_max).
 // Block order is XCD-aware: the (N tile, phase) blocks that share an M tile run back to back on one
 // XCD so the gathered input rows are served by that XCD's L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -25,8 +27,10 @@ struct KP3 {
   int cout, ldout, coffout;
   int Ktot, nk;
   int relu_in, act_out;
+  int relu_cend;      // ReLU is applied to input channels [0, relu_cend) only (the skip half of a concat buffer)
   int Hin, Win, Hout, Wout;
   int mtiles, ntiles;
+  int dbg;            // timing-only ablations (GI_IGEMM3_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads
 };
 
 __device__ __forceinline__ float act3(float v, int act) {
@@ -48,18 +52,23 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int PHASE, int BN>   // BN = 128, or 64 for the layers with 64 output channels
-__global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
+// BN = 128, or 64 for the layers with 64 output channels. NW = waves per workgroup: 8 (4x2, two per
+// SIMD) or 4 (4x1, ONE per SIMD, each wave owns 64 rows x BN columns so that every A fragment feeds
+// BN/16 MFMAs and the per-K-tile bookkeeping is issued once per SIMD instead of twice).
+template <int PHASE, int BN, int NW, int DBG = 0>   // DBG: compile-time timing ablations (tools only)
+__global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   constexpr int BM = 256, BK = 64;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 / 40 KiB
-  constexpr int AJ = 4, BJ = BN / 64;    // 8-row blocks per wave per tile
-  constexpr int WN = BN / 2;             // columns per wave
+  constexpr int AJ = 32 / NW, BJ = (BN / 8) / NW;    // 8-row blocks per wave per tile
+  constexpr int WNW = NW / 4;            // waves along N
+  constexpr int WN = BN / WNW;           // columns per wave
   constexpr int MT = 4, NT = WN / 16;
+  constexpr int NTHREADS = NW * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
 
   // ---- XCD-aware tile order ------------------------------------------------------------------
   const int nyz = p.ntiles * (PHASE ? 4 : 1);
@@ -129,11 +138,13 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
     char* sA = smem + stage * STAGE + wave * (AJ * 1024);
     char* sB = smem + stage * STAGE + A_BYTES + wave * (BJ * 1024);
     const int koff = c0 * 2;
+    if constexpr (!(DBG & 1)) {
 #pragma unroll
     for (int j = 0; j < AJ; ++j) glds16(pa[j] + koff, sA + j * 1024);
     const int64_t kb = (int64_t)kt_issue * (BK * 2);
 #pragma unroll
     for (int j = 0; j < BJ; ++j) glds16(pb[j] + kb, sB + j * 1024);
+    }
     ++kt_issue;
     c0 += BK;
     if (c0 >= p.cin) { c0 = 0; ++tap; set_tap(); }
@@ -150,29 +161,47 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   const int rdA1 = (wm * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
   const int rdB0 = A_BYTES + (wn * WN + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
   const int rdB1 = A_BYTES + (wn * WN + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
-  const int relu_in = p.relu_in;
+  const int relu_cend = p.relu_in ? p.relu_cend : 0;
+  int cc0 = 0;   // channel offset of the tile being computed
 
   auto compute = [&](auto STG) {
+    const bool relu_in = cc0 < relu_cend;   // wave-uniform
     constexpr int stage = decltype(STG)::value;
     const char* s = smem + stage * STAGE;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
       h8_t af[MT], bf[NT];
       const int oa = k2 ? rdA1 : rdA0, ob = k2 ? rdB1 : rdB0;
+      if constexpr ((DBG & 4) != 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { af[mt] = h8_t{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(af[mt])); }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { bf[nt] = h8_t{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(bf[nt])); }
+      } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(s + oa + mt * 2048);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(s + ob + nt * 2048);
+      }
       if (relu_in) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = relu_h8(af[mt]);
       }
+      if constexpr ((DBG & 2) != 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(af[mt]));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" :: "v"(bf[nt]));
+      } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+      }
     }
+    cc0 += BK;
+    if (cc0 >= p.cin) cc0 = 0;
   };
 
   // ---- 3-stage ring. Per tile each wave issues AJ+BJ = 6 LDS-DMA instructions; before computing tile
@@ -187,7 +216,9 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   auto step = [&](int t, auto CUR, auto NXT2) {
     if (t + 1 < nk) {
       if constexpr (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if constexpr (AJ + BJ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if constexpr (AJ + BJ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else { static_assert(AJ + BJ == 10, "unexpected DMA count"); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -196,7 +227,7 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
     if (t + 2 < nk) issue(NXT2);
     compute(CUR);
   };
-  for (int t = 0; t < nk; t += 3) {
+  for (int t = 0; t < ((DBG & 16) ? 0 : nk); t += 3) {
     step(t, S0{}, S2{});
     if (t + 1 < nk) step(t + 1, S1{}, S0{});
     if (t + 2 < nk) step(t + 2, S2{}, S1{});
@@ -218,27 +249,39 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col = wn * WN + nt * 16 + lr;
-    const float b = p.bias ? p.bias[n0 + col] : 0.f;
-    float s = 0.f, q = 0.f;
+    const int ch = wn * WN + nt * 16 + 4 * lq;           // this lane's 4 consecutive channels
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h4_t o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc[mt][nt][r] + b;
-        s += v;
-        q += v * v;
-        v = act3(v, p.act_out);
-        stg[(wm * 64 + mt * 16 + lq * 4 + r) * SLD + col] = (half_t)v;
+        float v = acc[mt][nt][r] + bs[r];
+        s[r] += v;
+        q[r] += v * v;
+        o[r] = (half_t)act3(v, p.act_out);
       }
-    if (p.partials) {
-      s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-      s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-      if (lane < 16) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
+    }
+    if (p.partials) {   // sum over the 16 pixels held by lanes with equal lq (xor 1,2,4,8)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+      }
     }
   }
   __syncthreads();
-  if (p.partials && tid < BN) {
+  if (p.partials && tid < BN) {   // (NTHREADS >= 256 >= BN)
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
@@ -249,9 +292,9 @@ __global__ void __launch_bounds__(512, 2) igemm3_kernel(KP3 p) {
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row
   const int oc = tid % CPRO;
 #pragma unroll 1
-  for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
+  for (int r = tid / CPRO; r < BM; r += NTHREADS / CPRO) {
     const int m = m0 + r;
-    if (m < p.M) {
+    if (m < p.M && !(DBG & 8)) {
       const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
       *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
     }
@@ -286,6 +329,8 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
   kp.Ktot = (phase_mode ? 4 : 16) * a.cin;
   kp.nk = kp.Ktot / 64;
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
+  kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
+  { const char* e = getenv("GI_IGEMM3_DBG"); kp.dbg = e ? atoi(e) : 0; }
   if (phase_mode) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
   else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
   GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
@@ -295,15 +340,47 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
   const int nyz = kp.ntiles * (phase_mode ? 4 : 1);
   const int grid = ((kp.mtiles + 7) / 8) * 8 * nyz;
   const int LDS = 3 * (256 + BN) * 128;
-  static bool attr_set[4] = {false, false, false, false};
-  const void* fn[4] = {(const void*)igemm3_kernel<0, 128>, (const void*)igemm3_kernel<1, 128>, (const void*)igemm3_kernel<0, 64>,
-                       (const void*)igemm3_kernel<1, 64>};
-  const int vi = (BN == 64 ? 2 : 0) + (phase_mode ? 1 : 0);
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  const void* fn[8] = {(const void*)igemm3_kernel<0, 128, 8>, (const void*)igemm3_kernel<1, 128, 8>, (const void*)igemm3_kernel<0, 64, 8>,
+                       (const void*)igemm3_kernel<1, 64, 8>, (const void*)igemm3_kernel<0, 128, 4>, (const void*)igemm3_kernel<1, 128, 4>,
+                       (const void*)igemm3_kernel<0, 64, 4>, (const void*)igemm3_kernel<1, 64, 4>};
+  static int nw_env = -1;
+  if (nw_env < 0) { const char* e = getenv("GI_IGEMM3_WAVES"); nw_env = e ? atoi(e) : 8; }
+  const int NWv = nw_env == 8 ? 8 : 4;
+  const int vi = (NWv == 4 ? 4 : 0) + (BN == 64 ? 2 : 0) + (phase_mode ? 1 : 0);
   if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128)); attr_set[vi] = true; }
-  if (vi == 0) hipLaunchKernelGGL((igemm3_kernel<0, 128>), dim3(grid), dim3(512), LDS, st, kp);
-  else if (vi == 1) hipLaunchKernelGGL((igemm3_kernel<1, 128>), dim3(grid), dim3(512), LDS, st, kp);
-  else if (vi == 2) hipLaunchKernelGGL((igemm3_kernel<0, 64>), dim3(grid), dim3(512), LDS, st, kp);
-  else hipLaunchKernelGGL((igemm3_kernel<1, 64>), dim3(grid), dim3(512), LDS, st, kp);
+  const dim3 g(grid), b(NWv * 64);
+  if (kp.dbg && vi == 1) {   // timing-only ablation builds of the PHASE / 128 / 8-wave kernel (GI_IGEMM3_DBG)
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 31>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+    switch (kp.dbg) {
+      case 1: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 1>), g, b, LDS, st, kp); break;
+      case 2: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 2>), g, b, LDS, st, kp); break;
+      case 4: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 4>), g, b, LDS, st, kp); break;
+      case 7: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 7>), g, b, LDS, st, kp); break;
+      case 8: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 8>), g, b, LDS, st, kp); break;
+      case 15: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 15>), g, b, LDS, st, kp); break;
+      default: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 31>), g, b, LDS, st, kp); break;
+    }
+    GI_LAUNCH_CHECK();
+    a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
+    return GI_OK;
+  }
+  switch (vi) {
+    case 0: hipLaunchKernelGGL((igemm3_kernel<0, 128, 8>), g, b, LDS, st, kp); break;
+    case 1: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8>), g, b, LDS, st, kp); break;
+    case 2: hipLaunchKernelGGL((igemm3_kernel<0, 64, 8>), g, b, LDS, st, kp); break;
+    case 3: hipLaunchKernelGGL((igemm3_kernel<1, 64, 8>), g, b, LDS, st, kp); break;
+    case 4: hipLaunchKernelGGL((igemm3_kernel<0, 128, 4>), g, b, LDS, st, kp); break;
+    case 5: hipLaunchKernelGGL((igemm3_kernel<1, 128, 4>), g, b, LDS, st, kp); break;
+    case 6: hipLaunchKernelGGL((igemm3_kernel<0, 64, 4>), g, b, LDS, st, kp); break;
+    default: hipLaunchKernelGGL((igemm3_kernel<1, 64, 4>), g, b, LDS, st, kp); break;
+  }
   GI_LAUNCH_CHECK();
   a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
   return GI_OK;

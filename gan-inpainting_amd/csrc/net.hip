@@ -429,9 +429,10 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
 }
 
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
-          int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles) {
+          int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
+  a.relu_cend = relu_cend;
   a.in = in; a.w = w; a.out = out; a.bias = nullptr;
   a.partials = stats ? (float*)net->shared(net->oPart) : nullptr;
   a.ws = net->split_bytes > 0 ? (float*)net->shared(net->oSplit) : nullptr;
@@ -520,7 +521,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     void* U = net->slot(s, net->oU[k]);
     int nt = 0;
     GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
-                 GI_ACT_NONE, true, &nt));
+                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0));
     const uint8_t* drop = nullptr;
     if (train && net->dropout_p > 0.f && k >= 5 && k <= nd - 1) {
       uint8_t* m = (uint8_t*)net->slot(s, net->oMask[k]);
@@ -531,7 +532,9 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
       }
       drop = m;
     }
-    GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_NONE, drop,
+    // the decoder half is only ever consumed through the parent's in-place ReLU (networks.py:289): store
+    // relu(u) so that consumers need the ReLU on the skip half only; [u > 0] masks are unchanged
+    GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_RELU, drop,
                       drop ? 1.f / (1.f - net->dropout_p) : 1.f, train));
   }
   float* osave = (float*)net->slot(s, net->oOut);

@@ -73,6 +73,13 @@ class GradSync:
         return 1.0 / self.world
 
 
+def local_device():
+    """CUDA device index of this rank: LOCAL_RANK, folded onto the visible devices."""
+    import os
+    n = max(torch.cuda.device_count(), 1)
+    return int(os.environ.get("LOCAL_RANK", "0")) % n
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
     import os
@@ -84,8 +91,9 @@ def init_from_env(backend=None):
         return 0, 1
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-    if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    # GI_DIST_BACKEND=gloo rehearses the multi-rank path with several ranks on ONE GPU (tests, 1-GPU boxes)
+    backend = backend or os.environ.get("GI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_device())
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world

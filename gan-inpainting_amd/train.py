@@ -68,7 +68,7 @@ def main(argv=None):
     from gan_inpainting_amd import parallel
     rank, world = parallel.init_from_env()
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(parallel.local_device())
     if args.data != "synthetic":
         raise NotImplementedError("only --data synthetic is wired in round 1 (the input pipeline is SURVEY.md 8f rank 4)")
     mk = lambda n, seed: torch.utils.data.DataLoader(   # noqa: E731
