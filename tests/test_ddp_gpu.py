@@ -65,7 +65,8 @@ def _worker(rank, world, port, q):
         G.impose_dropout_masks(_masks(it))
         step(g, m, it == 1)
     torch.cuda.synchronize()
-    q.put((rank, G.flat_params().cpu(), D.flat_params().cpu()))
+    # numpy arrays travel by value (torch tensors would be passed as file descriptors of a process that exits)
+    q.put((rank, G.flat_params().cpu().numpy(), D.flat_params().cpu().numpy()))
     torch.distributed.destroy_process_group()
 
 
@@ -77,7 +78,7 @@ def test_two_ranks_stay_identical_and_match_accumulated_gradients():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict((r, (g, d)) for r, g, d in [q.get(timeout=300) for _ in procs])
+    res = dict((r, (torch.from_numpy(g), torch.from_numpy(d))) for r, g, d in [q.get(timeout=300) for _ in procs])
     for p in procs:
         p.join(timeout=60)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "replicas diverged"
