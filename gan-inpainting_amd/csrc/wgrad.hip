@@ -24,7 +24,7 @@ struct WP {
   int cb, lgcb, ldL, coffL;
   int relu_S;
   float scale;
-  int tiles_per_split;   // K tiles (32 pixels) per split
+  int tiles_per_split;   // K tiles (BKP pixels) per split
 };
 
 template <typename T>
@@ -47,7 +47,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
   constexpr bool F16 = std::is_same<T, half_t>::value;
   constexpr int EPC = 16 / (int)sizeof(T);
-  constexpr int BKP = 32;                       // pixels per K tile
+  constexpr int BKP = F16 ? 64 : 32;            // pixels per K tile (fp16: 2 MFMA k-steps per barrier)
   constexpr int ROWB = 128 * (int)sizeof(T);    // bytes per tile row (128 channels)
   constexpr int LROW = F16 ? ROWB + 32 : ROWB;  // padded LDS row (fp16: +32 B -> conflict-free tr reads)
   constexpr int CPR = ROWB / 16;                // 16-byte chunks per row
@@ -125,12 +125,16 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
       // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(channel) block; lane 4q+p supplies the
       // address of block row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
       const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+      for (int ks = 0; ks < BKP / 32; ++ks) {
+      const char* sSk = sS + ks * 32 * LROW;
+      const char* sLk = sL + ks * 32 * LROW;
       h8_t af[MT], bf[NT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int ch = wm * 64 + mt * 16 + 4 * pp;
-        const char* a_lo = sS + (8 * g + q) * LROW + ch * 2;
-        const char* a_hi = sS + (8 * g + 4 + q) * LROW + ch * 2;
+        const char* a_lo = sSk + (8 * g + q) * LROW + ch * 2;
+        const char* a_hi = sSk + (8 * g + 4 + q) * LROW + ch * 2;
         fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)a_lo);
         fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)a_hi);
         h4_t l4 = __builtin_bit_cast(h4_t, lo), h4 = __builtin_bit_cast(h4_t, hi);
@@ -139,8 +143,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int ch = wn * 64 + nt * 16 + 4 * pp;
-        const char* b_lo = sL + (8 * g + q) * LROW + ch * 2;
-        const char* b_hi = sL + (8 * g + 4 + q) * LROW + ch * 2;
+        const char* b_lo = sLk + (8 * g + q) * LROW + ch * 2;
+        const char* b_hi = sLk + (8 * g + 4 + q) * LROW + ch * 2;
         fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)b_lo);
         fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)b_hi);
         h4_t l4 = __builtin_bit_cast(h4_t, lo), h4 = __builtin_bit_cast(h4_t, hi);
@@ -151,6 +155,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+      }
     } else {
       const float* fS = (const float*)sS;
       const float* fL = (const float*)sL;
@@ -225,15 +230,21 @@ int run(hipStream_t st, const WgradArgs& a) {
   GI_REQUIRE((int64_t)p.P * a.ldS < (1ll << 31) && (int64_t)a.n * p.HL * p.WL * a.ldL < (1ll << 31),
              "wgrad: tensor too large for 32-bit pixel math");
   const int tiles = (a.ca / 128) * (16 * a.cb / 128);
-  const int ktiles = (p.P + 31) / 32;
+  constexpr int BKP = F16 ? 64 : 32;
+  const int ktiles = (p.P + BKP - 1) / BKP;
   int split = (1024 + tiles - 1) / tiles;
   if (split > ktiles / 8) split = ktiles / 8;
   if (split < 1) split = 1;
   p.tiles_per_split = (ktiles + split - 1) / split;
   split = (ktiles + p.tiles_per_split - 1) / p.tiles_per_split;
   constexpr int LROW = F16 ? 256 + 32 : 512;
-  constexpr int LDS = 2 * 2 * 32 * LROW;
+  constexpr int LDS = 2 * 2 * BKP * LROW;
   dim3 grid(a.ca / 128, 16 * a.cb / 128, split);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GI_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr_set = true;
+  }
   hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), LDS, st, p);
   GI_LAUNCH_CHECK();
   return GI_OK;

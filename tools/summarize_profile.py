@@ -26,7 +26,7 @@ def stats(path, title, out):
 
 
 def pmc(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if "igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rows = [r for r in csv.DictReader(open(path)) if "igemm3_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
     vals = [float(r["Counter_Value"]) for r in rows]
     return sum(vals) / len(vals), len(vals)
 
@@ -40,7 +40,7 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
     stats(glob.glob(f"{src}/bench/runc/*_kernel_stats.csv")[0], "B. `python bench.py --steps 10 --warmup 5 --no-cpu-baseline` — whole benchmark process", out)
     fetch, nf = pmc(glob.glob(f"{src}/pmc_fetch/runc/*_counter_collection.csv")[0], "FETCH_SIZE")
     write, nw = pmc(glob.glob(f"{src}/pmc_write/runc/*_counter_collection.csv")[0], "WRITE_SIZE")
-    dom = [r for r in ko if "igemm_kernel" in r["Name"]][0]
+    dom = [r for r in ko if "igemm3_kernel" in r["Name"]][0]
     avg_ms = float(dom["AverageNs"]) / 1e6
     flop = 2.0 * 4 * 32768 * 128 * 2048
     traffic = (2 * fetch + write) * 1024
