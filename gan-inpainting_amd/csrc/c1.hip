@@ -634,7 +634,7 @@ __global__ void __launch_bounds__(256) head_dgrad_kernel(const float* dh, const 
   }
 }
 
-// dw5[tap][c] += sum_{n,p} dh[n,p] * a4[n,p+tap][c]   (grid.y = n)
+// dw5[tap][c] += sum_{n,p} dh[n,p] * a4[n,p+tap][c]   (grid.y = n, grid.z = output row py)
 template <typename T>
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const char* a4, float* dw5, int Hh, int Wh,
                                                          int c) {
@@ -644,24 +644,24 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const 
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 16 * cpt) return;
   const int tap = idx / cpt, cc = idx % cpt;
-  const int nn = blockIdx.y;
+  const int nn = blockIdx.y, py = blockIdx.z;
   float s[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) s[e] = 0.f;
-  for (int py = 0; py < Ph; ++py)
-    for (int px = 0; px < Pw; ++px) {
-      const float g = dh[((int64_t)nn * Ph + py) * Pw + px];
-      const char* src = a4 + ((((int64_t)nn * Hh + py + (tap >> 2)) * Wh + px + (tap & 3)) * c + cc * EPC) * (int64_t)sizeof(T);
-      if constexpr (std::is_same<T, half_t>::value) {
-        const h8_t v = *(const h8_t*)src;
+  (void)Ph;
+  for (int px = 0; px < Pw; ++px) {
+    const float g = dh[((int64_t)nn * Ph + py) * Pw + px];
+    const char* src = a4 + ((((int64_t)nn * Hh + py + (tap >> 2)) * Wh + px + (tap & 3)) * c + cc * EPC) * (int64_t)sizeof(T);
+    if constexpr (std::is_same<T, half_t>::value) {
+      const h8_t v = *(const h8_t*)src;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, (float)v[e], s[e]);
-      } else {
-        const f4_t v = *(const f4_t*)src;
+      for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, (float)v[e], s[e]);
+    } else {
+      const f4_t v = *(const f4_t*)src;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, v[e], s[e]);
-      }
+      for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, v[e], s[e]);
     }
+  }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) atomicAdd(dw5 + tap * c + cc * EPC + e, s[e]);
 }
@@ -810,7 +810,7 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
     hipLaunchKernelGGL(head_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, a.dh, a.w5, (char*)a.da4, a.n, a.Hh, a.Wh, a.c, a.loss_scale);
   GI_LAUNCH_CHECK();
   if (a.dw5) {
-    dim3 g((16 * (a.c / epc) + 255) / 256, a.n);
+    dim3 g((16 * (a.c / epc) + 255) / 256, a.n, Ph);
     if (dtype == GI_F16)
       hipLaunchKernelGGL(head_wgrad_kernel<half_t>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
     else

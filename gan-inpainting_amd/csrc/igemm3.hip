@@ -58,7 +58,8 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
 template <int PHASE, int BN, int NW, int DBG = 0>   // DBG: compile-time timing ablations (tools only)
 __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   constexpr int BM = 256, BK = 64;
-  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 48 / 40 KiB
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 64 / 48 / 40 KiB
+  constexpr int NSTG = BN == 256 ? 2 : 3;   // 256x256 tiles: two 64 KiB stages (half the loaded bytes per FLOP)
   constexpr int AJ = 32 / NW, BJ = (BN / 8) / NW;    // 8-row blocks per wave per tile
   constexpr int WNW = NW / 4;            // waves along N
   constexpr int WN = BN / WNW;           // columns per wave
@@ -211,26 +212,42 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   const int nk = p.nk;
-  issue(S0{});
-  if (nk > 1) issue(S1{});
-  auto step = [&](int t, auto CUR, auto NXT2) {
-    if (t + 1 < nk) {
-      if constexpr (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if constexpr (AJ + BJ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else if constexpr (AJ + BJ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-      else { static_assert(AJ + BJ == 10, "unexpected DMA count"); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (NSTG == 3) {
+    issue(S0{});
+    if (nk > 1) issue(S1{});
+    auto step = [&](int t, auto CUR, auto NXT2) {
+      if (t + 1 < nk) {
+        if constexpr (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (AJ + BJ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if constexpr (AJ + BJ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else { static_assert(AJ + BJ == 10 || NSTG != 3, "unexpected DMA count"); asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 2 < nk) issue(NXT2);
+      compute(CUR);
+    };
+    for (int t = 0; t < ((DBG & 16) ? 0 : nk); t += 3) {
+      step(t, S0{}, S2{});
+      if (t + 1 < nk) step(t + 1, S1{}, S0{});
+      if (t + 2 < nk) step(t + 2, S2{}, S1{});
     }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (t + 2 < nk) issue(NXT2);
-    compute(CUR);
-  };
-  for (int t = 0; t < ((DBG & 16) ? 0 : nk); t += 3) {
-    step(t, S0{}, S2{});
-    if (t + 1 < nk) step(t + 1, S1{}, S0{});
-    if (t + 2 < nk) step(t + 2, S2{}, S1{});
+  } else {
+    // two stages: tile t+1 streams in while tile t is multiplied
+    issue(S0{});
+    auto step2 = [&](int t, auto CUR, auto NXT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + 1 < nk) issue(NXT);
+      compute(CUR);
+    };
+    for (int t = 0; t < nk; t += 2) {
+      step2(t, S0{}, S1{});
+      if (t + 1 < nk) step2(t + 1, S1{}, S0{});
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -308,8 +325,11 @@ char* g_zero_page[16] = {nullptr};
 // returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
 int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
-  const int BN = (a.cout % 128 == 0) ? 128 : 64;
   const int M = a.n * a.Hs * a.Ws;
+  static int bn256 = -1;
+  if (bn256 < 0) { const char* e = getenv("GI_IGEMM3_BN256"); bn256 = e ? atoi(e) : 0; }   // measured equal to BN=128: off
+  int BN = (a.cout % 128 == 0) ? 128 : 64;
+  if (bn256 && a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) * (phase_mode ? 4 : 1) >= 256) BN = 256;
   {   // too few tiles to fill 256 CUs: the split-K path of igemm.hip serves those layers
     const int tiles = ((M + 255) / 256) * (a.cout / BN) * (phase_mode ? 4 : 1);
     if (tiles < 128) return GI_ERR_UNSUPPORTED;
@@ -339,7 +359,8 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
   kp.ntiles = a.cout / BN;
   const int nyz = kp.ntiles * (phase_mode ? 4 : 1);
   const int grid = ((kp.mtiles + 7) / 8) * 8 * nyz;
-  const int LDS = 3 * (256 + BN) * 128;
+  const int LDS = (BN == 256 ? 2 : 3) * (256 + BN) * 128 > 256 * (BN + 8) * 2 + 4 * BN * 8 ? (BN == 256 ? 2 : 3) * (256 + BN) * 128
+                                                                                            : 256 * (BN + 8) * 2 + 4 * BN * 8;
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   const void* fn[8] = {(const void*)igemm3_kernel<0, 128, 8>, (const void*)igemm3_kernel<1, 128, 8>, (const void*)igemm3_kernel<0, 64, 8>,
                        (const void*)igemm3_kernel<1, 64, 8>, (const void*)igemm3_kernel<0, 128, 4>, (const void*)igemm3_kernel<1, 128, 4>,
@@ -367,6 +388,19 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
       case 15: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 15>), g, b, LDS, st, kp); break;
       default: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 31>), g, b, LDS, st, kp); break;
     }
+    GI_LAUNCH_CHECK();
+    a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
+    return GI_OK;
+  }
+  if (BN == 256) {
+    static bool a256[2] = {false, false};
+    if (!a256[phase_mode ? 1 : 0]) {
+      GI_HIP(hipFuncSetAttribute(phase_mode ? (const void*)igemm3_kernel<1, 256, 8> : (const void*)igemm3_kernel<0, 256, 8>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128));
+      a256[phase_mode ? 1 : 0] = true;
+    }
+    if (phase_mode) hipLaunchKernelGGL((igemm3_kernel<1, 256, 8>), g, dim3(512), LDS, st, kp);
+    else hipLaunchKernelGGL((igemm3_kernel<0, 256, 8>), g, dim3(512), LDS, st, kp);
     GI_LAUNCH_CHECK();
     a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
     return GI_OK;

@@ -69,6 +69,9 @@ class _StepBase:
         self._shape = None
         for n in [net_G] + self.Ds:
             n.train()
+            # inside a step object parameters only change through the package's optimizers / clamp, which
+            # mark the network dirty: re-derive packed weights once per update instead of once per forward
+            n.always_sync = False
 
     def _bind_optimizers(self, *opts):
         if self.sync is not None:

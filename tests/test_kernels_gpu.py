@@ -29,6 +29,7 @@ CONV_CASES = [
     (8, 128, 128, 64, 128, False),   # >= 128 tiles: the 256x128 LDS-DMA kernel (igemm3.hip) in fp16
     (7, 72, 72, 64, 512, False),     # igemm3 with a ragged last M tile (M = 9072) and non-power-of-two maps
     (8, 128, 128, 128, 64, False),   # igemm3, 64-column variant
+    (8, 128, 128, 64, 512, False),   # igemm3, 256x256 two-stage variant (>= 256 such tiles)
 ]
 
 
@@ -81,6 +82,7 @@ CONVT_CASES = [
     (8, 32, 32, 256, 128, False),   # igemm3 (fp16): 32 M tiles x 4 phases
     (3, 40, 40, 128, 256, False),   # igemm3, ragged M (4800), two N tiles
     (8, 32, 32, 128, 64, False),    # igemm3, 64-column variant (the generator's u2 shape family)
+    (16, 32, 32, 128, 256, False),  # igemm3, 256x256 two-stage variant
 ]
 
 
