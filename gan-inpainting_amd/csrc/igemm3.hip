@@ -134,21 +134,23 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   set_tap();
 
   int kt_issue = 0;
-  auto issue = [&](auto STG) {
+  // one LDS-DMA piece (1 KiB) of the tile being issued: pieces 0..AJ-1 = A blocks, AJ..AJ+BJ-1 = B blocks
+  auto issue_piece = [&](auto STG, auto PIECE) {
     constexpr int stage = decltype(STG)::value;
-    char* sA = smem + stage * STAGE + wave * (AJ * 1024);
-    char* sB = smem + stage * STAGE + A_BYTES + wave * (BJ * 1024);
-    const int koff = c0 * 2;
+    constexpr int j = decltype(PIECE)::value;
     if constexpr (!(DBG & 1)) {
-#pragma unroll
-    for (int j = 0; j < AJ; ++j) glds16(pa[j] + koff, sA + j * 1024);
-    const int64_t kb = (int64_t)kt_issue * (BK * 2);
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) glds16(pb[j] + kb, sB + j * 1024);
+      if constexpr (j < AJ) glds16(pa[j] + c0 * 2, smem + stage * STAGE + wave * (AJ * 1024) + j * 1024);
+      else glds16(pb[j - AJ] + (int64_t)kt_issue * (BK * 2), smem + stage * STAGE + A_BYTES + wave * (BJ * 1024) + (j - AJ) * 1024);
     }
+  };
+  auto issue_done = [&]() {
     ++kt_issue;
     c0 += BK;
     if (c0 >= p.cin) { c0 = 0; ++tap; set_tap(); }
+  };
+  auto issue = [&](auto STG) {
+    static_for<AJ + BJ>([&](auto J) { issue_piece(STG, J); });
+    issue_done();
   };
 
   f4_t acc[MT][NT];
@@ -165,9 +167,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   const int relu_cend = p.relu_in ? p.relu_cend : 0;
   int cc0 = 0;   // channel offset of the tile being computed
 
-  auto compute = [&](auto STG) {
-    const bool relu_in = cc0 < relu_cend;   // wave-uniform
+  // compute tile from stage CUR; when ISS is set, the AJ+BJ LDS-DMA pieces of the tile two ahead are
+  // issued one at a time BETWEEN the MFMAs (one piece per NMF/(AJ+BJ) MFMAs): a piece occupies the CU's
+  // TA/L1 path for >= 16 cycles (1 KiB at 64 B/clk), and a burst of 8 waves x 6 pieces leaves the matrix
+  // pipe idle for ~800 cycles per K tile and the TA idle during the MFMA phase (ablation in DESIGN.md).
+  auto compute = [&](auto STG, auto NXT, auto ISS) {
     constexpr int stage = decltype(STG)::value;
+    constexpr bool iss = decltype(ISS)::value;
+    constexpr int NMF = 2 * MT * NT, NPC = AJ + BJ;
+    const bool relu_in = cc0 < relu_cend;   // wave-uniform
     const char* s = smem + stage * STAGE;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
@@ -180,27 +188,35 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
         for (int nt = 0; nt < NT; ++nt) { bf[nt] = h8_t{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(bf[nt])); }
       } else {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(s + oa + mt * 2048);
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(s + oa + mt * 2048);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(s + ob + nt * 2048);
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(s + ob + nt * 2048);
       }
       if (relu_in) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) af[mt] = relu_h8(af[mt]);
       }
-      if constexpr ((DBG & 2) != 0) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) asm volatile("" :: "v"(af[mt]));
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) asm volatile("" :: "v"(bf[nt]));
-      } else {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
-      }
+        for (int nt = 0; nt < NT; ++nt) {
+          const int idx = k2 * MT * NT + mt * NT + nt;
+          if constexpr ((DBG & 2) != 0) {
+            asm volatile("" :: "v"(af[mt]));
+            asm volatile("" :: "v"(bf[nt]));
+          } else {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+          }
+          if constexpr (iss) {
+            // piece q goes after MFMA number ((q+1)*NMF)/(NPC+1) - 1  (idx is a constant after unrolling)
+            static_for<NPC>([&](auto Q) {
+              constexpr int q = decltype(Q)::value;
+              if (idx == ((q + 1) * NMF) / (NPC + 1) - 1) issue_piece(NXT, Q);
+            });
+          }
+        }
     }
+    if constexpr (iss) issue_done();
     cc0 += BK;
     if (cc0 >= p.cin) cc0 = 0;
   };
@@ -212,11 +228,13 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   using S1 = std::integral_constant<int, 1>;
   using S2 = std::integral_constant<int, 2>;
   const int nk = p.nk;
+  using T1 = std::integral_constant<bool, true>;
+  using T0 = std::integral_constant<bool, false>;
   if constexpr (NSTG == 3) {
     issue(S0{});
     if (nk > 1) issue(S1{});
-    auto step = [&](int t, auto CUR, auto NXT2) {
-      if (t + 1 < nk) {
+    auto wait_tile = [&](bool newer_in_flight) {
+      if (newer_in_flight) {
         if constexpr (AJ + BJ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if constexpr (AJ + BJ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         else if constexpr (AJ + BJ == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -226,27 +244,34 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (t + 2 < nk) issue(NXT2);
-      compute(CUR);
     };
-    for (int t = 0; t < ((DBG & 16) ? 0 : nk); t += 3) {
-      step(t, S0{}, S2{});
-      if (t + 1 < nk) step(t + 1, S1{}, S0{});
-      if (t + 2 < nk) step(t + 2, S2{}, S1{});
+    int t = 0;
+    const int nfull = (DBG & 16) ? 0 : nk - 2;      // tiles whose step also issues tile t+2
+    for (; t + 2 < nfull; t += 3) {                 // steady state, stage indices are compile-time
+      wait_tile(true); compute(S0{}, S2{}, T1{});
+      wait_tile(true); compute(S1{}, S0{}, T1{});
+      wait_tile(true); compute(S2{}, S1{}, T1{});
+    }
+    // remaining tiles (at most 4), generic in the stage
+    for (; t < ((DBG & 16) ? 0 : nk); ++t) {
+      wait_tile(t + 1 < nk);
+      const bool is = t + 2 < nk;
+      switch (t % 3) {
+        case 0: if (is) compute(S0{}, S2{}, T1{}); else compute(S0{}, S2{}, T0{}); break;
+        case 1: if (is) compute(S1{}, S0{}, T1{}); else compute(S1{}, S0{}, T0{}); break;
+        default: if (is) compute(S2{}, S1{}, T1{}); else compute(S2{}, S1{}, T0{}); break;
+      }
     }
   } else {
     // two stages: tile t+1 streams in while tile t is multiplied
     issue(S0{});
-    auto step2 = [&](int t, auto CUR, auto NXT) {
+    for (int t = 0; t < nk; ++t) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (t + 1 < nk) issue(NXT);
-      compute(CUR);
-    };
-    for (int t = 0; t < nk; t += 2) {
-      step2(t, S0{}, S1{});
-      if (t + 1 < nk) step2(t + 1, S1{}, S0{});
+      const bool is = t + 1 < nk;
+      if (t & 1) { if (is) compute(S1{}, S0{}, T1{}); else compute(S1{}, S0{}, T0{}); }
+      else { if (is) compute(S0{}, S1{}, T1{}); else compute(S0{}, S1{}, T0{}); }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
