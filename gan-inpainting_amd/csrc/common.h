@@ -190,3 +190,10 @@ int op_convert_back(hipStream_t st, int dtype, const void* src, float* dst, int6
 int op_tanh_bwd(hipStream_t st, const float* dy, const float* y, float* dx, int64_t count, float scale);
 int op_fill_dropout(hipStream_t st, uint8_t* mask_nhwc, int64_t count, uint64_t seed, float p);
 int op_mask_nchw_to_nhwc(hipStream_t st, const uint8_t* src, uint8_t* dst, int n, int c, int hw, int to_nhwc);
+
+// gradient-penalty helpers (elementwise.hip)
+int op_mul_slope(hipStream_t st, int dtype, const void* tin, const void* a, void* tout, int64_t count);
+int op_bn_tangent_inject(hipStream_t st, int dtype, const void* dta, const void* y, const void* tx, const void* x, void* dxp,
+                         int64_t pixels, int c, const float* gamma, const float* mean, const float* inv, float* dgamma,
+                         float* partials, float* sums);
+int op_gp_direction(hipStream_t st, const float* g, int n, int64_t hw, float lam, float* sumsq, float* v, float* penalty);

@@ -262,6 +262,169 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   }
 }
 
+// ---- gradient-penalty helpers (WGAN-GP extension) ------------------------------------
+// t_out = t_in * slope(a): LeakyReLU Jacobian applied to a tangent (a = primal activation output)
+template <typename T>
+__global__ void __launch_bounds__(256) mul_slope_kernel(const char* tin, const char* a, char* tout, int64_t chunks) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < chunks; i += (int64_t)gridDim.x * 256) {
+    float t[EPC], av[EPC];
+    load_vec<T, EPC>(tin, i * EPC, t);
+    load_vec<T, EPC>(a, i * EPC, av);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) t[e] *= av[e] > 0.f ? 1.f : 0.2f;
+    store_vec<T, EPC>(tout, i * EPC, t);
+  }
+}
+
+// BatchNorm (train mode) tangent map tz = (gamma/sigma)(tx - mean(tx) - xhat*mean(xhat*tx)). Its dependence
+// on the PRIMAL x (through sigma and xhat) sends a gradient into x when the tangent graph is
+// differentiated: with a = slope(y) * d(ta) (gradient w.r.t. tz), per channel
+//   A   = sum(a*u),  u = tx - m1 - xhat*m2,  m1 = mean(tx), m2 = mean(xhat*tx)
+//   inj = -(gamma*inv^2)(xhat/M) A - gamma*inv*( m2*P(a) + mean(a*xhat)*P(tx) ),  P(w) = inv*(w - mean(w) - xhat*mean(w*xhat))
+//   dgamma += A*inv
+// pass 1: partial sums [blocks][5][c] of a, a*xhat, tx, tx*xhat, a*tx
+struct InjP {
+  const char* dta; const char* y; const char* tx; const char* x; char* dxp;   // dxp: += inj (in place on the primal gradient)
+  int64_t pixels; int c;
+  const float* gamma; const float* mean; const float* inv;
+  float* partials; const float* sums; float* dgamma;
+  int rows_per_block;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) bn_inject_reduce_kernel(InjP p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ float red[5 * 256 * EPC];
+  const int Q = p.c / EPC, RL = 256 / Q;
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+  const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block, r1 = min(p.pixels, r0 + p.rows_per_block);
+  float s[5][EPC], mu[EPC], iv[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k][e] = 0.f;
+    mu[e] = p.mean[q * EPC + e];
+    iv[e] = p.inv[q * EPC + e];
+  }
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    float d[EPC], yv[EPC], t[EPC], xv[EPC];
+    load_vec<T, EPC>(p.dta, r * p.c + q * EPC, d);
+    load_vec<T, EPC>(p.y, r * p.c + q * EPC, yv);
+    load_vec<T, EPC>(p.tx, r * p.c + q * EPC, t);
+    load_vec<T, EPC>(p.x, r * p.c + q * EPC, xv);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const float a = d[e] * (yv[e] > 0.f ? 1.f : 0.2f);
+      const float xh = (xv[e] - mu[e]) * iv[e];
+      s[0][e] += a; s[1][e] = fmaf(a, xh, s[1][e]); s[2][e] += t[e]; s[3][e] = fmaf(t[e], xh, s[3][e]); s[4][e] = fmaf(a, t[e], s[4][e]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) red[(k * 256 + threadIdx.x) * EPC + e] = s[k][e];
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < RL; ++i)
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[k][e] += red[(k * 256 + i * Q + q) * EPC + e];
+    float* ps = p.partials + ((int64_t)blockIdx.x * 5) * p.c + q * EPC;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) ps[k * p.c + e] = s[k][e];
+  }
+}
+__global__ void __launch_bounds__(256) bn_inject_sums_kernel(const float* partials, int rows, int c, float* sums) {
+  __shared__ double sh[5][256];
+  const int ch = blockIdx.x;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int r = threadIdx.x; r < rows; r += 256)
+    for (int k = 0; k < 5; ++k) s[k] += (double)partials[((int64_t)r * 5 + k) * c + ch];
+  for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) for (int k = 0; k < 5; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) for (int k = 0; k < 5; ++k) sums[k * c + ch] = (float)sh[k][0];
+}
+template <typename T>
+__global__ void __launch_bounds__(256) bn_inject_apply_kernel(InjP p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int cpp = p.c / EPC;
+  const int64_t total = p.pixels * cpp;
+  const float M = (float)p.pixels, invM = 1.f / M;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int cc = (int)(gid % cpp);
+    const int64_t pix = gid / cpp;
+    float d[EPC], yv[EPC], t[EPC], xv[EPC], o[EPC];
+    load_vec<T, EPC>(p.dta, pix * p.c + cc * EPC, d);
+    load_vec<T, EPC>(p.y, pix * p.c + cc * EPC, yv);
+    load_vec<T, EPC>(p.tx, pix * p.c + cc * EPC, t);
+    load_vec<T, EPC>(p.x, pix * p.c + cc * EPC, xv);
+    load_vec<T, EPC>(p.dxp, pix * p.c + cc * EPC, o);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int ch = cc * EPC + e;
+      const float inv = p.inv[ch], g = p.gamma[ch];
+      const float a = d[e] * (yv[e] > 0.f ? 1.f : 0.2f);
+      const float xh = (xv[e] - p.mean[ch]) * inv;
+      const float Sa = p.sums[ch], Sax = p.sums[p.c + ch], St = p.sums[2 * p.c + ch], Stx = p.sums[3 * p.c + ch], Sat = p.sums[4 * p.c + ch];
+      const float m2 = Stx * invM, max_ = Sax * invM;
+      const float A = Sat - Sa * St * invM - Sax * Stx * invM;
+      const float Pa = inv * (a - Sa * invM - xh * max_);
+      const float Pt = inv * (t[e] - St * invM - xh * m2);
+      o[e] += -(g * inv * inv) * (xh * invM) * A - g * inv * (m2 * Pa + max_ * Pt);
+    }
+    store_vec<T, EPC>(p.dxp, pix * p.c + cc * EPC, o);
+  }
+  if (p.dgamma && blockIdx.x == 0) {
+    for (int ch = threadIdx.x; ch < p.c; ch += 256) {
+      const float Sa = p.sums[ch], Sax = p.sums[p.c + ch], St = p.sums[2 * p.c + ch], Stx = p.sums[3 * p.c + ch], Sat = p.sums[4 * p.c + ch];
+      p.dgamma[ch] += (Sat - Sa * St * invM - Sax * Stx * invM) * p.inv[ch];
+    }
+  }
+}
+
+// per-sample squared L2 norm of g (n, hw) -> sumsq[n]
+__global__ void __launch_bounds__(256) sample_sumsq_kernel(const float* g, int64_t hw, float* sumsq) {
+  __shared__ double sh[4];
+  const float* p = g + (int64_t)blockIdx.x * hw;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < hw; i += 256) s += (double)p[i] * p[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) sumsq[blockIdx.x] = (float)(sh[0] + sh[1] + sh[2] + sh[3]);
+}
+// v[n,:] = lam/N * 2 (||g_n|| - 1) / ||g_n|| * g[n,:] ; penalty = lam * mean_n (||g_n|| - 1)^2 (written by block 0)
+__global__ void __launch_bounds__(256) gp_direction_kernel(const float* g, const float* sumsq, int n, int64_t hw, float lam,
+                                                           float* v, float* penalty) {
+  const int nn = blockIdx.y;
+  const float norm = sqrtf(sumsq[nn]);
+  const float coef = norm > 0.f ? lam / (float)n * 2.f * (norm - 1.f) / norm : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256)
+    v[(int64_t)nn * hw + i] = coef * g[(int64_t)nn * hw + i];
+  if (penalty && blockIdx.x == 0 && nn == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < n; ++k) { const double d = sqrt((double)sumsq[k]) - 1.0; s += d * d; }
+    penalty[0] = (float)(lam * s / n);
+  }
+}
+// out[n,:] = fake[n,:] + eps[n] * (real[n,:] - fake[n,:])
+__global__ void __launch_bounds__(256) interpolate_kernel(const float* real, const float* fake, const float* eps, int64_t hw,
+                                                          float* out) {
+  const int nn = blockIdx.y;
+  const float e = eps[nn];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) {
+    const int64_t j = (int64_t)nn * hw + i;
+    out[j] = e * real[j] + (1.f - e) * fake[j];
+  }
+}
+
 // ---- mask pipeline (bit-exact: selects / multiplies by 0 or 1) --------------------------------
 __global__ void __launch_bounds__(256) mask_apply_kernel(const float* ground, const float* mask, float* mask_c,
                                                          float* masked, int64_t count, int do_ceil) {
@@ -594,6 +757,46 @@ int op_mask_nchw_to_nhwc(hipStream_t st, const uint8_t* src, uint8_t* dst, int n
   return GI_OK;
 }
 
+int op_mul_slope(hipStream_t st, int dtype, const void* tin, const void* a, void* tout, int64_t count) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  GI_REQUIRE(count % epc == 0, "mul_slope: count must be a multiple of %d", epc);
+  if (dtype == GI_F16) hipLaunchKernelGGL(mul_slope_kernel<half_t>, dim3(nblocks(count / epc, 2)), dim3(256), 0, st, (const char*)tin, (const char*)a, (char*)tout, count / epc);
+  else hipLaunchKernelGGL(mul_slope_kernel<float>, dim3(nblocks(count / epc, 2)), dim3(256), 0, st, (const char*)tin, (const char*)a, (char*)tout, count / epc);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_bn_tangent_inject(hipStream_t st, int dtype, const void* dta, const void* y, const void* tx, const void* x, void* dxp,
+                         int64_t pixels, int c, const float* gamma, const float* mean, const float* inv, float* dgamma,
+                         float* partials, float* sums) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  const int Q = c / epc;
+  GI_REQUIRE(c % epc == 0 && gi_is_pow2(Q) && Q <= 256, "bn_tangent_inject: c=%d unsupported", c);
+  InjP p;
+  p.dta = (const char*)dta; p.y = (const char*)y; p.tx = (const char*)tx; p.x = (const char*)x; p.dxp = (char*)dxp;
+  p.pixels = pixels; p.c = c; p.gamma = gamma; p.mean = mean; p.inv = inv; p.partials = partials; p.sums = sums; p.dgamma = dgamma;
+  int blocks = 0;
+  p.rows_per_block = rows_per_block_for(pixels, &blocks);
+  if (dtype == GI_F16) hipLaunchKernelGGL(bn_inject_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(bn_inject_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p);
+  GI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_inject_sums_kernel, dim3(c), dim3(256), 0, st, partials, blocks, c, sums);
+  GI_LAUNCH_CHECK();
+  const int grid2 = nblocks(pixels * Q, 2);
+  if (dtype == GI_F16) hipLaunchKernelGGL(bn_inject_apply_kernel<half_t>, dim3(grid2), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(bn_inject_apply_kernel<float>, dim3(grid2), dim3(256), 0, st, p);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_gp_direction(hipStream_t st, const float* g, int n, int64_t hw, float lam, float* sumsq, float* v, float* penalty) {
+  hipLaunchKernelGGL(sample_sumsq_kernel, dim3(n), dim3(256), 0, st, g, hw, sumsq);
+  GI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gp_direction_kernel, dim3(nblocks(hw) > 64 ? 64 : nblocks(hw), n), dim3(256), 0, st, g, sumsq, n, hw, lam, v, penalty);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
 // ---- C-ABI entry points that are pure elementwise ops -------------------------------------------
 extern "C" {
 
@@ -609,6 +812,13 @@ int gi_mask_composite(gi_ctx* ctx, const float* masked, const float* gen, const 
 }
 int gi_mul(gi_ctx* ctx, const float* a, const float* b, float* out, int64_t count) {
   hipLaunchKernelGGL(mul_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, a, b, out, count);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int gi_interpolate(gi_ctx* ctx, const float* real, const float* fake, const float* eps, int n, int64_t hw, float* out) {
+  GI_REQUIRE(ctx && real && fake && eps && out && n > 0, "interpolate: bad argument");
+  hipLaunchKernelGGL(interpolate_kernel, dim3(nblocks(hw) > 64 ? 64 : nblocks(hw), n), dim3(256), 0, ctx->stream, real, fake, eps, hw, out);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

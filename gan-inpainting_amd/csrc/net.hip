@@ -75,6 +75,10 @@ struct gi_net {
   std::vector<int64_t> ogC, ogA;
   int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1, oCol = -1;
   int64_t part_floats = 0, split_bytes = 0;
+  // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
+  int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
+  int64_t oD2 = -1, oTZ = -1, oGimg = -1, oVimg = -1, oGPs = -1, oGPpart = -1, oGPsums = -1, oTh = -1;
+  int gp_slot = -1;
   std::vector<int> slot_n, slot_train;
   std::vector<std::vector<const uint8_t*>> ext_mask;  // [slot][level]
 
@@ -295,6 +299,24 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
   net->oDh = A.take(N * net->P * 4);
   net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
+  {   // gradient penalty (fp32 critics): tangent / stacked-gradient tensors
+    int64_t maxl = 0;
+    for (int i = 1; i <= 4; ++i) {
+      const int64_t e = N * (H >> i) * (W >> i) * chans[i] * T;
+      net->oA2[i] = A.take(2 * e);
+      net->oG2[i] = A.take(2 * e);
+      net->oTX[i] = A.take(e);
+      maxl = max64(maxl, e);
+    }
+    net->oD2 = A.take(2 * maxl);
+    net->oTZ = A.take(maxl);
+    net->oGimg = A.take(N * H * W * 4);
+    net->oVimg = A.take(N * H * W * 4);
+    net->oGPs = A.take((N + 16) * 4 * 2);
+    net->oGPpart = A.take((int64_t)1100 * 5 * 512 * 4);
+    net->oGPsums = A.take(5 * 512 * 4);
+    net->oTh = A.take(N * net->P * 4 * 2);
+  }
   Arena S;
   for (int i = 1; i <= 4; ++i) net->oA[i] = S.take(N * (H >> i) * (W >> i) * chans[i] * T);
   for (int i = 2; i <= 4; ++i) net->oRd[i] = S.take(N * (H >> i) * (W >> i) * chans[i] * T);
@@ -305,9 +327,10 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 4 * net->dbn[i].c; }
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
-  net->slot_base = A.take(S.size * n_slots);
-  net->slot_n.assign(n_slots, 0);
-  net->slot_train.assign(n_slots, 0);
+  net->gp_slot = n_slots;                      // one private activation set for the gradient penalty
+  net->slot_base = A.take(S.size * (n_slots + 1));
+  net->slot_n.assign(n_slots + 1, 0);
+  net->slot_train.assign(n_slots + 1, 0);
   *out = net;
   return GI_OK;
 }
@@ -476,6 +499,10 @@ int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, cons
   a.partials = (float*)net->shared(net->oPart);
   a.sums = (float*)net->shared(net->oSums);
   return op_act_bn_bwd(net->ctx->stream, net->dtype, a);
+}
+
+__global__ void __launch_bounds__(256) fill_f32_kernel(float* dst, int count, float v) {
+  for (int i = threadIdx.x; i < count; i += 256) dst[i] = v;
 }
 
 __global__ void __launch_bounds__(256) sum_acc_kernel(const float* src, int64_t count, float* dst, float scale) {
@@ -689,6 +716,110 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
 }
 
 }  // namespace
+
+namespace {
+
+// WGAN-GP extension (NOT in the reference): accumulates d/dtheta of
+//   lam * mean_n ( || grad_x sum_m D(x)_m ||_2 - 1 )^2
+// into the bound gradients. Formulation: g = grad_x sum D (one frozen backward); v = d(penalty)/dg;
+// d(penalty)/dtheta = d/dtheta [ v . g ] = d/dtheta [ JVP of sum D along v ]. The JVP (tangent forward)
+// and the reverse pass over the tangent graph reuse the convolution kernels; BatchNorm in train mode
+// couples the tangent to the PRIMAL activations through the batch statistics, which injects a primal
+// gradient at every norm layer (op_bn_tangent_inject). Tangent-side and primal-side gradients are
+// stacked as a 2n batch so every layer needs one input-gradient GEMM and one weight-gradient GEMM.
+int patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, float* penalty_out) {
+  hipStream_t st = net->ctx->stream;
+  const int dt = net->dtype, H = net->H, W = net->W, s = net->gp_slot;
+  GI_REQUIRE(dt == GI_F32, "gradient_penalty: built for fp32 critics (BASELINE config 2); fp16 needs tangent scaling");
+  GI_REQUIRE(!net->sigmoid && net->train, "gradient_penalty: needs a train-mode critic without sigmoid");
+  const int64_t T = 4;
+  const int chans[5] = {1, 64, 128, 256, 512};
+  auto A2 = [&](int i, int half) { return (void*)(net->shared(net->oA2[i]) + (int64_t)half * n * (H >> i) * (W >> i) * chans[i] * T); };
+  auto G2 = [&](int i, int half) { return (void*)(net->shared(net->oG2[i]) + (int64_t)half * n * (H >> i) * (W >> i) * chans[i] * T); };
+  float* gimg = (float*)net->shared(net->oGimg);
+  float* vimg = (float*)net->shared(net->oVimg);
+  float* ones = (float*)net->shared(net->oGPs);
+  float* sumsq = ones + (n + 16);
+  float* th = (float*)net->shared(net->oTh);
+  float* dth = th + (int64_t)n * net->P;
+  float* ytmp = sumsq;   // (n) critic outputs, overwritten by sumsq afterwards
+  // 1) primal forward + frozen backward: g = d(sum D)/dx
+  GI_TRY(patchgan_forward(net, s, xhat, ytmp, n));
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(1), dim3(256), 0, st, ones, n, 1.0f);
+  GI_LAUNCH_CHECK();
+  GI_TRY(patchgan_backward(net, s, ones, gimg, 0));
+  // 2) penalty value and v = d(penalty)/dg
+  GI_TRY(op_gp_direction(st, gimg, n, (int64_t)H * W, lam, sumsq, vimg, penalty_out));
+  // 3) tangent forward
+  void* TZ = net->shared(net->oTZ);
+  {
+    const int64_t cnt = (int64_t)n * (H / 2) * (W / 2) * 64;
+    GI_TRY(op_c1_gather(st, dt, vimg, net->params + net->dconv[1].w_off, net->shared(net->oTX[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_NONE, 1.f));
+    GI_TRY(op_mul_slope(st, dt, net->shared(net->oTX[1]), net->slot(s, net->oA[1]), A2(1, 0), cnt));
+    GI_HIP(hipMemcpyAsync(A2(1, 1), net->slot(s, net->oA[1]), cnt * T, hipMemcpyDeviceToDevice, st));
+  }
+  for (int i = 2; i <= 4; ++i) {
+    const Conv& c = net->dconv[i];
+    const int Hs = H >> i, Ws = W >> i;
+    const int64_t pix = (int64_t)n * Hs * Ws, cnt = pix * c.ca;
+    void* TX = net->shared(net->oTX[i]);
+    GI_TRY(igemm(net, 0, A2(i - 1, 0), c.cb, c.cb, 0, packed_ptr(net, c), TX, c.ca, c.ca, 0, n, Hs, Ws, 0, GI_ACT_NONE, false, nullptr));
+    GI_TRY(act_bn_bwd(net, s, TX, c.ca, 0, nullptr, 0, 0, TX, c.ca, 0, net->slot(s, net->oRd[i]), TZ, pix, c.ca, GI_ACT_NONE, 1.f,
+                      &net->dbn[i], 0));   // BatchNorm Jacobian applied to the tangent
+    GI_TRY(op_mul_slope(st, dt, TZ, net->slot(s, net->oA[i]), A2(i, 0), cnt));
+    GI_HIP(hipMemcpyAsync(A2(i, 1), net->slot(s, net->oA[i]), cnt * T, hipMemcpyDeviceToDevice, st));
+  }
+  // head: phi = sum_n wl . (w5 * ta4)
+  HeadArgs h;
+  h.a4 = A2(4, 0); h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;
+  h.h = th; h.out = ytmp; h.n = n; h.Hh = net->Hh; h.Wh = net->Wh; h.c = 512; h.sigmoid = 0;
+  GI_TRY(op_head_forward(st, dt, h));
+  // 4) reverse pass over the tangent graph (seed d(phi)/d(tz) = 1; the Linear bias does not enter phi)
+  HeadBwdArgs hb;
+  hb.a4 = A2(4, 0); hb.w5 = h.w5; hb.wl = h.wl; hb.h = th; hb.out = ytmp; hb.dy = ones; hb.da4 = G2(4, 0);
+  hb.dw5 = net->grads + net->w5_off; hb.dwl = net->grads + net->wl_off; hb.dbl = nullptr; hb.dh = dth;
+  hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = 0; hb.loss_scale = 1.f;
+  GI_TRY(op_head_backward(st, dt, hb));
+  GI_HIP(hipMemsetAsync(G2(4, 1), 0, (size_t)n * net->Hh * net->Wh * 512 * T, st));   // no primal gradient enters above the head
+  char* D2 = net->shared(net->oD2);
+  for (int i = 4; i >= 2; --i) {
+    const Conv& c = net->dconv[i];
+    const int Hs = H >> i, Ws = W >> i;
+    const int64_t pix = (int64_t)n * Hs * Ws, half = pix * c.ca * T;
+    // tangent-gradient chain: d(tx_i) = J_BN( slope * d(ta_i) )
+    GI_TRY(act_bn_bwd(net, s, G2(i, 0), c.ca, 0, nullptr, 0, 0, net->slot(s, net->oA[i]), c.ca, 0, net->slot(s, net->oRd[i]), D2, pix, c.ca,
+                      GI_ACT_LRELU, 1.f, &net->dbn[i], 0));
+    // primal chain: standard BatchNorm backward of the gradient arriving from the layer above
+    GI_TRY(act_bn_bwd(net, s, G2(i, 1), c.ca, 0, nullptr, 0, 0, net->slot(s, net->oA[i]), c.ca, 0, net->slot(s, net->oRd[i]), D2 + half, pix,
+                      c.ca, GI_ACT_LRELU, 1.f, &net->dbn[i], 1));
+    // dependence of the BatchNorm Jacobian on the primal input
+    BNPtrs bp = bn_ptrs(net, s, net->dbn[i]);
+    GI_TRY(op_bn_tangent_inject(st, dt, G2(i, 0), net->slot(s, net->oA[i]), net->shared(net->oTX[i]), net->slot(s, net->oRd[i]), D2 + half, pix,
+                                c.ca, net->params + net->dbn[i].gamma_off, bp.mean, bp.inv, net->grads + net->dbn[i].gamma_off,
+                                (float*)net->shared(net->oGPpart), (float*)net->shared(net->oGPsums)));
+    // conv_i on the stacked 2n batch: [d(tx_i); dxp_i] x [ta_{i-1}; a_{i-1}]
+    GI_TRY(wgrad(net, D2, c.ca, c.ca, 0, 0, A2(i - 1, 0), c.cb, c.cb, 0, 2 * n, Hs, Ws, net->grads + c.w_off));
+    GI_TRY(igemm(net, 1, D2, c.ca, c.ca, 0, phase_ptr(net, c), G2(i - 1, 0), c.cb, c.cb, 0, 2 * n, Hs, Ws, 0, GI_ACT_NONE, false, nullptr));
+  }
+  {
+    const int64_t pix = (int64_t)n * (H / 2) * (W / 2), half = pix * 64 * T;
+    GI_TRY(act_bn_bwd(net, s, G2(1, 0), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D2, pix, 64, GI_ACT_LRELU, 1.f, nullptr, 0));
+    GI_TRY(act_bn_bwd(net, s, G2(1, 1), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D2 + half, pix, 64, GI_ACT_LRELU, 1.f,
+                      nullptr, 0));
+    GI_TRY(op_c1_wgrad(st, dt, D2, vimg, net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, 1.f, 1.f));
+    GI_TRY(op_c1_wgrad(st, dt, D2 + half, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0,
+                       1.f, 1.f));
+  }
+  return GI_OK;
+}
+
+}  // namespace
+
+extern "C" int gi_patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, float* penalty_out) {
+  GI_REQUIRE(net && net->bound && net->kind == 1, "gradient_penalty: bound discriminator handle required");
+  GI_REQUIRE(xhat && n >= 1 && n <= net->max_n, "gradient_penalty: n=%d (max %d)", n, net->max_n);
+  return patchgan_gradient_penalty(net, xhat, n, lam, penalty_out);
+}
 
 extern "C" int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n) {
   GI_REQUIRE(net && net->bound, "net_forward: net not bound");

@@ -491,3 +491,27 @@ class PatchGANDiscriminator(HipNet):
 
     def _output_shape(self, n, H, W):
         return (n, 1)
+
+    def gradient_penalty(self, real, fake, eps=None, lam=10.0):
+        """WGAN-GP extension (not in the reference): adds d/dtheta of
+        lam * mean_n (||grad_x D(xhat)_n||_2 - 1)^2, xhat = eps*real + (1-eps)*fake, to the parameter
+        gradients and returns the penalty (0-d device tensor). eps: (n,) in [0,1), drawn here if None.
+        fp32 critics built with sigmoid=False."""
+        real, fake = real.contiguous(), fake.detach().contiguous()
+        n, _, H, W = real.shape
+        if eps is None:
+            eps = torch.rand(n, device=real.device)
+        eps = eps.to(real.device, torch.float32).contiguous().view(-1)
+        self._ensure_handle(n, H, W)
+        lib, ctx = B.lib(), B.get_ctx(real.device)
+        if self._dirty or self.always_sync:
+            B.check(lib.gi_net_sync_weights(self._handle))
+            self._dirty = False
+        B.check(lib.gi_net_set_train(self._handle, 1))
+        xhat = torch.empty_like(real)
+        B.check(lib.gi_interpolate(ctx, B.ptr(real), B.ptr(fake), B.ptr(eps), n, H * W, B.ptr(xhat)))
+        out = torch.zeros(1, dtype=torch.float32, device=real.device)
+        self._attach_grads()
+        B.check(lib.gi_patchgan_gradient_penalty(self._handle, B.ptr(xhat), n, float(lam), B.ptr(out)))
+        self._nbt_pending += 1   # the penalty's own forward runs the BatchNorm layers in train mode
+        return out.view(())

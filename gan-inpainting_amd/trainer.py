@@ -179,9 +179,13 @@ class WGANStep(_StepBase):
     """clip > 0 applies the reference's weight clipping after the critic update. If opt_D is this
     package's RMSprop its `clamp` is set so the clip is fused into the optimizer kernel."""
 
-    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None):
+    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None, gp_lambda=0.0):
         super().__init__(net_G, [net_D], net_G.device, sync)
         self.D, self.optG, self.optD, self.recon, self.clip = net_D, opt_G, opt_D, recon, clip
+        # gp_lambda > 0: WGAN-GP extension (BASELINE config 2) instead of the reference's weight clipping
+        self.gp_lambda = gp_lambda
+        if gp_lambda > 0:
+            self.clip = clip = 0.0
         self._fused_clip = isinstance(opt_D, optim.RMSprop)
         if self._fused_clip:
             opt_D.clamp = clip
@@ -201,6 +205,8 @@ class WGANStep(_StepBase):
         self._bwd(self.D, tr, self.dpred, False, True)
         o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)       # backward(mone) :140-141
         self._bwd(self.D, tf, self.dpred, False, True)
+        if self.gp_lambda > 0:
+            self.L["gp"] = self.D.gradient_penalty(ground, self.inpainted, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
         self._reduce(self.D)
         self.optD.step()                                                        # :147
         if self.clip > 0 and not self._fused_clip:

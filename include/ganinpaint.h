@@ -101,6 +101,14 @@ int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_
 int gi_net_backward_phase(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad, int phase);
 int64_t gi_net_phase_split(gi_net* net);
 
+/* WGAN-GP EXTENSION (not in the reference, which clips weights: wgan_l1.py:151-153): accumulates the
+ * parameter gradient of  lam * mean_n (||grad_x D(xhat)_n||_2 - 1)^2  into the bound grads and writes the
+ * penalty to penalty_out[0] (device). xhat: (n,1,H,W) interpolates, e.g. from gi_interpolate.
+ * fp32 critics without sigmoid, train mode. Uses a private activation set (no user slot is touched). */
+int gi_patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, float* penalty_out);
+/* out[n] = eps[n]*real[n] + (1-eps[n])*fake[n] */
+int gi_interpolate(gi_ctx* ctx, const float* real, const float* fake, const float* eps, int n, int64_t hw, float* out);
+
 /* ---- mask pipeline: experiment_list/minimaxgan_l1.py:113-122 ------------------------------ */
 /* mask_c = do_ceil ? ceil(mask) : mask ; masked = ground * (1 - mask_c) */
 int gi_mask_apply(gi_ctx* ctx, const float* ground, const float* mask, float* mask_c, float* masked,
