@@ -98,6 +98,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128"],
+                    help="wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-only", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=50)
@@ -106,6 +108,12 @@ def main():
     import gan_inpainting_amd  # noqa: F401
     from gan_inpainting_amd import optim, parallel, trainer
     from gan_inpainting_amd.lib.models import networks
+    global H, W, BS
+    gp = args.workload == "wgan_gp_128"
+    if gp:
+        H = W = 128
+        BS = 16
+        args.dtype = "fp32"
 
     rank, world = parallel.init_from_env()
     if world != args.gpus and rank == 0:
@@ -130,7 +138,7 @@ def main():
         torch.distributed.broadcast(G.flat_params(), 0)
         torch.distributed.broadcast(D.flat_params(), 0)
         G.mark_dirty(), D.mark_dirty()
-    step = trainer.WGANStep(G, D, oG, oD, recon="rmse", clip=0.01, sync=sync)
+    step = trainer.WGANStep(G, D, oG, oD, recon="l1" if gp else "rmse", clip=0.01, sync=sync, gp_lambda=10.0 if gp else 0.0)
     batches = [synth(BS, 0x5EED0000 + rank * 1000 + i, dev) for i in range(4)]
 
     def barrier():
@@ -159,6 +167,13 @@ def main():
     losses = {k: float(v.item()) for k, v in step.L.items()}
 
     if rank != 0:
+        return
+    if gp:   # secondary workload: plain line, no roofline / cpu legs
+        print(json.dumps({"metric": "training images/sec at 128x128 bs=16/GPU (wgan_l1 + gradient penalty, fp32)",
+                          "value": world * BS * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "wgan_l1 128x128 bs=16 fp32 + WGAN-GP (BASELINE.json configs[1])"}, "losses": losses}))
         return
     # generator forward latency (train-mode forward as inside the loop), HIP events on the compute stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

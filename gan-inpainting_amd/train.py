@@ -58,6 +58,8 @@ def main(argv=None):
     parser.add_argument("--debug", default="false")
     # backend additions
     parser.add_argument("--dtype", choices=["fp16", "fp32"], default="fp16")
+    parser.add_argument("--gp-lambda", dest="gp_lambda", type=float, default=0.0,
+                        help="> 0: WGAN-GP gradient penalty (extension, fp32) instead of the reference's weight clipping")
     parser.add_argument("--data", default="synthetic")
     parser.add_argument("--samples", type=int, default=1024)
     parser.add_argument("--outdir", default=os.path.join(os.getcwd(), "runs"))
