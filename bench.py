@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128"],
                     help="wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
+                    help="1: critic on a side HIP stream (trainer.WGANStep overlap=True)")
     ap.add_argument("--kernel-only", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=50)
     args = ap.parse_args()
@@ -138,7 +140,8 @@ def main():
         torch.distributed.broadcast(G.flat_params(), 0)
         torch.distributed.broadcast(D.flat_params(), 0)
         G.mark_dirty(), D.mark_dirty()
-    step = trainer.WGANStep(G, D, oG, oD, recon="l1" if gp else "rmse", clip=0.01, sync=sync, gp_lambda=10.0 if gp else 0.0)
+    step = trainer.WGANStep(G, D, oG, oD, recon="l1" if gp else "rmse", clip=0.01, sync=sync, gp_lambda=10.0 if gp else 0.0,
+                            overlap=bool(args.overlap))
     batches = [synth(BS, 0x5EED0000 + rank * 1000 + i, dev) for i in range(4)]
 
     def barrier():

@@ -11,7 +11,7 @@ def begin(state, loaders):
     net_G, (net_D,) = C.build_networks(state, device, n_disc=1, sigmoid=False)    # wgan_l1.py:58
     opt_G, opt_D = C.make_optimizers("rmsprop", net_G, net_D.parameters())
     step = C.trainer.WGANStep(net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=C.make_sync(),
-                              gp_lambda=float(state.get("gp_lambda", 0.0)))   # > 0: WGAN-GP extension instead of clipping (fp32)
+                              gp_lambda=float(state.get("gp_lambda", 0.0)), overlap=bool(state.get("overlap", True)))   # > 0: WGAN-GP extension instead of clipping (fp32)
     counters = {"G_iter_count": 0}
 
     def batch(bi, ground, mask):

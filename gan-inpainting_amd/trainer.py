@@ -179,9 +179,20 @@ class WGANStep(_StepBase):
     """clip > 0 applies the reference's weight clipping after the critic update. If opt_D is this
     package's RMSprop its `clamp` is set so the clip is fused into the optimizer kernel."""
 
-    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None, gp_lambda=0.0):
+    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None, gp_lambda=0.0, overlap=False):
         super().__init__(net_G, [net_D], net_G.device, sync)
         self.D, self.optG, self.optD, self.recon, self.clip = net_D, opt_G, opt_D, recon, clip
+        # overlap=True: the critic runs on a side HIP stream. Its real-image forward/backward does not depend
+        # on the generator forward, and in critic-only batches the next batch's generator forward does not
+        # depend on this batch's critic update, so the two networks' small / latency-bound kernels fill each
+        # other's idle CUs. Results are identical (same kernels, same order per network).
+        self.overlap = overlap
+        if overlap:
+            self._sD = torch.cuda.Stream(device=net_G.device)
+            net_D._release_handle()          # the handle launches on the stream that is current when it is created
+            self._inp2 = [None, None]
+            self._evD = [None, None]
+            self._k = 0
         # gp_lambda > 0: WGAN-GP extension (BASELINE config 2) instead of the reference's weight clipping
         self.gp_lambda = gp_lambda
         if gp_lambda > 0:
@@ -192,7 +203,61 @@ class WGANStep(_StepBase):
         self._bind_optimizers(opt_G, opt_D)
 
     @torch.no_grad()
+    def _call_overlapped(self, ground, mask, update_g):
+        o = self.ops
+        self._buffers(ground)
+        main = torch.cuda.current_stream(ground.device)
+        sD = self._sD
+        k = self._k
+        self._k ^= 1
+        if self._inp2[k] is None:
+            self._inp2[k] = torch.empty_like(ground)
+        inp = self._inp2[k]
+        if self._evD[k] is not None:
+            main.wait_event(self._evD[k])        # the critic pass that read this buffer two batches ago is done
+        e0 = main.record_event()
+        o.mask_apply(ground, mask, self.mask_c, self.masked, True)
+        gen, gtok = self._fwd(self.G, self.masked)
+        o.composite(self.masked, gen, self.mask_c, inp)
+        e_inp = main.record_event()
+        self.inpainted = inp
+        d_adv = None
+        with torch.cuda.stream(sD):
+            sD.wait_event(e0)
+            self.optD.zero_grad()
+            pr, tr = self._fwd(self.D, ground)
+            o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)
+            self._bwd(self.D, tr, self.dpred, False, True)
+            sD.wait_event(e_inp)
+            pf, tf = self._fwd(self.D, inp)
+            o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)
+            self._bwd(self.D, tf, self.dpred, False, True)
+            if self.gp_lambda > 0:
+                self.L["gp"] = self.D.gradient_penalty(ground, inp, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
+            self._reduce(self.D)
+            self.optD.step()
+            if self.clip > 0 and not self._fused_clip:
+                util.clamp_parameters(self.D, -self.clip, self.clip)
+            if update_g:
+                p, t = self._fwd(self.D, inp)
+                o.adv(p, MEAN, 0.0, self._loss("g_adv"), self.dpred, +1.0)
+                d_adv = self._bwd(self.D, t, self.dpred, True, False)
+            self._evD[k] = sD.record_event()
+        if update_g:
+            main.wait_event(self._evD[k])
+            d_adv.record_stream(main)
+            self.optG.zero_grad()
+            o.recon(self.recon, inp, ground, self._loss("recon"), self.g_rec)
+            o.add(d_adv, self.g_rec, self.tmp1)
+            o.mul(self.tmp1, self.mask_c, self.g_gen)
+            self._bwd_G(gtok, self.g_gen)
+            self.optG.step()
+        return self.L
+
+    @torch.no_grad()
     def __call__(self, ground, mask, update_g):
+        if self.overlap:
+            return self._call_overlapped(ground, mask, update_g)
         o = self.ops
         self._buffers(ground)
         o.mask_apply(ground, mask, self.mask_c, self.masked, True)

@@ -59,7 +59,8 @@ def _worker(rank, world, port, q):
     torch.distributed.broadcast(D.flat_params(), 0)
     G.mark_dirty(), D.mark_dirty()
     sync = parallel.GradSync(bucket_floats=4 * 1024 * 1024)
-    step = trainer.WGANStep(G, D, optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5), sync=sync)
+    step = trainer.WGANStep(G, D, optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5), sync=sync,
+                            overlap=True)   # critic on a side stream, as bench.py runs it
     for it in range(2):
         g, m = _batch(rank, it)
         G.impose_dropout_masks(_masks(it))

@@ -87,18 +87,20 @@ def test_minimax_steps_vs_reference(dtype):
     assert np.array_equal(final[mc == 0], g[mc == 0])
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_wgan_steps_vs_reference(dtype):
+def test_wgan_steps_vs_reference(dtype, overlap):
     fx = load("wgan_steps")
     seed, N = int(fx["seed"]), int(fx["N"])
     G, (D,) = build(seed, [seed + 1], False, dtype)
     oG = optim.RMSprop(G.parameters(), lr=0.00005)
     oD = optim.RMSprop(D.parameters(), lr=0.00005)
-    step = trainer.WGANStep(G, D, oG, oD, recon="l1", clip=0.01)
+    step = trainer.WGANStep(G, D, oG, oD, recon="l1", clip=0.01, overlap=overlap)   # overlap: critic on a side stream
     for it, upd in enumerate(int(v) for v in fx["pattern"]):
         g, m = op.synth_batch(seed * 100 + it, N, 128, 128)
         G.impose_dropout_masks(unpack_masks(fx, f"it{it}_"))
         L = step(torch.from_numpy(g).cuda(), torch.from_numpy(m).cuda(), bool(upd))
+        torch.cuda.synchronize()
         keys = ("d_loss_real", "d_loss_fake") + (("g_adv", "recon") if upd else ())
         for k in keys:
             check_loss(f"wgan it{it}", k, L[k].item(), fx[f"it{it}_{k}"], dtype, floor=2e-3)
