@@ -143,6 +143,8 @@ def main():
     step = trainer.WGANStep(G, D, oG, oD, recon="l1" if gp else "rmse", clip=0.01, sync=sync, gp_lambda=10.0 if gp else 0.0,
                             overlap=bool(args.overlap))
     batches = [synth(BS, 0x5EED0000 + rank * 1000 + i, dev) for i in range(4)]
+    torch.cuda.synchronize()
+    step.inputs_resident = True    # batches are resident in HBM before the first step is issued
 
     def barrier():
         torch.cuda.synchronize()
