@@ -92,14 +92,50 @@ def cpu_baseline():
                        f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1")
 
 
+def ssim_workload(args, dev):
+    """Secondary line (not the headline): the fused SSIM metric kernel, one step = ssim(ground, inpainted)
+    on a resident 256x256 bs=32 pair. HBM-bound: 8 algorithmic bytes per pixel (two fp32 reads)."""
+    from gan_inpainting_amd.lib import pytorch_ssim
+    from oracle import params as op          # input generator + CPU oracle (checker / cpu_baseline leg only)
+    from oracle import torch_ref as orc
+    x, y = (torch.from_numpy(a) for a in op.synth_ssim_pair(0x551, BS, 1, H, W))
+    dx, dy = x.to(dev), y.to(dev)
+    for _ in range(max(args.warmup, 3)):
+        out = pytorch_ssim.ssim(dx, dy)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        out = pytorch_ssim.ssim(dx, dy)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / args.steps
+    ms = e0.elapsed_time(e1) / args.steps
+    nbytes = 2 * 4 * BS * H * W
+    t0 = time.perf_counter()
+    ref = float(orc.ssim(x, y))
+    cpu_s = time.perf_counter() - t0
+    return {"metric": "ssim_images_per_sec", "value": BS / wall, "unit": "images/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ssim(ground, inpainted) 256x256 bs=32, window 11 (experiment1_global_local_D.py:209)"},
+            "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+                         "note": "3 launches per call (tile kernel + 2 finish kernels), stream time per call"},
+            "cpu_baseline": {"value": BS / cpu_s, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                             "sample": "one oracle.ssim call on the same pair"},
+            "value_check": {"gpu": float(out), "oracle": ref}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128"],
-                    help="wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
+    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256"],
+                    help="ssim_256 = the per-batch SSIM metric of experiment1_global_local_D.py:209 at 256x256 bs=32 (SURVEY 8f rank 2); wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
                     help="1: critic on a side HIP stream (trainer.WGANStep overlap=True)")
@@ -123,6 +159,10 @@ def main():
     local = parallel.local_device()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    if args.workload == "ssim_256":
+        print(json.dumps(ssim_workload(args, dev)))
+        return
 
     if args.kernel_only:
         k = dominant_kernel(args.kernel_iters)

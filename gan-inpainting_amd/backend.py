@@ -56,6 +56,8 @@ PROTOTYPES = {
     "gi_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f]),
     "gi_clamp": (_i, [_vp, _vp, _i64, _f, _f]),
     "gi_grad_absmean": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    "gi_ssim_scratch_floats": (_i64, [_i, _i, _i, _i, _i]),
+    "gi_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_convT_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_wgrad_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f]),

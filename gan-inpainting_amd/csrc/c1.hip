@@ -644,11 +644,14 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const 
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 16 * cpt) return;
   const int tap = idx / cpt, cc = idx % cpt;
-  const int nn = blockIdx.y, py = blockIdx.z;
+  // blockIdx.z covers a band of output rows: 1/band of the atomics (they contend on 16*c addresses)
+  const int nn = blockIdx.y;
+  const int band = (Ph + (int)gridDim.z - 1) / (int)gridDim.z;
+  const int py0 = blockIdx.z * band, py1 = min(Ph, py0 + band);
   float s[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) s[e] = 0.f;
-  (void)Ph;
+  for (int py = py0; py < py1; ++py)
   for (int px = 0; px < Pw; ++px) {
     const float g = dh[((int64_t)nn * Ph + py) * Pw + px];
     const char* src = a4 + ((((int64_t)nn * Hh + py + (tap >> 2)) * Wh + px + (tap & 3)) * c + cc * EPC) * (int64_t)sizeof(T);
@@ -810,7 +813,7 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
     hipLaunchKernelGGL(head_dgrad_kernel<float>, dim3(grid), dim3(256), 0, st, a.dh, a.w5, (char*)a.da4, a.n, a.Hh, a.Wh, a.c, a.loss_scale);
   GI_LAUNCH_CHECK();
   if (a.dw5) {
-    dim3 g((16 * (a.c / epc) + 255) / 256, a.n, Ph);
+    dim3 g((16 * (a.c / epc) + 255) / 256, a.n, Ph >= 8 ? 2 : 1);
     if (dtype == GI_F16)
       hipLaunchKernelGGL(head_wgrad_kernel<half_t>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
     else

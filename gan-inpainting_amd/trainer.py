@@ -317,6 +317,7 @@ class DualDStep(_StepBase):
         o.mask_apply(ground, mask, None, self.masked, False)                    # :144
         self.optG.zero_grad()
         gen, gtok = self._fwd(self.G, self.masked)                              # :154
+        self.gen = gen                                                          # the reference's `inpainted` (:154, metric at :209)
         # D_global(inpainted), D_local(mask*inpainted) with frozen Ds :156-157
         p, t = self._fwd(self.Dg, gen)
         o.adv(p, LSGAN, 1.0, self._loss("g_adv_global"), self.dpred)

@@ -152,6 +152,17 @@ int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi);
 int gi_grad_absmean(gi_ctx* ctx, const float* g, const int64_t* seg_off, const int64_t* seg_len,
                     int nseg, float* out);
 
+/* ---- SSIM metric. lib/pytorch_ssim/__init__.py:20-40 `_ssim`, :68-76 `ssim()`,
+ *      called per batch at experiment1_global_local_D.py:209. img1/img2: (n,c,H,W) fp32 contiguous on
+ *      the device; depthwise window_size^2 Gaussian (sigma 1.5, zero padding window_size/2; window_size
+ *      odd, <= 31), C1 = 0.01^2, C2 = 0.03^2. per_sample (n floats, may be NULL) = size_average=False;
+ *      mean_out (1 float, may be NULL) = size_average=True. window_host: the 1-D window as
+ *      `window_size` HOST floats, or NULL for the reference's gaussian(window_size, 1.5). scratch:
+ *      gi_ssim_scratch_floats(...) device floats, 8-byte aligned (returns -1 for unsupported sizes) -- */
+int64_t gi_ssim_scratch_floats(int n, int c, int H, int W, int window_size);
+int gi_ssim(gi_ctx* ctx, const float* img1, const float* img2, int n, int c, int H, int W, int window_size,
+            const float* window_host, float* per_sample, float* mean_out, float* scratch);
+
 /* ---- single-layer entry points (unit parity tests and kernel roofline measurements) -------- */
 /* out[n,y,x,a] = act( sum_{ky,kx,b} in[n,2y-1+ky,2x-1+kx,b] * w[a][ky][kx][b] ), NHWC, dtype T.
  * in: (n,H,W,cb) ld=ldin; out: (n,H/2,W/2,ca) ld=ldout. w_packed is T [ca][16*cb].

@@ -134,3 +134,14 @@ def synth_batch(seed, N, H, W, fractional_edge=False):
             mask[n, 0, y0, x0:x0 + w] = 0.25
             mask[n, 0, y0:y0 + h, x0] = 0.5
     return ground, mask
+
+
+def synth_ssim_pair(seed, n, c, h, w):
+    """Inpainting-like pair in [0,1] for the SSIM metric: y = x with one block replaced by noise
+    (what experiment1_global_local_D.py:209 feeds it: ground truth vs generator output)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.random((n, c, h, w), dtype=np.float32)
+    x = (x + np.roll(x, 1, 2) + np.roll(x, 1, 3) + np.roll(x, (1, 1), (2, 3))) / 4   # local variances differ
+    y = x.copy()
+    y[:, :, h // 4: h // 2, w // 3: 2 * w // 3] = rng.random((n, c, h // 2 - h // 4, 2 * w // 3 - w // 3), dtype=np.float32)
+    return x.astype(np.float32), y.astype(np.float32)

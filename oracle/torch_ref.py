@@ -137,6 +137,34 @@ def local_loss(yhat, y, mask, base="l1"):
     raise ValueError(base)
 
 
+def ssim_window(window_size=11, sigma=1.5):
+    """1-D normalised Gaussian, fp32 (lib/pytorch_ssim/__init__.py:10-12: python-float exp, fp32 tensor,
+    divided by its fp32 sum)."""
+    import math
+    g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)) for x in range(window_size)],
+                     dtype=torch.float32)
+    return g / g.sum()
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """SSIM of two (n,c,h,w) batches (lib/pytorch_ssim/__init__.py:14-40,68-76): depthwise
+    window_size^2 Gaussian (outer product of the 1-D window, zero padding window_size//2) of x, y,
+    x^2, y^2, xy; C1=0.01^2, C2=0.03^2; mean over everything or per sample."""
+    n, c, h, w = img1.shape
+    g = ssim_window(window_size).to(img1.dtype).unsqueeze(1)
+    win = g.mm(g.t()).unsqueeze(0).unsqueeze(0).expand(c, 1, window_size, window_size).contiguous()
+    p = window_size // 2
+    conv = lambda t: F.conv2d(t, win, padding=p, groups=c)
+    mu1, mu2 = conv(img1), conv(img2)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    s1 = conv(img1 * img1) - mu1_sq
+    s2 = conv(img2 * img2) - mu2_sq
+    s12 = conv(img1 * img2) - mu1_mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+
+
 def bce_loss(p, target):
     """nn.BCELoss (minimaxgan_l1.py:61,135,141,162): log terms clamped at -100."""
     lp = torch.clamp(torch.log(p), min=-100.0)

@@ -417,6 +417,35 @@ def case_init(networks, name, seed):
     return fx
 
 
+SSIM_CASES = [  # (seed, n, c, h, w, window_size)
+    (61, 3, 1, 40, 56, 11), (62, 2, 3, 33, 47, 11), (63, 2, 1, 128, 128, 11), (64, 2, 1, 24, 24, 7),
+    (65, 1, 2, 9, 70, 11), (66, 2, 1, 64, 64, 3),
+]
+
+
+def case_ssim(ref_root, name):
+    """lib/pytorch_ssim (pure torch) imported unmodified: ssim() and the SSIM module, both reductions."""
+    sys.path.insert(0, ref_root)
+    import lib.pytorch_ssim as rs  # noqa
+    sys.path.pop(0)
+    fx = {"cases": np.array(SSIM_CASES, dtype=np.int64)}
+    for i, (seed, n, c, h, w, ws) in enumerate(SSIM_CASES):
+        x, y = op.synth_ssim_pair(seed, n, c, h, w)
+        tx, ty = torch.from_numpy(x), torch.from_numpy(y)
+        m = rs.ssim(tx, ty, window_size=ws)
+        per = rs.ssim(tx, ty, window_size=ws, size_average=False)
+        m2 = rs.SSIM(window_size=ws)(tx, ty)
+        assert torch.equal(m, m2)
+        close(orc.ssim(tx, ty, ws), m, 0, "ssim mean %d" % i)
+        close(orc.ssim(tx, ty, ws, size_average=False), per, 0, "ssim per-sample %d" % i)
+        same = rs.ssim(tx, tx, window_size=ws)
+        fx["mean_%d" % i] = m.numpy()
+        fx["per_sample_%d" % i] = per.numpy()
+        fx["self_%d" % i] = same.numpy()
+        fx["mean64_%d" % i] = orc.ssim(tx.double(), ty.double(), ws).numpy()
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -435,6 +464,7 @@ def main():
         dual_d_step=lambda: case_dual(networks, util, "dual_d_step", 51, 2),
         optim=lambda: case_optim("optim"),
         init_parity=lambda: case_init(networks, "init_parity", 7),
+        ssim=lambda: case_ssim(args.ref, "ssim"),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):

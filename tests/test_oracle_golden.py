@@ -121,3 +121,14 @@ def test_wgan_cadence():
     assert orc.wgan_update_g(140, 0) and not orc.wgan_update_g(5, 0)
     assert orc.wgan_update_g(5, 30) and not orc.wgan_update_g(6, 30)
     assert not orc.wgan_update_g(5, 500) and orc.wgan_update_g(280, 500)
+
+
+def test_ssim_metric():
+    """oracle.ssim == the imported reference's lib/pytorch_ssim (both reductions, 6 shapes / windows)."""
+    fx = load("ssim")
+    for i, (seed, n, c, h, w, ws) in enumerate(fx["cases"].tolist()):
+        x, y = (torch.from_numpy(a) for a in op.synth_ssim_pair(seed, n, c, h, w))
+        assert abs(float(orc.ssim(x, y, ws)) - float(fx[f"mean_{i}"])) <= 1e-6
+        assert np.abs(orc.ssim(x, y, ws, size_average=False).numpy() - fx[f"per_sample_{i}"]).max() <= 1e-6
+        assert abs(float(orc.ssim(x, x, ws)) - float(fx[f"self_{i}"])) <= 1e-6
+        assert abs(float(fx[f"mean_{i}"]) - float(fx[f"mean64_{i}"])) <= 2e-6      # fp32 pipeline vs fp64

