@@ -58,6 +58,9 @@ PROTOTYPES = {
     "gi_grad_absmean": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "gi_ssim_scratch_floats": (_i64, [_i, _i, _i, _i, _i]),
     "gi_ssim": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "gi_eval_recon_scratch_floats": (_i64, [_i64]),
+    "gi_eval_recon": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
+    "gi_seg_metrics": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp]),
     "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_convT_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_wgrad_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f]),

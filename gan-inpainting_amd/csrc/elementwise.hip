@@ -429,7 +429,8 @@ __global__ void __launch_bounds__(256) interpolate_kernel(const float* real, con
 __global__ void __launch_bounds__(256) mask_apply_kernel(const float* ground, const float* mask, float* mask_c,
                                                          float* masked, int64_t count, int do_ceil) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-    const float m = do_ceil ? ceilf(mask[i]) : mask[i];
+    float m = (do_ceil & 1) ? ceilf(mask[i]) : mask[i];
+    if (do_ceil & 2) m = 1.f - m;
     if (mask_c) mask_c[i] = m;
     masked[i] = ground[i] * (1.f - m);
   }

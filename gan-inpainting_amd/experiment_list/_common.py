@@ -8,8 +8,9 @@ Differences to the reference, all host-side and listed in DESIGN.md:
   * losses are read back once per `logevery` batches instead of ~45 blocking .item() calls per batch;
   * the gradient-flow histogram (one .item() per tensor per batch, :180-182,:195-197) is one kernel +
     one copy per batch (util.GradFlow), accumulated on the device;
-  * evaluation metrics that need FID / the segmentation model (evaluate.calculate_metric) are outside
-    this backend's scope: `state['eval_fn']`, if given, is called with (net_G, loader, epoch).
+  * the evaluation pass (minimaxgan_l1.py:234-240) runs lib.models.evaluate.calculate_metric on the
+    train and test loaders (reconstruction metrics on fused HIP reductions; FID reported as -1, needs
+    Inception weights); `state['eval_fn']`, if given, replaces it and is called with (net_G, loader, epoch).
 """
 import logging
 import os
@@ -19,7 +20,7 @@ import time
 import torch
 
 from .. import optim, trainer
-from ..lib.models import networks, util
+from ..lib.models import evaluate, networks, util
 
 
 def setup(state, title):
@@ -92,6 +93,11 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
         if epoch % evaluate_every == 0 and epoch > 0:
             if state.get("eval_fn"):
                 eval_hist.append(state["eval_fn"](net_G, loaders.get("test"), epoch))
+            else:                                                # minimaxgan_l1.py:235-240
+                rec_eval = {k: evaluate.calculate_metric(device, loaders[k], net_G, mode=k, epoch=epoch)
+                            for k in ("train", "test") if loaders.get(k) is not None}
+                eval_hist.append(rec_eval)
+                logger.info("VALIDATION: %s", ", ".join(f"{k} - {v}" for k, v in rec_eval.items()))
             with open(os.path.join(exp_dir, "training_epoch_history.obj"), "wb") as h:
                 pickle.dump(history, h, protocol=pickle.HIGHEST_PROTOCOL)
             with open(os.path.join(exp_dir, "eval_history.obj"), "wb") as h:

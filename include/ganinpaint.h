@@ -110,9 +110,10 @@ int gi_patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float la
 int gi_interpolate(gi_ctx* ctx, const float* real, const float* fake, const float* eps, int n, int64_t hw, float* out);
 
 /* ---- mask pipeline: experiment_list/minimaxgan_l1.py:113-122 ------------------------------ */
-/* mask_c = do_ceil ? ceil(mask) : mask ; masked = ground * (1 - mask_c) */
+/* mask_c = ceil(mask) if (flags & 1) else mask ; if (flags & 2) mask_c = 1 - mask_c (is_flip_mask of
+ * evaluate.py:130-132) ; masked = ground * (1 - mask_c) */
 int gi_mask_apply(gi_ctx* ctx, const float* ground, const float* mask, float* mask_c, float* masked,
-                  int64_t count, int do_ceil);
+                  int64_t count, int flags);
 /* inpainted = masked + gen * mask_c */
 int gi_mask_composite(gi_ctx* ctx, const float* masked, const float* gen, const float* mask_c,
                       float* inpainted, int64_t count);
@@ -162,6 +163,26 @@ int gi_grad_absmean(gi_ctx* ctx, const float* g, const int64_t* seg_off, const i
 int64_t gi_ssim_scratch_floats(int n, int c, int H, int W, int window_size);
 int gi_ssim(gi_ctx* ctx, const float* img1, const float* img2, int n, int c, int H, int W, int window_size,
             const float* window_host, float* per_sample, float* mean_out, float* scratch);
+
+/* ---- evaluation pass ------------------------------------------------------
+ * lib/models/evaluate.py:127-158: per batch  out = gen*m + ground*(1-m)  (m = mask_c from
+ * gi_mask_apply: ceil, optionally flipped) and
+ *   rmse_global = sqrt(mean (ground-out)^2 + eps)      l1_global = mean |ground-out|
+ *   rmse_local  = sqrt(sum (out*m-ground*m)^2 / count(m!=0) + eps)   l1_local = sum |out*m-ground*m| / count(m!=0)
+ * acc (device, 5 floats, may be NULL): acc[0..3] += {rmse_global, l1_global, rmse_local, l1_local},
+ * acc[4] += 1 (the reference divides its running sums by the number of batches, :160-165);
+ * batch_out (4 floats, may be NULL) receives this batch's values; inpainted_out (count floats, may be
+ * NULL) the composite. scratch: gi_eval_recon_scratch_floats(count) floats, 8-byte aligned. */
+int64_t gi_eval_recon_scratch_floats(int64_t count);
+int gi_eval_recon(gi_ctx* ctx, const float* ground, const float* gen, const float* mask_c, int64_t count, float eps,
+                  float* inpainted_out, float* acc, float* batch_out, float* scratch);
+/* lib/models/evaluate.py:179-224 calculate_segmentation_eval_metric: prediction = argmax over the
+ * class axis of logits (n,num_classes,hw) fp32; for each u of unique_labels_host[nu] (HOST ints, nu<=16):
+ * precision / recall / IoU per sample from the pixel counts (eps 1e-32), mean over the n samples.
+ * per_class: nu*3 floats {precision, recall, iou}; across: 3 floats (mean over classes).
+ * labels: (n,hw) int64. scratch_counts: n*16*3 ints. */
+int gi_seg_metrics(gi_ctx* ctx, const int64_t* labels, const float* logits, int n, int num_classes, int64_t hw,
+                   const int* unique_labels_host, int nu, float* per_class, float* across, int* scratch_counts);
 
 /* ---- single-layer entry points (unit parity tests and kernel roofline measurements) -------- */
 /* out[n,y,x,a] = act( sum_{ky,kx,b} in[n,2y-1+ky,2x-1+kx,b] * w[a][ky][kx][b] ), NHWC, dtype T.

@@ -145,3 +145,20 @@ def synth_ssim_pair(seed, n, c, h, w):
     y = x.copy()
     y[:, :, h // 4: h // 2, w // 3: 2 * w // 3] = rng.random((n, c, h // 2 - h // 4, 2 * w // 3 - w // 3), dtype=np.float32)
     return x.astype(np.float32), y.astype(np.float32)
+
+
+def synth_segmentation(seed, n, num_classes, h, w, with_minus_one=False):
+    """(labels int64 (n,h,w), logits fp32 (n,num_classes,h,w)) for the face-parsing metrics: blocky label
+    maps, logits = noisy one-hot so that predictions agree with the labels on most pixels; one sample
+    lacks the last class entirely (empty-union edge case) and ties are present (argmax takes the first)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    coarse = rng.integers(0, num_classes, size=(n, (h + 7) // 8, (w + 7) // 8))
+    labels = np.repeat(np.repeat(coarse, 8, 1), 8, 2)[:, :h, :w].astype(np.int64)
+    labels[0][labels[0] == num_classes - 1] = 0
+    logits = rng.standard_normal((n, num_classes, h, w)).astype(np.float32)
+    onehot = (labels[:, None] == np.arange(num_classes)[None, :, None, None]).astype(np.float32)
+    logits += 1.5 * onehot
+    logits[:, :, 0, :] = 0.25                      # exact ties along the first row
+    if with_minus_one:
+        labels[:, 1, :] = -1
+    return labels, logits

@@ -165,6 +165,46 @@ def ssim(img1, img2, window_size=11, size_average=True):
     return m.mean() if size_average else m.mean(1).mean(1).mean(1)
 
 
+def eval_recon_batch(ground, gen, mask, is_flip_mask=False):
+    """One batch of lib/models/evaluate.py:127-158 after the network call: m = ceil(mask) (flipped if
+    asked), out = gen*m + ground*(1-m); returns (out, rmse_global, l1_global, rmse_local, l1_local) with
+    RMSELoss (loss.py:11-19), nn.L1Loss, LocalLoss(nn.L1Loss) (loss.py:24-47) and, for the local RMSE,
+    the evident intent sqrt(masked mean square + eps) (the reference's `LocalLoss(loss.RMSELoss())`
+    raises at construction: it passes an instance where the class is called)."""
+    m = torch.ceil(mask)
+    if is_flip_mask:
+        m = 1 - m
+    masked = ground * (1 - m)
+    out = gen * m + masked
+    return (out, rmse_loss(ground, out), l1_loss(ground, out), local_loss(ground, out, m, base="rmse"),
+            local_loss(ground, out, m, base="l1"))
+
+
+def segmentation_eval_metric(labels, outputs, unique_labels):
+    """lib/models/evaluate.py:179-224: prediction = argmax over dim 1; per class u and per sample
+    intersection / union / |p| / |g| pixel counts -> iou, precision, recall (eps 1e-32), mean over the
+    batch; across-class = mean over the classes. A label value of -1 matches every class (the reference
+    marks matches with -1 in place, :193-195)."""
+    prediction = torch.argmax(outputs, 1)
+    eps = 1e-32
+    batch = labels.shape[0]
+    per_class, across = {}, {"precision": 0, "recall": 0, "iou": 0}
+    for u in unique_labels:
+        g = ((labels.view(batch, -1) == u) | (labels.view(batch, -1) == -1)).long()
+        p = (prediction.view(batch, -1) == u).long()
+        inter = (p & g).sum(1).float()
+        union = (p | g).sum(1).float()
+        iou = inter / (union + eps)
+        precision = inter / (p.sum(1) + eps)
+        recall = inter / (g.sum(1) + eps)
+        per_class[u] = {"precision": precision.mean(), "recall": recall.mean(), "iou": iou.mean()}
+        for k in across:
+            across[k] = across[k] + per_class[u][k]
+    for k in across:
+        across[k] = across[k] / len(unique_labels)
+    return per_class, across
+
+
 def bce_loss(p, target):
     """nn.BCELoss (minimaxgan_l1.py:61,135,141,162): log terms clamped at -100."""
     lp = torch.clamp(torch.log(p), min=-100.0)

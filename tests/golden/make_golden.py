@@ -446,6 +446,48 @@ def case_ssim(ref_root, name):
     return fx
 
 
+SEG_CASES = [  # (seed, n, num_classes, h, w, unique_labels, labels contain -1)
+    (71, 3, 4, 32, 40, [0, 1, 2, 3], 0), (72, 2, 4, 64, 64, [0, 1, 2, 3], 0), (73, 2, 6, 24, 24, [1, 3, 5], 0),
+    (74, 2, 4, 16, 24, [0, 1, 2, 3], 1),
+]
+
+
+def case_evalmetrics(ref_root, name):
+    """lib/models/evaluate.py does not import (mixed tabs/spaces, undefined names), but
+    calculate_segmentation_eval_metric (:179-224) is a self-contained torch function: its text is read
+    from the reference AT GENERATION TIME, executed, and only its numeric outputs are stored. The
+    reconstruction metrics of :127-158 are recorded from the oracle (composition of the pinned losses)."""
+    src = open(os.path.join(ref_root, "lib/models/evaluate.py")).read()
+    start = src.index("def calculate_segmentation_eval_metric")
+    ns = {"torch": torch}
+    exec(compile(src[start:], "reference:evaluate.py", "exec"), ns)
+    ref_fn = ns["calculate_segmentation_eval_metric"]
+    fx = {"seg_cases": np.array([c[:5] + (c[6],) for c in SEG_CASES], dtype=np.int64)}
+    for i, (seed, n, K, h, w, uniq, neg) in enumerate(SEG_CASES):
+        labels, logits = op.synth_segmentation(seed, n, K, h, w, with_minus_one=bool(neg))
+        tl, to = torch.from_numpy(labels), torch.from_numpy(logits)
+        m, a = ref_fn(tl, to, uniq)
+        om, oa = orc.segmentation_eval_metric(tl, to, uniq)
+        per = np.array([[float(m[u][k]) for k in ("precision", "recall", "iou")] for u in uniq], np.float32)
+        acr = np.array([float(a[k]) for k in ("precision", "recall", "iou")], np.float32)
+        close(np.array([[float(om[u][k]) for k in ("precision", "recall", "iou")] for u in uniq]), per, 0, "seg per-class %d" % i)
+        close(np.array([float(oa[k]) for k in ("precision", "recall", "iou")]), acr, 0, "seg across %d" % i)
+        fx["seg_unique_%d" % i] = np.array(uniq, np.int64)
+        fx["seg_per_class_%d" % i] = per
+        fx["seg_across_%d" % i] = acr
+    # reconstruction metrics: two batches (one with fractional mask edges), both mask polarities
+    for j, flip in enumerate((False, True)):
+        tot = np.zeros(4)
+        for b in range(2):
+            g, mk = op.synth_batch(8100 + b, 3, 64, 64, fractional_edge=(b == 0))
+            gen = np.random.Generator(np.random.PCG64(8200 + b)).random((3, 1, 64, 64), dtype=np.float32)
+            r = orc.eval_recon_batch(torch.from_numpy(g), torch.from_numpy(gen), torch.from_numpy(mk), flip)
+            tot += np.array([float(v) for v in r[1:]])
+            fx["recon_out_sum_%d_%d" % (j, b)] = np.array(float(r[0].double().sum()))
+        fx["recon_%d" % j] = (tot / 2).astype(np.float64)
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -465,6 +507,7 @@ def main():
         optim=lambda: case_optim("optim"),
         init_parity=lambda: case_init(networks, "init_parity", 7),
         ssim=lambda: case_ssim(args.ref, "ssim"),
+        evalmetrics=lambda: case_evalmetrics(args.ref, "evalmetrics"),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):

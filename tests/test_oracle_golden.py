@@ -132,3 +132,24 @@ def test_ssim_metric():
         assert np.abs(orc.ssim(x, y, ws, size_average=False).numpy() - fx[f"per_sample_{i}"]).max() <= 1e-6
         assert abs(float(orc.ssim(x, x, ws)) - float(fx[f"self_{i}"])) <= 1e-6
         assert abs(float(fx[f"mean_{i}"]) - float(fx[f"mean64_{i}"])) <= 2e-6      # fp32 pipeline vs fp64
+
+
+def test_evaluation_metrics():
+    """oracle.segmentation_eval_metric == the reference's function (executed at fixture generation),
+    incl. the -1 label quirk; oracle.eval_recon_batch reproduces its recorded values."""
+    fx = load("evalmetrics")
+    for i, (seed, n, K, h, w, neg) in enumerate(fx["seg_cases"].tolist()):
+        labels, logits = op.synth_segmentation(seed, n, K, h, w, with_minus_one=bool(neg))
+        uniq = fx[f"seg_unique_{i}"].tolist()
+        m, a = orc.segmentation_eval_metric(torch.from_numpy(labels), torch.from_numpy(logits), uniq)
+        per = np.array([[float(m[u][k]) for k in ("precision", "recall", "iou")] for u in uniq])
+        assert np.abs(per - fx[f"seg_per_class_{i}"]).max() <= 1e-6
+        assert np.abs(np.array([float(a[k]) for k in ("precision", "recall", "iou")]) - fx[f"seg_across_{i}"]).max() <= 1e-6
+    for j, flip in enumerate((False, True)):
+        tot = np.zeros(4)
+        for b in range(2):
+            g, mk = op.synth_batch(8100 + b, 3, 64, 64, fractional_edge=(b == 0))
+            gen = np.random.Generator(np.random.PCG64(8200 + b)).random((3, 1, 64, 64), dtype=np.float32)
+            r = orc.eval_recon_batch(torch.from_numpy(g), torch.from_numpy(gen), torch.from_numpy(mk), flip)
+            tot += np.array([float(v) for v in r[1:]])
+        assert np.abs(tot / 2 - fx[f"recon_{j}"]).max() <= 1e-6

@@ -22,3 +22,15 @@ def test_plugin_runs_and_checkpoints(tmp_path, exp):
     assert "model.model.0.weight" in sd and tuple(sd["model.model.0.weight"].shape) == (64, 1, 4, 4)
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
     assert os.path.exists(os.path.join(str(tmp_path), "model", exp, "training_epoch_history.obj"))
+    import pickle
+    with open(os.path.join(str(tmp_path), "model", exp, "eval_history.obj"), "rb") as h:
+        ev = pickle.load(h)
+    # the evaluation pass of minimaxgan_l1.py:235-240: train + test reconstruction metrics
+    assert set(ev[-1]) == {"train", "test"}
+    for part in ev[-1].values():
+        assert all(0.0 <= part[k] < 10.0 for k in ("recon_rmse_global", "recon_l1_global", "recon_rmse_local", "recon_l1_local"))
+        assert part["recon_rmse_global"] >= part["recon_l1_global"] and part["fid"] == -1
+    if exp == "experiment1_global_local_D":
+        with open(os.path.join(str(tmp_path), "model", exp, "training_epoch_history.obj"), "rb") as h:
+            hist = pickle.load(h)
+        assert 0.0 < hist[-1]["losses"]["ssim"] <= 1.0                      # experiment1_global_local_D.py:209
