@@ -128,13 +128,45 @@ def ssim_workload(args, dev):
             "value_check": {"gpu": float(out), "oracle": ref}}
 
 
+def vgg_workload(args, dev):
+    """Secondary line (not the headline): perceptual + style terms of BASELINE configs[4] (512x512, 8 image
+    pairs per GPU): VGG-19 features of output and target (16 images), 5 taps, Gram matrices. One step = one
+    perceptual_and_style_loss call. Algorithmic work: 203.8 GFLOP per image x 16."""
+    from gan_inpainting_amd.lib.models import networks
+    n, hw = 8, 512
+    torch.manual_seed(99)
+    vgg = networks.VGG19Wrapper(max_pairs=n).to(dev)
+    out, tgt = torch.rand(n, 1, hw, hw, device=dev), torch.rand(n, 1, hw, hw, device=dev)
+    for _ in range(max(args.warmup, 2)):
+        r = vgg.perceptual_and_style(out, tgt, 0.01, 0.01)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        r = vgg.perceptual_and_style(out, tgt, 0.01, 0.01)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / args.steps
+    ms = e0.elapsed_time(e1) / args.steps
+    flop = 203.8e9 * 2 * n
+    return {"metric": "vgg_pairs_per_sec", "value": n / wall, "unit": "image pairs/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "perceptual_and_style_loss 512x512, 8 pairs (wgan_perceptual_style_faceparsing.py:216), random-init VGG-19"},
+            "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, "traffic": None,
+                         "note": "whole call (13 convolutions + pools + 5 Gram GEMMs + reductions), conv FLOP only"},
+            "losses": {"perceptual": float(r[0]), "style": float(r[1])}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256"],
+    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512"],
                     help="ssim_256 = the per-batch SSIM metric of experiment1_global_local_D.py:209 at 256x256 bs=32 (SURVEY 8f rank 2); wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
@@ -162,6 +194,9 @@ def main():
 
     if args.workload == "ssim_256":
         print(json.dumps(ssim_workload(args, dev)))
+        return
+    if args.workload == "vgg_512":
+        print(json.dumps(vgg_workload(args, dev)))
         return
 
     if args.kernel_only:

@@ -61,6 +61,18 @@ PROTOTYPES = {
     "gi_eval_recon_scratch_floats": (_i64, [_i64]),
     "gi_eval_recon": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _vp, _vp, _vp, _vp]),
     "gi_seg_metrics": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _i, _vp, _vp, _vp]),
+    "gi_loss_tv": (_i, [_vp, _vp, _i, _i, _i, _f, _vp, _vp, _f, _vp]),
+    "gi_loss_cross_entropy": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _i, _vp, _vp, _f, _vp]),
+    "gi_vgg19_create": (_i, [_vp, _i, _i, _i, _vp]),
+    "gi_vgg19_destroy": (None, [_vp]),
+    "gi_vgg19_param_floats": (_i64, [_vp]),
+    "gi_vgg19_workspace_bytes": (_i64, [_vp]),
+    "gi_vgg19_num_tensors": (_i, [_vp]),
+    "gi_vgg19_tensor_desc": (_i, [_vp, _i, _vp, _i, _vp, _vp]),
+    "gi_vgg19_bind": (_i, [_vp, _vp, _vp, _i64]),
+    "gi_vgg19_sync_weights": (_i, [_vp]),
+    "gi_vgg19_perceptual_style": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
+    "gi_vgg19_features": (_i, [_vp, _vp, _i, _i, _vp]),
     "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_convT_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_wgrad_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f]),

@@ -490,7 +490,7 @@ int run(hipStream_t st, IgemmArgs& a) {
 
 }  // namespace
 
-int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a);   // igemm3.hip: 256xBN tiles, LDS-DMA ring
+int op_igemm3(hipStream_t st, int mode, IgemmArgs& a);   // igemm3.hip: 256xBN tiles, LDS-DMA ring
 
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a) {
   // GI_IGEMM_VARIANT (tools / A-B timing only): 3 = LDS-DMA kernel (default), 1 = register-staged kernel only

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   const int wm = wave / WNW, wn = wave % WNW;
 
   // ---- XCD-aware tile order ------------------------------------------------------------------
-  const int nyz = p.ntiles * (PHASE ? 4 : 1);
+  const int nyz = p.ntiles * (PHASE == 1 ? 4 : 1);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
   const int mt_idx = (local / nyz) * 8 + xcd;
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   const int ph = yz / p.ntiles;
   const int py = ph >> 1, px = ph & 1;
   const int m0 = mt_idx * BM, n0 = nt_idx * BN;
-  const char* wptr = p.w + (PHASE ? (int64_t)ph * p.cout * p.Ktot * 2 : 0);
+  const char* wptr = p.w + (PHASE == 1 ? (int64_t)ph * p.cout * p.Ktot * 2 : 0);
 
   // ---- per-lane gather rows ------------------------------------------------------------------
   const int lrow = lane >> 3;                       // row inside the 8-row block
@@ -99,7 +99,15 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
       const int t = m / p.Ws;
       const int y = t % p.Hs;
       const int n = t / p.Hs;
-      if (PHASE) {
+      if (PHASE == 2) {          // 3x3 / stride 1 / pad 1 (VGG features): tap (ky,kx) reads (y-1+ky, x-1+kx)
+        const int y0 = y - 1, x0 = x - 1;
+        abase[j] = ((n * p.Hin + y0) * p.Win + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 9; ++tt) {
+          const int iy = y0 + tt / 3, ix = x0 + tt % 3;
+          if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) amask[j] |= 1u << tt;
+        }
+      } else if (PHASE) {
         const int y0 = y + py, x0 = x + px;
         abase[j] = ((n * p.Hs + y0) * p.Ws + x0) * p.ldin + p.coffin;
 #pragma unroll
@@ -123,7 +131,8 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   int tap = 0, c0 = 0;
   auto set_tap = [&]() {
     int toff;
-    if (PHASE) toff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
+    if (PHASE == 2) toff = ((tap / 3) * p.Win + (tap % 3)) * p.ldin;
+    else if (PHASE) toff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
     else toff = ((tap >> 2) * p.Win + (tap & 3)) * p.ldin;
 #pragma unroll
     for (int j = 0; j < AJ; ++j)
@@ -279,7 +288,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
 
   // ---- epilogue (same contract as igemm.hip) --------------------------------------------------------
   auto out_pixel = [&](int m) -> int {
-    if (!PHASE) return m;
+    if (PHASE != 1) return m;
     const int x = m % p.Ws;
     const int t = m / p.Ws;
     const int y = t % p.Hs;
@@ -347,16 +356,16 @@ char* g_zero_page[16] = {nullptr};
 
 }  // namespace
 
+// mode: 0 = Conv2d 4x4/s2/p1 gather, 1 = sub-pixel phases (ConvTranspose2d forward / Conv2d dgrad),
+//       2 = Conv2d 3x3/s1/p1 (VGG features; weights [cout][9*cin], tap-major).
 // returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
-int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
+int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
   const int M = a.n * a.Hs * a.Ws;
-  static int bn256 = -1;
-  if (bn256 < 0) { const char* e = getenv("GI_IGEMM3_BN256"); bn256 = e ? atoi(e) : 0; }   // measured equal to BN=128: off
-  int BN = (a.cout % 128 == 0) ? 128 : 64;
-  if (bn256 && a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) * (phase_mode ? 4 : 1) >= 256) BN = 256;
-  {   // too few tiles to fill 256 CUs: the split-K path of igemm.hip serves those layers
-    const int tiles = ((M + 255) / 256) * (a.cout / BN) * (phase_mode ? 4 : 1);
+  const int nph = mode == 1 ? 4 : 1;
+  const int BN = (a.cout % 128 == 0) ? 128 : 64;
+  if (mode != 2) {   // too few tiles to fill 256 CUs: the split-K path of igemm.hip serves those layers
+    const int tiles = ((M + 255) / 256) * (a.cout / BN) * nph;
     if (tiles < 128) return GI_ERR_UNSUPPORTED;
   }
   int dev = 0;
@@ -371,39 +380,41 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
   kp.M = M; kp.Hs = a.Hs; kp.Ws = a.Ws;
   kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
   kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
-  kp.Ktot = (phase_mode ? 4 : 16) * a.cin;
+  kp.Ktot = (mode == 1 ? 4 : (mode == 2 ? 9 : 16)) * a.cin;
   kp.nk = kp.Ktot / 64;
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
   { const char* e = getenv("GI_IGEMM3_DBG"); kp.dbg = e ? atoi(e) : 0; }
-  if (phase_mode) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
+  if (mode == 1) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
+  else if (mode == 2) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
   else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
   GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
              "igemm3: tensor too large for 32-bit offsets");
   kp.mtiles = (M + 255) / 256;
   kp.ntiles = a.cout / BN;
-  const int nyz = kp.ntiles * (phase_mode ? 4 : 1);
+  const int nyz = kp.ntiles * nph;
   const int grid = ((kp.mtiles + 7) / 8) * 8 * nyz;
-  const int LDS = (BN == 256 ? 2 : 3) * (256 + BN) * 128 > 256 * (BN + 8) * 2 + 4 * BN * 8 ? (BN == 256 ? 2 : 3) * (256 + BN) * 128
-                                                                                            : 256 * (BN + 8) * 2 + 4 * BN * 8;
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-  const void* fn[8] = {(const void*)igemm3_kernel<0, 128, 8>, (const void*)igemm3_kernel<1, 128, 8>, (const void*)igemm3_kernel<0, 64, 8>,
-                       (const void*)igemm3_kernel<1, 64, 8>, (const void*)igemm3_kernel<0, 128, 4>, (const void*)igemm3_kernel<1, 128, 4>,
-                       (const void*)igemm3_kernel<0, 64, 4>, (const void*)igemm3_kernel<1, 64, 4>};
-  static int nw_env = -1;
-  if (nw_env < 0) { const char* e = getenv("GI_IGEMM3_WAVES"); nw_env = e ? atoi(e) : 8; }
-  const int NWv = nw_env == 8 ? 8 : 4;
-  const int vi = (NWv == 4 ? 4 : 0) + (BN == 64 ? 2 : 0) + (phase_mode ? 1 : 0);
-  if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128)); attr_set[vi] = true; }
-  const dim3 g(grid), b(NWv * 64);
-  if (kp.dbg && vi == 1) {   // timing-only ablation builds of the PHASE / 128 / 8-wave kernel (GI_IGEMM3_DBG)
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 31>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
-    hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128);
+  constexpr int LDS_MAX = 3 * (256 + 128) * 128;
+  const int ring = 3 * (256 + BN) * 128, epi = 256 * (BN + 8) * 2 + 4 * BN * 8;
+  const int LDS = ring > epi ? ring : epi;
+  static bool attr_set[6] = {false, false, false, false, false, false};
+  const void* fn[6] = {(const void*)igemm3_kernel<0, 128, 8>, (const void*)igemm3_kernel<1, 128, 8>, (const void*)igemm3_kernel<2, 128, 8>,
+                       (const void*)igemm3_kernel<0, 64, 8>,  (const void*)igemm3_kernel<1, 64, 8>,  (const void*)igemm3_kernel<2, 64, 8>};
+  const int vi = (BN == 64 ? 3 : 0) + mode;
+  if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); attr_set[vi] = true; }
+  const dim3 g(grid), b(512);
+  if (kp.dbg && vi == 1) {   // timing-only ablation builds of the PHASE / 128 kernel (GI_IGEMM3_DBG, tools only)
+    static bool dbg_attr = false;
+    if (!dbg_attr) {
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      GI_HIP(hipFuncSetAttribute((const void*)igemm3_kernel<1, 128, 8, 31>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX));
+      dbg_attr = true;
+    }
     switch (kp.dbg) {
       case 1: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 1>), g, b, LDS, st, kp); break;
       case 2: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 2>), g, b, LDS, st, kp); break;
@@ -414,33 +425,18 @@ int op_igemm3(hipStream_t st, int phase_mode, IgemmArgs& a) {
       default: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8, 31>), g, b, LDS, st, kp); break;
     }
     GI_LAUNCH_CHECK();
-    a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
-    return GI_OK;
-  }
-  if (BN == 256) {
-    static bool a256[2] = {false, false};
-    if (!a256[phase_mode ? 1 : 0]) {
-      GI_HIP(hipFuncSetAttribute(phase_mode ? (const void*)igemm3_kernel<1, 256, 8> : (const void*)igemm3_kernel<0, 256, 8>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (256 + 128) * 128));
-      a256[phase_mode ? 1 : 0] = true;
-    }
-    if (phase_mode) hipLaunchKernelGGL((igemm3_kernel<1, 256, 8>), g, dim3(512), LDS, st, kp);
-    else hipLaunchKernelGGL((igemm3_kernel<0, 256, 8>), g, dim3(512), LDS, st, kp);
-    GI_LAUNCH_CHECK();
-    a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
+    a.ntiles_out = kp.mtiles * nph;
     return GI_OK;
   }
   switch (vi) {
     case 0: hipLaunchKernelGGL((igemm3_kernel<0, 128, 8>), g, b, LDS, st, kp); break;
     case 1: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8>), g, b, LDS, st, kp); break;
-    case 2: hipLaunchKernelGGL((igemm3_kernel<0, 64, 8>), g, b, LDS, st, kp); break;
-    case 3: hipLaunchKernelGGL((igemm3_kernel<1, 64, 8>), g, b, LDS, st, kp); break;
-    case 4: hipLaunchKernelGGL((igemm3_kernel<0, 128, 4>), g, b, LDS, st, kp); break;
-    case 5: hipLaunchKernelGGL((igemm3_kernel<1, 128, 4>), g, b, LDS, st, kp); break;
-    case 6: hipLaunchKernelGGL((igemm3_kernel<0, 64, 4>), g, b, LDS, st, kp); break;
-    default: hipLaunchKernelGGL((igemm3_kernel<1, 64, 4>), g, b, LDS, st, kp); break;
+    case 2: hipLaunchKernelGGL((igemm3_kernel<2, 128, 8>), g, b, LDS, st, kp); break;
+    case 3: hipLaunchKernelGGL((igemm3_kernel<0, 64, 8>), g, b, LDS, st, kp); break;
+    case 4: hipLaunchKernelGGL((igemm3_kernel<1, 64, 8>), g, b, LDS, st, kp); break;
+    default: hipLaunchKernelGGL((igemm3_kernel<2, 64, 8>), g, b, LDS, st, kp); break;
   }
   GI_LAUNCH_CHECK();
-  a.ntiles_out = kp.mtiles * (phase_mode ? 4 : 1);
+  a.ntiles_out = kp.mtiles * nph;
   return GI_OK;
 }

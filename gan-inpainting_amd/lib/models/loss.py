@@ -129,3 +129,105 @@ class LSGANLoss(nn.Module):
 def critic_mean(pred):
     """torch.mean(d_pred).view(1) of the WGAN plugins (wgan_l1.py:137-143,177)."""
     return _AdvFn.apply(pred, 2, 0.0).view(1)
+
+
+# ---- config-5 extras: perceptual / style / TV / weighted cross entropy (SURVEY 8a row a12) ------------
+vgg = None   # the reference builds VGG19Wrapper().to(device) at import (loss.py:4-5); here on first use or via set_vgg
+
+
+def set_vgg(wrapper):
+    """Install the feature network (e.g. after load_state_dict of torchvision's pretrained vgg19)."""
+    global vgg
+    vgg = wrapper
+    return wrapper
+
+
+def _vgg_for(x):
+    global vgg
+    if vgg is None:
+        import warnings
+        from . import networks
+        warnings.warn("perceptual/style loss: no VGG-19 weights installed (loss.set_vgg); using a random He-initialised "
+                      "feature network - the pretrained download of the reference (networks.py:371) is not available here")
+        vgg = networks.VGG19Wrapper(max_pairs=max(8, x.shape[0])).to(x.device)
+    return vgg
+
+
+def perceptual_and_style_loss(output, target, weight_p=0.05, weight_s=100):
+    """loss.py:93-115. Constants w.r.t. the generator, exactly like the reference (no_grad + detach)."""
+    return _vgg_for(output).perceptual_and_style(output, target, weight_p, weight_s)
+
+
+def perceptual_loss(output, target, weight=0.05):
+    """loss.py:50-69."""
+    return _vgg_for(output).perceptual_and_style(output, target, weight, 0.0)[0]
+
+
+def style_loss(output, target, weight=0.1):
+    """loss.py:71-90."""
+    return _vgg_for(output).perceptual_and_style(output, target, 0.0, weight)[1]
+
+
+class _TVFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, tv_weight):
+        x = img.contiguous()
+        if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 4:
+            raise B.BackendError("tv_loss takes a (n,c,H,W) float32 tensor on the gfx950 device")
+        n, c, h, w = x.shape
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x) if img.requires_grad else None
+        scr = torch.empty(2048, dtype=torch.float64, device=x.device)
+        B.check(B.lib().gi_loss_tv(B.get_ctx(x.device), B.ptr(x), n * c, h, w, float(tv_weight), B.ptr(out), B.ptr(grad), 1.0, B.ptr(scr)))
+        ctx.grad = grad
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None
+
+
+def tv_loss(img, tv_weight):
+    """loss.py:138-151, with its gradient (the only config-5 extra besides the face-parsing term that
+    reaches the generator)."""
+    return _TVFn.apply(img, tv_weight)
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight, ignore_index):
+        z = logits.contiguous()
+        y = labels.contiguous()
+        if z.dtype != torch.float32 or not z.is_cuda or y.dtype != torch.int64 or y.device != z.device:
+            raise B.BackendError("CrossEntropyLoss takes float32 logits and int64 labels on the gfx950 device")
+        n, k = z.shape[0], z.shape[1]
+        hw = z.numel() // (n * k)
+        if y.numel() != n * hw:
+            raise ValueError("labels %s do not match logits %s" % (tuple(y.shape), tuple(z.shape)))
+        import ctypes as C
+        hwt = (C.c_float * k)(*[float(v) for v in weight]) if weight is not None else None
+        out = torch.empty(2, dtype=torch.float32, device=z.device)
+        grad = torch.empty_like(z) if logits.requires_grad else None
+        scr = torch.empty(2048, dtype=torch.float64, device=z.device)
+        B.check(B.lib().gi_loss_cross_entropy(B.get_ctx(z.device), B.ptr(z), B.ptr(y), n, k, hw,
+                                              C.cast(hwt, C.c_void_p) if hwt is not None else None, int(ignore_index),
+                                              B.ptr(out), B.ptr(grad), 1.0, B.ptr(scr)))
+        ctx.grad = grad
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (ctx.grad * g if ctx.grad is not None else None), None, None, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss(weight=w) on (n,K,H,W) logits / (n,H,W) labels
+    (wgan_perceptual_style_faceparsing.py:67-68,212-213), K in {2,3,4,8,16}."""
+
+    def __init__(self, weight=None, ignore_index=-100):
+        super().__init__()
+        self.weight = None if weight is None else [float(v) for v in torch.as_tensor(weight).tolist()]
+        self.ignore_index = ignore_index
+
+    def forward(self, logits, labels):
+        return _CEFn.apply(logits, labels, self.weight, self.ignore_index)

@@ -515,3 +515,125 @@ class PatchGANDiscriminator(HipNet):
         B.check(lib.gi_patchgan_gradient_penalty(self._handle, B.ptr(xhat), n, float(lam), B.ptr(out)))
         self._nbt_pending += 1   # the penalty's own forward runs the BatchNorm layers in train mode
         return out.view(())
+
+
+class VGG19Wrapper(nn.Module):
+    """The feature network behind the perceptual / style losses (reference networks.py:367-389:
+    torchvision `vgg19(pretrained=True)` with hooks on features[1,6,11,20,29]; loss.py:4 builds one at
+    import). Here: the 13 convolutions up to features.28 as one flat fp32 parameter buffer driven by
+    `gi_vgg19_*` (fp16 MFMA 3x3 implicit GEMM, forward only - the reference calls it under no_grad).
+
+    The pretrained weights cannot be downloaded in this environment: the constructor initialises like
+    torchvision does for `pretrained=False` (He-normal fan_out, zero bias); `load_state_dict` accepts a
+    torchvision vgg19 state_dict (keys `features.<i>.weight|bias`, optionally prefixed `vgg19.`) and
+    ignores the classifier / unused tail."""
+
+    CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28)
+    CHANNELS = (64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512)
+
+    def __init__(self, max_pairs=8):
+        super().__init__()
+        self.max_pairs = max_pairs
+        sizes, cin = [], 3
+        for cout in self.CHANNELS:
+            sizes.append((cout, cin))
+            cin = cout
+        self._shapes = sizes
+        flat = []
+        for cout, ci in sizes:
+            w = torch.empty(cout, ci, 3, 3)
+            nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+            flat += [w.reshape(-1), torch.zeros(cout)]
+        self.register_buffer("flat", torch.cat(flat))
+        self._handles = {}
+        self._dirty = True
+
+    # ---- state_dict in torchvision's naming --------------------------------------------------------
+    def _views(self):
+        off, out = 0, {}
+        for i, (cout, ci) in zip(self.CONV_IDX, self._shapes):
+            out[f"features.{i}.weight"] = self.flat[off: off + cout * ci * 9].view(cout, ci, 3, 3)
+            off += cout * ci * 9
+            out[f"features.{i}.bias"] = self.flat[off: off + cout]
+            off += cout
+        return out
+
+    def state_dict(self, *args, **kw):
+        return {k: v.detach().clone() for k, v in self._views().items()}
+
+    def load_state_dict(self, sd, strict=True):
+        views = self._views()
+        seen = set()
+        for k, v in sd.items():
+            k = k[len("vgg19."):] if k.startswith("vgg19.") else k
+            if k in views:
+                views[k].copy_(torch.as_tensor(v).to(views[k].device, torch.float32))
+                seen.add(k)
+        missing = [k for k in views if k not in seen]
+        if strict and missing:
+            raise RuntimeError("VGG19Wrapper.load_state_dict: missing keys %s" % missing)
+        self._dirty = True
+        return missing
+
+    def _handle(self, h, w, dev):
+        key = (h, w, dev.index, torch.cuda.current_stream(dev).cuda_stream)
+        if key not in self._handles:
+            lib, ctx = B.lib(), B.get_ctx(dev)
+            hd = C.c_void_p()
+            B.check(lib.gi_vgg19_create(ctx, h, w, self.max_pairs, C.byref(hd)))
+            if lib.gi_vgg19_param_floats(hd) != self.flat.numel():
+                raise B.BackendError("VGG19Wrapper: parameter layout mismatch")
+            ws = torch.empty(lib.gi_vgg19_workspace_bytes(hd) + 256, dtype=torch.uint8, device=dev)
+            off = (-ws.data_ptr()) % 256
+            B.check(lib.gi_vgg19_bind(hd, B.ptr(self.flat), ws.data_ptr() + off, ws.numel() - off))
+            self._handles[key] = (hd, ws)
+            self._dirty = True
+        hd = self._handles[key][0]
+        if self._dirty:
+            for h2, _ in self._handles.values():
+                B.check(B.lib().gi_vgg19_sync_weights(h2))
+            self._dirty = False
+        return hd
+
+    def _check(self, x):
+        if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 1:
+            raise B.BackendError("VGG19Wrapper takes (n,1,H,W) float32 tensors on the gfx950 device")
+        if self.flat.device != x.device:
+            raise B.BackendError("VGG19Wrapper parameters live on %s, input on %s: call .to(device)" % (self.flat.device, x.device))
+        if x.shape[0] > self.max_pairs:
+            raise B.BackendError("VGG19Wrapper(max_pairs=%d) got a batch of %d" % (self.max_pairs, x.shape[0]))
+
+    @torch.no_grad()
+    def perceptual_and_style(self, output, target, weight_p, weight_s, per_tap=False):
+        """(weight_p * sum_taps mse(F_o, F_t), weight_s * sum_taps mse(G_o, G_t)) as device scalars."""
+        self._check(output)
+        self._check(target)
+        output, target = output.detach().contiguous(), target.detach().contiguous()
+        hd = self._handle(output.shape[2], output.shape[3], output.device)
+        out = torch.empty(2, dtype=torch.float32, device=output.device)
+        taps = torch.empty(10, dtype=torch.float32, device=output.device) if per_tap else None
+        B.check(B.lib().gi_vgg19_perceptual_style(hd, B.ptr(output), B.ptr(target), output.shape[0], float(weight_p), float(weight_s),
+                                                  B.ptr(out), B.ptr(taps)))
+        return (out[0], out[1], taps) if per_tap else (out[0], out[1])
+
+    @torch.no_grad()
+    def features(self, x, tap):
+        """Feature map of tap 0..4 (relu1_1 .. relu5_1) as (n,C,h,w) float32."""
+        self._check(x)
+        x = x.detach().contiguous()
+        hd = self._handle(x.shape[2], x.shape[3], x.device)
+        c = (64, 128, 256, 512, 512)[tap]
+        s = 1 << tap
+        out = torch.empty(x.shape[0], c, x.shape[2] // s, x.shape[3] // s, dtype=torch.float32, device=x.device)
+        B.check(B.lib().gi_vgg19_features(hd, B.ptr(x), x.shape[0], tap, B.ptr(out)))
+        return out
+
+    def forward(self, x):
+        raise NotImplementedError("the classifier head of vgg19 is not part of the loss path (reference loss.py uses features only)")
+
+    def __del__(self):
+        try:
+            for hd, _ in self._handles.values():
+                B.lib().gi_vgg19_destroy(hd)
+        except Exception:
+            pass

@@ -184,6 +184,41 @@ int gi_eval_recon(gi_ctx* ctx, const float* ground, const float* gen, const floa
 int gi_seg_metrics(gi_ctx* ctx, const int64_t* labels, const float* logits, int n, int num_classes, int64_t hw,
                    const int* unique_labels_host, int nu, float* per_class, float* across, int* scratch_counts);
 
+/* ---- config-5 generator-loss extras ------------------------------------
+ * tv_loss (lib/models/loss.py:138-151): tv_weight * (mean_h-diff^2 + mean_w-diff^2) over `planes` = n*c
+ * planes of H x W fp32; grad (may be NULL) = d loss / d img * gscale. loss_out: 1 float.
+ * scratch: >= 4096 floats, 8-byte aligned. */
+int gi_loss_tv(gi_ctx* ctx, const float* img, int planes, int H, int W, float tv_weight, float* loss_out,
+               float* grad, float gscale, float* scratch);
+/* nn.CrossEntropyLoss(weight=w) on (n,num_classes,hw) fp32 logits and (n,hw) int64 labels
+ * (wgan_perceptual_style_faceparsing.py:67-68,212-213): sum_p w[y_p] * nll_p / sum_p w[y_p]; labels equal
+ * to ignore_index (torch default -100) carry no weight. class_weight_host: num_classes HOST floats or NULL
+ * (ones). num_classes in {2,3,4,8,16}. loss_out: 2 floats {loss, sum of weights}; grad_logits may be NULL. */
+int gi_loss_cross_entropy(gi_ctx* ctx, const float* logits, const int64_t* labels, int n, int num_classes,
+                          int64_t hw, const float* class_weight_host, int ignore_index, float* loss_out,
+                          float* grad_logits, float gscale, float* scratch);
+
+/* VGG-19 features for perceptual_loss / style_loss / perceptual_and_style_loss (lib/models/loss.py:50-115)
+ * and gram_matrix (:117-136): taps relu1_1, relu2_1, relu3_1, relu4_1, relu5_1 (features[1,6,11,20,29]) of
+ * the grey image repeated over 3 channels (:54-55). Forward only (the reference runs it under no_grad).
+ * params: fp32, torchvision layout, the 13 convolutions up to features.28 (gi_vgg19_tensor_desc gives
+ * name "features.<i>.weight|bias", shape, offset); fp16 MFMA compute. max_pairs = largest n. */
+typedef struct gi_vgg gi_vgg;
+int gi_vgg19_create(gi_ctx* ctx, int H, int W, int max_pairs, gi_vgg** out);
+void gi_vgg19_destroy(gi_vgg* v);
+int64_t gi_vgg19_param_floats(const gi_vgg* v);
+int64_t gi_vgg19_workspace_bytes(const gi_vgg* v);
+int gi_vgg19_num_tensors(const gi_vgg* v);
+int gi_vgg19_tensor_desc(const gi_vgg* v, int index, char* name, int name_cap, int* shape4, int64_t* offset);
+int gi_vgg19_bind(gi_vgg* v, const float* params, void* ws, int64_t ws_bytes);   /* ws 256-byte aligned */
+int gi_vgg19_sync_weights(gi_vgg* v);                                            /* after params change */
+/* out2 = { weight_p * sum_taps mean((F_o-F_t)^2), weight_s * sum_taps mean((G_o-G_t)^2) }, G = F F^T/(HWC);
+ * output/target: (n,1,H,W) fp32; per_tap10 (may be NULL): the 5 perceptual then the 5 style terms. */
+int gi_vgg19_perceptual_style(gi_vgg* v, const float* output, const float* target, int n, float weight_p,
+                              float weight_s, float* out2, float* per_tap10);
+/* feature map of tap 0..4 as (n,C,h,w) fp32 (parity checks) */
+int gi_vgg19_features(gi_vgg* v, const float* x, int n, int tap, float* out_nchw);
+
 /* ---- single-layer entry points (unit parity tests and kernel roofline measurements) -------- */
 /* out[n,y,x,a] = act( sum_{ky,kx,b} in[n,2y-1+ky,2x-1+kx,b] * w[a][ky][kx][b] ), NHWC, dtype T.
  * in: (n,H,W,cb) ld=ldin; out: (n,H/2,W/2,ca) ld=ldout. w_packed is T [ca][16*cb].

@@ -162,3 +162,35 @@ def synth_segmentation(seed, n, num_classes, h, w, with_minus_one=False):
     if with_minus_one:
         labels[:, 1, :] = -1
     return labels, logits
+
+
+# torchvision vgg19 "features" layout (configuration E), restated from the public architecture:
+# conv3x3(+ReLU) channel counts with 'M' = 2x2 max pooling. Module indices 0..36.
+VGG19_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+def vgg19_conv_indices():
+    """features.<i> index of every convolution, in order (0, 2, 5, 7, 10, ...)."""
+    idx, i = [], 0
+    for v in VGG19_CFG:
+        if v == "M":
+            i += 1
+        else:
+            idx.append(i)
+            i += 2
+    return idx
+
+
+def make_vgg19_params(seed, n_convs=16):
+    """Deterministic stand-in for the (unavailable) pretrained weights: He-normal fan_out like
+    torchvision's initialiser, small non-zero biases so the bias path is exercised. Keys as in
+    torchvision's state_dict: features.<i>.weight / .bias."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P, cin = {}, 3
+    chans = [v for v in VGG19_CFG if v != "M"]
+    for i, cout in zip(vgg19_conv_indices()[:n_convs], chans[:n_convs]):
+        std = (2.0 / (cout * 9)) ** 0.5
+        P[f"features.{i}.weight"] = (rng.standard_normal((cout, cin, 3, 3)) * std).astype(np.float32)
+        P[f"features.{i}.bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
+        cin = cout
+    return P

@@ -205,6 +205,60 @@ def segmentation_eval_metric(labels, outputs, unique_labels):
     return per_class, across
 
 
+VGG_TAPS = (1, 6, 11, 20, 29)     # relu1_1, relu2_1, relu3_1, relu4_1, relu5_1 (lib/models/loss.py:53,73,93)
+
+
+def vgg19_tap_features(P, x, last=29):
+    """Feature maps after features[1,6,11,20,29] of a VGG-19 `features` stack with parameters P
+    (torchvision keys) applied to the grey batch x repeated over 3 channels (loss.py:54-61)."""
+    from . import params as op
+    h = x.repeat(1, 3, 1, 1)
+    taps, i = [], 0
+    for v in op.VGG19_CFG:
+        if v == "M":
+            h = F.max_pool2d(h, 2, 2)
+            i += 1
+        else:
+            h = F.relu(F.conv2d(h, P[f"features.{i}.weight"], P[f"features.{i}.bias"], padding=1))
+            if i + 1 in VGG_TAPS:
+                taps.append(h)
+            i += 2
+        if i > last:
+            break
+    return taps
+
+
+def gram_matrix(features, normalize=True):
+    """loss.py:117-136."""
+    N, C, H, W = features.shape
+    f = features.reshape(N, C, -1)
+    g = torch.bmm(f, f.transpose(1, 2))
+    return g / (H * W * C) if normalize else g
+
+
+def perceptual_and_style_loss(P, output, target, weight_p=0.05, weight_s=100):
+    """loss.py:93-115 (no gradient: the reference runs it under no_grad on detached inputs). Also
+    returns the per-tap terms."""
+    with torch.no_grad():
+        fo, ft = vgg19_tap_features(P, output.detach()), vgg19_tap_features(P, target.detach())
+        p_terms = [torch.mean(torch.pow(a - b, 2)) for a, b in zip(fo, ft)]
+        s_terms = [torch.mean(torch.pow(gram_matrix(a) - gram_matrix(b), 2)) for a, b in zip(fo, ft)]
+        return weight_p * sum(p_terms), weight_s * sum(s_terms), p_terms, s_terms
+
+
+def tv_loss(img, tv_weight):
+    """loss.py:138-151."""
+    w_variance = torch.mean(torch.pow(img[:, :, :, :-1] - img[:, :, :, 1:], 2))
+    h_variance = torch.mean(torch.pow(img[:, :, :-1, :] - img[:, :, 1:, :], 2))
+    return tv_weight * (h_variance + w_variance)
+
+
+def weighted_cross_entropy(logits, labels, weight):
+    """nn.CrossEntropyLoss(weight=w)(logits, labels) as called at
+    wgan_perceptual_style_faceparsing.py:67-68,212-213."""
+    return F.cross_entropy(logits, labels, weight=weight)
+
+
 def bce_loss(p, target):
     """nn.BCELoss (minimaxgan_l1.py:61,135,141,162): log terms clamped at -100."""
     lp = torch.clamp(torch.log(p), min=-100.0)

@@ -488,6 +488,76 @@ def case_evalmetrics(ref_root, name):
     return fx
 
 
+class _VggStandIn:
+    """What loss.py:4 builds from torchvision (absent here): an object whose `.vgg19.features._modules`
+    is the ordered module list of VGG-19 `features` (architecture restated in oracle/params.VGG19_CFG),
+    loaded with the deterministic stand-in weights."""
+
+    def __init__(self, P):
+        layers, cin = [], 3
+        for v in op.VGG19_CFG:
+            if v == "M":
+                layers.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [torch.nn.Conv2d(cin, v, kernel_size=3, padding=1), torch.nn.ReLU(inplace=True)]
+                cin = v
+        self.vgg19 = types.SimpleNamespace(features=torch.nn.Sequential(*layers))
+        self.vgg19.features.load_state_dict({k[len("features."):]: torch.from_numpy(v) for k, v in P.items()}, strict=True)
+
+
+AUX_CASES = [(91, 2, 64), (92, 1, 128)]   # (seed, n, H=W)
+
+
+def case_auxloss(ref_root, name):
+    """The function texts of lib/models/loss.py from `def perceptual_loss` on (perceptual / style /
+    gram / tv: pure torch, they only iterate a module list) are read from the reference AT GENERATION
+    TIME and executed over the stand-in VGG; the file itself cannot be imported (its line 4 needs
+    torchvision's pretrained download). Cross entropy is torch.nn.CrossEntropyLoss as the plugin calls it."""
+    src = open(os.path.join(ref_root, "lib/models/loss.py")).read()
+    ns = {"torch": torch}
+    exec(compile(src[src.index("def perceptual_loss"):], "reference:loss.py", "exec"), ns)
+    fx = {"aux_cases": np.array(AUX_CASES, dtype=np.int64)}
+    for i, (seed, n, hw) in enumerate(AUX_CASES):
+        P = op.make_vgg19_params(seed)
+        ns["vgg"] = _VggStandIn(P)
+        TP = {k: torch.from_numpy(v) for k, v in P.items()}
+        g, mk = op.synth_batch(seed + 1, n, hw, hw)
+        gen = np.random.Generator(np.random.PCG64(seed + 2)).random((n, 1, hw, hw), dtype=np.float32)
+        ground = torch.from_numpy(g)
+        out = torch.from_numpy(gen * np.ceil(mk) + g * (1 - np.ceil(mk)))            # an inpainted composite
+        p, s = ns["perceptual_and_style_loss"](out, ground, weight_p=0.01, weight_s=0.01)   # plugin weights :216
+        p1 = ns["perceptual_loss"](out, ground)
+        s1 = ns["style_loss"](out, ground)
+        op_, os_, pt, st = orc.perceptual_and_style_loss(TP, out, ground, 0.01, 0.01)
+        close(op_, p, 1e-6, "perceptual %d" % i)
+        close(os_, s, 1e-6, "style %d" % i)
+        close(0.05 * sum(pt), p1, 1e-6, "perceptual_loss %d" % i)
+        close(0.1 * sum(st), s1, 1e-6, "style_loss %d" % i)
+        tv = ns["tv_loss"](out, 1)
+        close(orc.tv_loss(out, 1), tv, 0, "tv %d" % i)
+        feats = orc.vgg19_tap_features(TP, out)
+        close(orc.gram_matrix(feats[1]), ns["gram_matrix"](feats[1]), 0, "gram %d" % i)
+        fx["perceptual_%d" % i] = np.array(float(p)); fx["style_%d" % i] = np.array(float(s))
+        fx["p_terms_%d" % i] = np.array([float(v) for v in pt]); fx["s_terms_%d" % i] = np.array([float(v) for v in st])
+        fx["tv_%d" % i] = np.array(float(tv))
+        fx["tap_absmean_%d" % i] = np.array([float(f.abs().mean()) for f in feats])
+        fx["tap3_head_%d" % i] = feats[3][0, :8, :4, :4].numpy()
+        # tv gradient and the weighted cross entropy (+ gradient) via autograd
+        x = out.clone().requires_grad_(True)
+        ns["tv_loss"](x, 1).backward()
+        fx["tv_grad_sum_abs_%d" % i] = np.array(float(x.grad.abs().sum()))
+        fx["tv_grad_head_%d" % i] = x.grad[0, 0, :4, :6].numpy()
+        labels, logits = op.synth_segmentation(seed + 3, n, 4, hw, hw)
+        z = torch.tanh(torch.from_numpy(logits)).requires_grad_(True)               # the seg U-Net ends in Tanh
+        w = torch.tensor([0, 1.2, 0.7, 0.7])
+        ce = torch.nn.CrossEntropyLoss(weight=w)(z, torch.from_numpy(labels))
+        ce.backward()
+        close(orc.weighted_cross_entropy(z.detach(), torch.from_numpy(labels), w), ce.detach(), 0, "ce %d" % i)
+        fx["ce_%d" % i] = np.array(float(ce)); fx["ce_grad_sum_abs_%d" % i] = np.array(float(z.grad.abs().sum()))
+        fx["ce_grad_head_%d" % i] = z.grad[0, :, :3, :5].numpy()
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -508,6 +578,7 @@ def main():
         init_parity=lambda: case_init(networks, "init_parity", 7),
         ssim=lambda: case_ssim(args.ref, "ssim"),
         evalmetrics=lambda: case_evalmetrics(args.ref, "evalmetrics"),
+        auxloss=lambda: case_auxloss(args.ref, "auxloss"),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):

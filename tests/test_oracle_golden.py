@@ -153,3 +153,21 @@ def test_evaluation_metrics():
             r = orc.eval_recon_batch(torch.from_numpy(g), torch.from_numpy(gen), torch.from_numpy(mk), flip)
             tot += np.array([float(v) for v in r[1:]])
         assert np.abs(tot / 2 - fx[f"recon_{j}"]).max() <= 1e-6
+
+
+def test_config5_losses():
+    """oracle perceptual / style / tv / weighted CE == the values recorded by executing the reference's
+    own loss.py functions over the stand-in VGG-19 (tests/golden/make_golden.py case_auxloss)."""
+    fx = load("auxloss")
+    seed, n, hw = fx["aux_cases"][0].tolist()
+    P = {k: torch.from_numpy(v) for k, v in op.make_vgg19_params(seed).items()}
+    g, mk = op.synth_batch(seed + 1, n, hw, hw)
+    gen = np.random.Generator(np.random.PCG64(seed + 2)).random((n, 1, hw, hw), dtype=np.float32)
+    out = torch.from_numpy((gen * np.ceil(mk) + g * (1 - np.ceil(mk))).astype(np.float32))
+    p, s, pt, st = orc.perceptual_and_style_loss(P, out, torch.from_numpy(g), 0.01, 0.01)
+    assert relerr(float(p), float(fx["perceptual_0"])) < 1e-5 and relerr(float(s), float(fx["style_0"])) < 1e-4
+    assert relerr(np.array([float(v) for v in pt]), fx["p_terms_0"]) < 1e-5
+    assert relerr(float(orc.tv_loss(out, 1)), float(fx["tv_0"])) < 1e-6
+    labels, logits = op.synth_segmentation(seed + 3, n, 4, hw, hw)
+    ce = orc.weighted_cross_entropy(torch.tanh(torch.from_numpy(logits)), torch.from_numpy(labels), torch.tensor([0, 1.2, 0.7, 0.7]))
+    assert relerr(float(ce), float(fx["ce_0"])) < 1e-6
