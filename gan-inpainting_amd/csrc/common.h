@@ -153,6 +153,7 @@ struct ActBnBwdArgs {
   int64_t pixels; int c;
   int act; float drop_scale;
   int has_bn;
+  int eval_bn;                        // BatchNorm ran on running statistics (frozen eval net): dx = gamma*inv*dz, no batch terms
   const float* gamma; const float* save_mean; const float* save_invstd;
   float* dgamma; float* dbeta;        // accumulated (+=) with 1/loss_scale when non-null
   float inv_loss_scale;

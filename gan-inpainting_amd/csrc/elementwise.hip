@@ -700,7 +700,12 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   int blocks = 0;
   p.rows_per_block = rows_per_block_for(a.pixels, &blocks);
   const int grid2 = nblocks(a.pixels * Q, 2);
-  if (a.has_bn) {
+  if (a.has_bn && a.eval_bn) {
+    // running-statistics BatchNorm is a per-channel affine map: the batch-mean terms vanish (sums = 0)
+    GI_HIP(hipMemsetAsync(a.sums, 0, sizeof(float) * 2 * a.c, st));
+    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1>), dim3(grid2), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1>), dim3(grid2), dim3(256), 0, st, p);
+  } else if (a.has_bn) {
     if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p);
     GI_LAUNCH_CHECK();

@@ -52,6 +52,9 @@ struct gi_net {
   uint64_t drop_seed = 0x5EED0000ull, drop_counter = 0;
   // unet
   int nd = 0, ngf = 0;
+  int bwd_eval = 0;                  // (transient) the backward in progress differentiates an eval-mode forward
+  int out_c = 1;                     // output channels; > 1: u1 runs on the generic kernels with b zero-padded to 64
+  int64_t oU1 = -1, oUp1Pad = -1, oUp1Packed = -1, oUp1Phase = -1;
   float dropout_p = 0.f;
   std::vector<int> ch, Hk, Wk;       // 1-based per level
   std::vector<Conv> conv, up;        // 1-based
@@ -128,18 +131,20 @@ int64_t part_rows(int64_t pixels) { return max64(pixels / 64 + 8, 1100); }
 // =================================================================================================
 // creation
 // =================================================================================================
-extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, int W, int max_n, int dtype,
-                              int n_slots, gi_net** out) {
+extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float dropout_p, int H, int W, int max_n,
+                                 int dtype, int n_slots, gi_net** out) {
   GI_REQUIRE(out, "unet_create: null argument");  // ctx may be null: inventory-only handle
   GI_REQUIRE(dtype == GI_F16 || dtype == GI_F32, "unet_create: dtype=%d", dtype);
   GI_REQUIRE(num_downs >= 5 && num_downs <= 9, "unet_create: num_downs=%d (supported 5..9)", num_downs);
-  GI_REQUIRE(ngf % 64 == 0 && ngf >= 64, "unet_create: ngf=%d must be a multiple of 64", ngf);
+  if (ctx) GI_REQUIRE(ngf % 64 == 0 && ngf >= 64, "unet_create: ngf=%d must be a multiple of 64", ngf);
+  else GI_REQUIRE(ngf % 8 == 0 && ngf >= 8, "unet_create: ngf=%d must be a multiple of 8 (inventory-only handle)", ngf);
+  GI_REQUIRE(out_c >= 1 && out_c <= 64, "unet_create: out_c=%d (1..64)", out_c);
   GI_REQUIRE(gi_is_pow2(H) && gi_is_pow2(W) && (H >> num_downs) >= 1 && (W >> num_downs) >= 1,
              "unet_create: H=%d W=%d must be powers of two >= 2^num_downs", H, W);
   GI_REQUIRE(max_n >= 1 && n_slots >= 1 && n_slots <= 8, "unet_create: max_n=%d n_slots=%d", max_n, n_slots);
   gi_net* net = new gi_net();
   net->ctx = ctx; net->kind = 0; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
-  net->nd = num_downs; net->ngf = ngf; net->dropout_p = dropout_p;
+  net->nd = num_downs; net->ngf = ngf; net->dropout_p = dropout_p; net->out_c = out_c;
   net->loss_scale = dtype == GI_F16 ? 65536.f : 1.f;
   const int nd = num_downs;
   net->ch.assign(nd + 1, 0); net->Hk.assign(nd + 1, 0); net->Wk.assign(nd + 1, 0);
@@ -173,9 +178,9 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
       }
       Conv& uv = net->up[k];
       uv.ca = inner ? net->ch[k] : 2 * net->ch[k];
-      uv.cb = outer ? 1 : net->ch[k - 1];
+      uv.cb = outer ? net->out_c : net->ch[k - 1];
       add_tensor(net, upn + ".weight", 0, {uv.ca, uv.cb, 4, 4}, &uv.w_off);
-      if (outer) add_tensor(net, upn + ".bias", 1, {1}, &uv.bias_off);
+      if (outer) add_tensor(net, upn + ".bias", 1, {net->out_c}, &uv.bias_off);
       if (!outer) add_bn(net, p + (inner ? ".4" : ".6"), net->unorm[k], net->ch[k - 1], bns);
     }
   } emit{net, nd, prefix, bns};
@@ -214,7 +219,14 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
     maxSplit = max64(maxSplit, pix * net->ch[nd] * 4);
   }
   net->oD = A.take(maxD);
-  net->oG0 = A.take(N * H * W * 4);
+  net->oG0 = A.take(N * H * W * 4 * out_c);
+  if (out_c > 1) {   // u1 on the generic kernels: weights [a][16][b] with b zero-padded to 64, NHWC staging buffer
+    const int64_t cnt = (int64_t)2 * net->ch[1] * 16 * 64;
+    net->oUp1Pad = A.take(cnt * 4);
+    net->oUp1Packed = (dtype == GI_F32) ? -2 : A.take(cnt * T);
+    net->oUp1Phase = A.take(cnt * T);
+    net->oU1 = A.take(N * H * W * 64 * T);
+  }
   net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
@@ -229,7 +241,7 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
   net->oE = S.take(N * net->Hk[nd] * net->Wk[nd] * net->ch[nd] * T);
   for (int k = 2; k <= nd; ++k) net->oU[k] = S.take(N * net->Hk[k - 1] * net->Wk[k - 1] * net->ch[k - 1] * T);
   for (int k = 5; k <= nd - 1; ++k) net->oMask[k] = S.take(N * net->Hk[k - 1] * net->Wk[k - 1] * net->ch[k - 1]);
-  net->oOut = S.take(N * H * W * 4);
+  net->oOut = S.take(N * H * W * 4 * out_c);
   net->oX = S.take(N * H * W * 4);
   int64_t stat_floats = 0;
   for (int k = 1; k <= nd; ++k)
@@ -243,6 +255,11 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
   return GI_OK;
+}
+
+extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, int W, int max_n, int dtype,
+                              int n_slots, gi_net** out) {
+  return gi_unet_create_ex(ctx, num_downs, ngf, 1, dropout_p, H, W, max_n, dtype, n_slots, out);
 }
 
 extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots, gi_net** out) {
@@ -381,6 +398,15 @@ const void* packed_ptr(const gi_net* net, const Conv& c) {
 }
 const void* phase_ptr(const gi_net* net, const Conv& c) { return net->shared(c.phase_off); }
 
+// [rows][b] -> [rows][bp] zero-padded (the outermost up-convolution of a multi-channel generator)
+__global__ void __launch_bounds__(256) pad_b_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int b, int bp) {
+  const int64_t total = rows * bp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % bp);
+    dst[i] = j < b ? src[(i / bp) * b + j] : 0.f;
+  }
+}
+
 int sync_conv(gi_net* net, const Conv& c) {
   void* packed = c.packed_off >= 0 ? (void*)net->shared(c.packed_off) : nullptr;
   return op_pack_weights(net->ctx->stream, net->dtype, net->params + c.w_off, c.ca, c.cb, packed, net->shared(c.phase_off));
@@ -393,6 +419,15 @@ extern "C" int gi_net_sync_weights(gi_net* net) {
     for (int k = 2; k <= net->nd; ++k) {
       GI_TRY(sync_conv(net, net->conv[k]));
       GI_TRY(sync_conv(net, net->up[k]));
+    }
+    if (net->out_c > 1) {
+      const int ca = net->up[1].ca;
+      float* pad = (float*)net->shared(net->oUp1Pad);
+      hipLaunchKernelGGL(pad_b_kernel, dim3(256), dim3(256), 0, net->ctx->stream, net->params + net->up[1].w_off, pad, (int64_t)ca * 16,
+                         net->out_c, 64);
+      GI_LAUNCH_CHECK();
+      GI_TRY(op_pack_weights(net->ctx->stream, net->dtype, pad, ca, 64, net->oUp1Packed >= 0 ? (void*)net->shared(net->oUp1Packed) : nullptr,
+                             net->shared(net->oUp1Phase)));
     }
   } else {
     for (int i = 2; i <= 4; ++i) GI_TRY(sync_conv(net, net->dconv[i]));
@@ -489,6 +524,7 @@ int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, cons
   a.y = y; a.ldy = ldy; a.coffy = coffy;
   a.x = x; a.dx = dx; a.pixels = pixels; a.c = c; a.act = act; a.drop_scale = drop_scale;
   a.has_bn = bn ? 1 : 0;
+  a.eval_bn = net->bwd_eval;
   if (bn) {
     BNPtrs p = bn_ptrs(net, slot, *bn);
     a.gamma = net->params + bn->gamma_off; a.save_mean = p.mean; a.save_invstd = p.inv;
@@ -513,6 +549,37 @@ __global__ void __launch_bounds__(256) sum_acc_kernel(const float* src, int64_t 
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(dst, (float)((sh[0] + sh[1] + sh[2] + sh[3]) * scale));
+}
+
+int grid1d(int64_t work) {
+  int64_t b = (work + 255) / 256;
+  if (b > 8192) b = 8192;
+  return (int)(b < 1 ? 1 : b);
+}
+// y[n][j][p] = tanh(u[n][p][j] + bias[j]), j < out_c, u NHWC with 64 (padded) channels
+template <typename T>
+__global__ void __launch_bounds__(256) head_tanh_kernel(const T* __restrict__ u, const float* __restrict__ bias, float* __restrict__ y, int n,
+                                                        int out_c, int hw) {
+  const int64_t total = (int64_t)n * out_c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    const int64_t t = i / hw;
+    const int j = (int)(t % out_c);
+    const int64_t img = t / out_c;
+    y[i] = tanhf((float)u[(img * hw + p) * 64 + j] + bias[j]);
+  }
+}
+// g (n,out_c,hw) fp32 -> NHWC T with 64 channels, zero beyond out_c
+template <typename T>
+__global__ void __launch_bounds__(256) pad_dy_kernel(const float* __restrict__ g, T* __restrict__ out, int n, int out_c, int hw) {
+  const int64_t total = (int64_t)n * hw * 64;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i & 63);
+    const int64_t t = i >> 6;
+    const int p = (int)(t % hw);
+    const int64_t img = t / hw;
+    out[i] = j < out_c ? (T)g[(img * out_c + j) * hw + p] : (T)0.f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -565,9 +632,26 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
                       drop ? 1.f / (1.f - net->dropout_p) : 1.f, train));
   }
   float* osave = (float*)net->slot(s, net->oOut);
-  GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
-                       net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol)));
-  GI_HIP(hipMemcpyAsync(y, osave, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
+  if (net->out_c == 1) {
+    GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
+                         net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol)));
+  } else {
+    // u1 with out_c channels: the same sub-pixel GEMM as the other up-convolutions on weights zero-padded to 64
+    // output channels, then bias + tanh of the first out_c channels into the (n,out_c,H,W) fp32 result
+    void* U1 = net->shared(net->oU1);
+    const int c1 = 2 * net->ch[1];
+    GI_TRY(igemm(net, 1, C(1), c1, c1, 0, net->shared(net->oUp1Phase), U1, 64, 64, 0, n, net->Hk[1], net->Wk[1], 1, GI_ACT_NONE, false,
+                 nullptr, net->ch[1]));
+    const int64_t total = (int64_t)n * net->out_c * H * W;
+    if (dt == GI_F16)
+      hipLaunchKernelGGL(head_tanh_kernel<half_t>, dim3(grid1d(total)), dim3(256), 0, st, (const half_t*)U1, net->params + net->up[1].bias_off,
+                         osave, n, net->out_c, H * W);
+    else
+      hipLaunchKernelGGL(head_tanh_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, (const float*)U1, net->params + net->up[1].bias_off,
+                         osave, n, net->out_c, H * W);
+    GI_LAUNCH_CHECK();
+  }
+  GI_HIP(hipMemcpyAsync(y, osave, (size_t)n * net->out_c * H * W * 4, hipMemcpyDeviceToDevice, st));
   return GI_OK;
 }
 
@@ -578,7 +662,12 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   hipStream_t st = net->ctx->stream;
   const int nd = net->nd, dt = net->dtype;
   const int H = net->H, W = net->W, n = net->slot_n[s];
-  GI_REQUIRE(n > 0 && net->slot_train[s], "unet_backward: slot %d holds no train-mode forward", s);
+  // a forward in eval mode (running-statistics BatchNorm, no dropout) can be differentiated w.r.t. its input only:
+  // the frozen segmentation network of the face-parsing loss (wgan_perceptual_style_faceparsing.py:212-213)
+  GI_REQUIRE(n > 0 && (net->slot_train[s] || !need_wgrad), "unet_backward: slot %d holds no train-mode forward", s);
+  GI_REQUIRE(net->out_c == 1 || !need_wgrad, "unet_backward: parameter gradients of a %d-channel generator are not built", net->out_c);
+  const int evalbn = net->slot_train[s] ? 0 : 1;
+  net->bwd_eval = evalbn;
   const float LS = net->loss_scale, iLS = 1.f / LS;
   auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
   auto gC = [&](int k) { return (void*)net->shared(net->ogC[k]); };
@@ -588,7 +677,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   const int64_t npx = (int64_t)n * H * W;
   if (phase != 2) {
   // tanh' and loss scaling
-  GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx, LS));
+  GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx * net->out_c, LS));
   // u1: ConvTranspose2d(2ngf -> 1) + bias
   const int c1 = 2 * net->ch[1];
   if (need_wgrad) {
@@ -596,13 +685,22 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     GI_LAUNCH_CHECK();
     GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f));
   }
-  GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
+  if (net->out_c == 1) {
+    GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
+  } else {
+    void* U1 = net->shared(net->oU1);
+    if (dt == GI_F16) hipLaunchKernelGGL(pad_dy_kernel<half_t>, dim3(grid1d(npx * 64)), dim3(256), 0, st, G0, (half_t*)U1, n, net->out_c, H * W);
+    else hipLaunchKernelGGL(pad_dy_kernel<float>, dim3(grid1d(npx * 64)), dim3(256), 0, st, G0, (float*)U1, n, net->out_c, H * W);
+    GI_LAUNCH_CHECK();
+    const void* wp = net->oUp1Packed >= 0 ? (const void*)net->shared(net->oUp1Packed) : (const void*)net->shared(net->oUp1Pad);
+    GI_TRY(igemm(net, 0, U1, 64, 64, 0, wp, gC(1), c1, c1, 0, n, net->Hk[1], net->Wk[1], 0, GI_ACT_NONE, false, nullptr));
+  }
   // decoder, outermost -> innermost: level k's concat gradient feeds up[k+1]
   for (int k = 1; k <= nd - 1; ++k) {
     const int kk = k + 1;
     const int ck = net->ch[k];
     const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
-    const float ds = (net->dropout_p > 0.f && kk >= 5 && kk <= nd - 1) ? 1.f / (1.f - net->dropout_p) : 1.f;
+    const float ds = (!evalbn && net->dropout_p > 0.f && kk >= 5 && kk <= nd - 1) ? 1.f / (1.f - net->dropout_p) : 1.f;
     GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, gC(k), 2 * ck, ck, C(k), 2 * ck, ck, net->slot(s, net->oU[kk]), D, pix, ck,
                       GI_ACT_NONE, ds, &net->unorm[kk], need_wgrad));
     const void* Sin = (kk == nd) ? (const void*)net->slot(s, net->oE) : C(kk);
@@ -682,6 +780,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   hipStream_t st = net->ctx->stream;
   const int dt = net->dtype, H = net->H, W = net->W, n = net->slot_n[s];
   GI_REQUIRE(n > 0 && net->slot_train[s], "patchgan_backward: slot %d holds no train-mode forward", s);
+  net->bwd_eval = 0;
   const float LS = net->loss_scale, iLS = 1.f / LS;
   void* D = net->shared(net->oD);
   HeadBwdArgs hb;

@@ -72,7 +72,8 @@ class _Holder(nn.Module):
 class _NetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, net):
-        need_wgrad = any(p.requires_grad for p in net.parameters())
+        # an eval-mode forward (running-statistics BatchNorm) is differentiable w.r.t. its input only
+        need_wgrad = net.training and any(p.requires_grad for p in net.parameters())
         y, slot, gen = net._forward_raw(x)
         ctx.net, ctx.slot, ctx.gen = net, slot, gen
         ctx.need_dx = x.requires_grad
@@ -328,7 +329,7 @@ class HipNet(nn.Module):
         return dx
 
     def forward(self, x):
-        if torch.is_grad_enabled() and self.training:
+        if torch.is_grad_enabled() and (self.training or x.requires_grad):
             return _NetFunction.apply(x, self._anchor, self)
         return self._forward_raw(x)[0]
 
@@ -341,13 +342,22 @@ def _init_conv(cout, cin, transposed=False, bias=False):
 
 
 class UnetGenerator(HipNet):
-    """networks.py:216-253 (+ UnetSkipConnectionBlock :255-324). input_nc = output_nc = 1."""
+    """networks.py:216-253 (+ UnetSkipConnectionBlock :255-324). input_nc = 1; output_nc = 1 (the inpainting
+    generator) or up to 64 (the frozen face-parsing network UnetGenerator(1,4,7,ngf=32), train.py:171-172:
+    forward + input gradient only). ngf must be a multiple of 64 on the device; other widths (ngf=32) are
+    served by EmbeddedUnetGenerator, which this constructor returns transparently."""
+
+    def __new__(cls, input_nc=1, output_nc=1, num_downs=7, ngf=64, *args, **kw):
+        if cls is UnetGenerator and ngf % 64 != 0:
+            return EmbeddedUnetGenerator(input_nc, output_nc, num_downs, ngf, *args, **kw)
+        return super().__new__(cls)
 
     def __init__(self, input_nc=1, output_nc=1, num_downs=7, ngf=64, norm_layer=nn.BatchNorm2d, use_dropout=False,
                  use_sigmoid_output=False, dtype=None):
         super().__init__(dtype)
-        if input_nc != 1 or output_nc != 1:
-            raise NotImplementedError("HIP backend: UnetGenerator is built for 1-channel images (input_nc=output_nc=1)")
+        if input_nc != 1 or not (1 <= output_nc <= 64):
+            raise NotImplementedError("HIP backend: UnetGenerator takes 1-channel images and emits 1..64 channels")
+        self.output_nc = output_nc
         fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
         if fn is not nn.BatchNorm2d:
             raise NotImplementedError("HIP backend: only BatchNorm2d generators (the get_network default) are built")
@@ -359,7 +369,7 @@ class UnetGenerator(HipNet):
         lib = B.lib()
         h = C.c_void_p()
         size0 = 1 << max(num_downs, 7)
-        B.check(lib.gi_unet_create(None, num_downs, ngf, self.dropout_p, size0, size0, 1, self._dtype, 1, C.byref(h)))
+        B.check(lib.gi_unet_create_ex(None, num_downs, ngf, output_nc, self.dropout_p, size0, size0, 1, self._dtype, 1, C.byref(h)))
         self._build_tree(self._inventory(h), lib.gi_net_param_floats(h), lib.gi_net_buffer_floats(h))
         lib.gi_net_destroy(h)
         self.reset_parameters()
@@ -394,12 +404,12 @@ class UnetGenerator(HipNet):
 
     def _create_handle(self, ctx, H, W, max_n):
         h = C.c_void_p()
-        B.check(B.lib().gi_unet_create(ctx, self.num_downs, self.ngf, self.dropout_p, H, W, max_n, self._dtype,
-                                       self.n_slots, C.byref(h)))
+        B.check(B.lib().gi_unet_create_ex(ctx, self.num_downs, self.ngf, self.output_nc, self.dropout_p, H, W, max_n, self._dtype,
+                                          self.n_slots, C.byref(h)))
         return h
 
     def _output_shape(self, n, H, W):
-        return (n, 1, H, W)
+        return (n, self.output_nc, H, W)
 
     # dropout control (parity tests feed the device-generated masks to the oracle, or impose masks)
     def set_dropout_seed(self, seed):
@@ -440,6 +450,127 @@ class UnetGenerator(HipNet):
     def impose_dropout_masks(self, masks):
         """Use these keep-masks ({level: uint8 (N,C,H,W)}) in the NEXT forward (parity tests)."""
         self._pending_masks = dict(masks)
+
+
+class EmbeddedUnetGenerator(nn.Module):
+    """UnetGenerator whose width is not a multiple of 64 (the reference's face-parsing network has ngf=32,
+    train.py:171-172), run on the ngf'=64*ceil(ngf/64) kernels by zero-embedding: every channel axis is padded
+    with zero weights, BatchNorm of the padded channels has weight = bias = running_mean = 0 and
+    running_var = 1, and the two halves of a skip concatenation are embedded separately. Padded channels carry
+    exact zeros through convolutions, BatchNorm, LeakyReLU/ReLU and their gradients, so outputs and input
+    gradients equal the narrow network's (tests/test_segnet_gpu.py); the cost is (ngf'/ngf)^2 x the FLOPs -
+    native narrow kernels are the next step. state_dict()/load_state_dict() speak the NARROW shapes and the
+    reference's key names."""
+
+    def __init__(self, input_nc=1, output_nc=1, num_downs=7, ngf=32, norm_layer=nn.BatchNorm2d, use_dropout=False,
+                 use_sigmoid_output=False, dtype=None):
+        super().__init__()
+        self.ngf, self.num_downs, self.output_nc = ngf, num_downs, output_nc
+        self.ngf_phys = 64 * ((ngf + 63) // 64)
+        lib = B.lib()
+        h = C.c_void_p()
+        size0 = 1 << max(num_downs, 7)
+        dcode = B.dtype_code(dtype or DEFAULT_DTYPE)
+        B.check(lib.gi_unet_create_ex(None, num_downs, ngf, output_nc, 0.0, size0, size0, 1, dcode, 1, C.byref(h)))
+        self._narrow = {t["name"]: t for t in HipNet._inventory(self, h)}
+        lib.gi_net_destroy(h)
+        # draw the narrow network's initial weights exactly like the reference constructor, then embed
+        probe = _NarrowInit(self._narrow, num_downs)
+        self.phys = UnetGenerator(input_nc, output_nc, num_downs, self.ngf_phys, norm_layer, use_dropout, use_sigmoid_output, dtype)
+        self.load_state_dict(probe.state, strict=True)
+
+    # channel index maps narrow -> physical per tensor axis
+    def _axis_maps(self, name, shape):
+        ch = lambda k: self.ngf * min(2 ** (k - 1), 8)          # noqa: E731  channels of level k (narrow)
+        r = self.ngf_phys // self.ngf
+        def plain(c):
+            return torch.arange(c)
+        def halves(c):                                          # [skip | decoder] concat of two c/2 blocks
+            h = c // 2
+            return torch.cat([torch.arange(h), r * h + torch.arange(h)])
+        is_up_conv = name.endswith(".weight") and len(shape) == 4 and name in self._up_names()
+        maps = []
+        for ax, c in enumerate(shape[:2] if len(shape) == 4 else shape):
+            if len(shape) == 4 and is_up_conv and ax == 0 and name != self._up_names()[-1]:
+                maps.append(halves(c))                          # ConvTranspose2d in-channels = concat (all but the innermost)
+            else:
+                maps.append(plain(c))
+        return maps
+
+    def _up_names(self):
+        out, p = [], "model.model"
+        for k in range(1, self.num_downs + 1):
+            outer, inner = k == 1, k == self.num_downs
+            out.append(p + (".3" if (outer or inner) else ".5") + ".weight")
+            p = p + (".1" if outer else ".3") + ".model"
+        return out
+
+    def state_dict(self, *args, **kw):
+        phys = self.phys.state_dict()
+        out = {}
+        for name, t in self._narrow.items():
+            v = phys[name]
+            maps = self._axis_maps(name, t["shape"])
+            if len(t["shape"]) == 4:
+                v = v[maps[0].to(v.device)][:, maps[1].to(v.device)]
+            else:
+                v = v[maps[0].to(v.device)]
+            out[name] = v.clone()
+            if name.endswith("running_var"):
+                out[name[:-len("running_var")] + "num_batches_tracked"] = phys[name[:-len("running_var")] + "num_batches_tracked"].clone()
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        phys = self.phys.state_dict()
+        missing = [k for k in self._narrow if k not in sd]
+        if strict and missing:
+            raise RuntimeError("EmbeddedUnetGenerator.load_state_dict: missing keys %s" % missing)
+        for name, t in self._narrow.items():
+            if name not in sd:
+                continue
+            src = torch.as_tensor(sd[name]).float()
+            if tuple(src.shape) != tuple(t["shape"]):
+                raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(src.shape), tuple(t["shape"])))
+            dst = phys[name]
+            full = torch.ones_like(dst) if name.endswith("running_var") else torch.zeros_like(dst)
+            maps = self._axis_maps(name, t["shape"])
+            if len(t["shape"]) == 4:
+                full[maps[0].to(dst.device)[:, None], maps[1].to(dst.device)[None, :]] = src.to(dst.device)
+            else:
+                full[maps[0].to(dst.device)] = src.to(dst.device)
+            phys[name] = full
+        self.phys.load_state_dict(phys, strict=True)
+        return missing
+
+    def forward(self, x):
+        return self.phys(x)
+
+
+class _NarrowInit:
+    """Initial weights of a narrow UnetGenerator drawn from torch's RNG in the reference constructor's order."""
+
+    def __init__(self, inv, num_downs):
+        self.state = {}
+        names, p = [], "model.model"
+        for k in range(1, num_downs + 1):
+            outer, inner = k == 1, k == num_downs
+            names.append((p + (".0" if outer else ".1") + ".weight", p + (".3" if (outer or inner) else ".5") + ".weight"))
+            p = p + (".1" if outer else ".3") + ".model"
+        for down, up in reversed(names):
+            a, b = inv[down]["shape"][:2]
+            self.state[down] = _init_conv(a, b)[0]
+            a, b = inv[up]["shape"][:2]
+            bias_name = up[:-len("weight")] + "bias"
+            w, bias = _init_conv(b, a, transposed=True, bias=bias_name in inv)
+            self.state[up] = w
+            if bias is not None:
+                self.state[bias_name] = bias
+        for name, t in inv.items():
+            if name.endswith("running_mean"):
+                pre = name[:-len("running_mean")]
+                c = t["shape"][0]
+                self.state[pre + "weight"], self.state[pre + "bias"] = torch.ones(c), torch.zeros(c)
+                self.state[pre + "running_mean"], self.state[pre + "running_var"] = torch.zeros(c), torch.ones(c)
 
 
 class Flatten(nn.Module):

@@ -59,6 +59,13 @@ int gi_ctx_sync(gi_ctx* ctx);
  * independent activation sets (forward calls that may be live before their backward). */
 int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, int W, int max_n,
                    int dtype, int n_slots, gi_net** out);
+/* UnetGenerator(1, out_c, ...) with out_c in 1..64 output channels (the frozen face-parsing network
+ * UnetGenerator(1,4,7,ngf=32), train.py:171-172; Tanh head as in networks.py:293-298). out_c > 1 nets
+ * are forward + input-gradient only (gi_net_backward with need_param_grads = 0, also after an eval-mode
+ * forward: running-statistics BatchNorm). y / dy are (n,out_c,H,W). ngf must be a multiple of 64 for a
+ * bound handle; an inventory-only handle (ctx NULL) accepts multiples of 8 (Python embeds ngf=32 in 64). */
+int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float dropout_p, int H, int W,
+                      int max_n, int dtype, int n_slots, gi_net** out);
 /* PatchGANDiscriminator(c=1, sigmoid): Linear(25,1) generalised to ((H/16-3)*(W/16-3),1). */
 int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots,
                        gi_net** out);

@@ -558,6 +558,36 @@ def case_auxloss(ref_root, name):
     return fx
 
 
+def case_segnet(networks, name, seed, N, HW):
+    """The frozen face-parsing network exactly as train.py:171-175 builds it (UnetGenerator(1,4,7,ngf=32,
+    BatchNorm2d affine+running stats, use_dropout='False').eval()) with deterministic parameters, the
+    weighted cross entropy of wgan_perceptual_style_faceparsing.py:67-68,212-213 on its output, and the
+    gradient of that loss w.r.t. the input image (what reaches the generator)."""
+    import functools
+    P = op.make_unet_params(seed, num_downs=7, ngf=32, in_c=1, out_c=4)
+    net = networks.UnetGenerator(1, 4, 7, ngf=32, norm_layer=functools.partial(torch.nn.BatchNorm2d, affine=True, track_running_stats=True),
+                                 use_dropout='False')
+    load(net, P)
+    net.eval()
+    g, _ = op.synth_batch(seed + 1, N, HW, HW)
+    labels, _ = op.synth_segmentation(seed + 2, N, 4, HW, HW)
+    x = torch.from_numpy(g).requires_grad_(True)
+    y = net(x)
+    ce = torch.nn.CrossEntropyLoss(weight=torch.tensor([0, 1.2, 0.7, 0.7]))(y, torch.from_numpy(labels))
+    (0.01 * ce).backward()
+    # oracle: same forward / same gradient
+    TP = orc.to_torch(P, requires_grad=False)
+    xo = torch.from_numpy(g).requires_grad_(True)
+    yo = orc.unet_forward(TP, xo, 7, False, None)
+    close(yo.detach(), y.detach(), 1e-5, "segnet forward")
+    (0.01 * orc.weighted_cross_entropy(yo, torch.from_numpy(labels), torch.tensor([0, 1.2, 0.7, 0.7]))).backward()
+    assert float((xo.grad - x.grad).abs().max()) <= 1e-5 * float(x.grad.abs().max()), "oracle != reference for segnet input gradient"
+    return dict(seed=np.array(seed), N=np.array(N), HW=np.array(HW), ce=np.array(float(ce)),
+                out_absmean=np.array(float(y.abs().mean())), out_head=y.detach()[0, :, :4, :6].numpy(),
+                xgrad_abssum=np.array(float(x.grad.abs().sum())), xgrad_head=x.grad[0, 0, :6, :8].numpy(),
+                xgrad_full=x.grad.numpy().astype(np.float32), out_full=y.detach().numpy().astype(np.float16))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -579,6 +609,7 @@ def main():
         ssim=lambda: case_ssim(args.ref, "ssim"),
         evalmetrics=lambda: case_evalmetrics(args.ref, "evalmetrics"),
         auxloss=lambda: case_auxloss(args.ref, "auxloss"),
+        segnet=lambda: case_segnet(networks, "segnet", 95, 2, 128),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):
