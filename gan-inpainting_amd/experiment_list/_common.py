@@ -57,8 +57,9 @@ def build_networks(state, device, n_disc=1, sigmoid=True):
     return G.to(device), Ds
 
 
-def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn, d_names):
-    """batch_fn(batch_index, ground, mask) -> (loss dict of device scalars, g_updated: bool)."""
+def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn, d_names, pass_extra=False):
+    """batch_fn(batch_index, ground, mask[, extra]) -> (loss dict of device scalars, g_updated: bool); extra = the
+    loader's third item (the segmentation labels of dataset.py:35-51) when pass_extra is set."""
     num_epochs, save_every, evaluate_every = state["numepoch"], state["saveevery"], state["evalevery"]
     log_every = state.get("logevery", 50)
     flow_G = util.GradFlow(net_G)
@@ -69,10 +70,13 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
         sums, g_updates, batches = {}, 0, 0
         acc_g = torch.zeros(len(flow_G.names), device=device)
         acc_d = [torch.zeros(len(f.names), device=device) for f in flows_D]
-        for bi, (ground, mask, _) in enumerate(loaders["train"]):
+        for bi, (ground, mask, extra) in enumerate(loaders["train"]):
             ground = ground.to(device, non_blocking=True).float().contiguous()
             mask = mask.to(device, non_blocking=True).float().contiguous()
-            L, g_updated = batch_fn(bi, ground, mask)
+            if pass_extra:
+                L, g_updated = batch_fn(bi, ground, mask, extra.to(device, non_blocking=True).contiguous())
+            else:
+                L, g_updated = batch_fn(bi, ground, mask)
             for k, v in L.items():
                 sums[k] = sums.get(k, 0) + v.detach().clone()
             batches += 1

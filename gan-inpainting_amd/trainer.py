@@ -21,7 +21,7 @@ class _Ops:
 
     def __init__(self, device):
         self.dev = torch.device(device)
-        self.scratch = torch.empty(4096, dtype=torch.float32, device=self.dev)
+        self.scratch = torch.empty(2048, dtype=torch.float64, device=self.dev).view(torch.float32)   # 4096 floats, 8-byte aligned
 
     @property
     def ctx(self):
@@ -53,6 +53,25 @@ class _Ops:
                                      B.ptr(self.scratch)))
         else:
             raise ValueError(kind)
+
+    def local(self, kind, yhat, y, mask, loss_out, grad, gscale=1.0):
+        """LocalLoss (loss.py:24-47): kind 'l1' | 'mse' | 'rmse' (the sqrt extension); gradient w.r.t. yhat."""
+        code = {"l1": 0, "mse": 1, "rmse": 2}[kind]
+        B.check(B.lib().gi_loss_local(self.ctx, B.ptr(yhat), B.ptr(y), B.ptr(mask), yhat.numel(), code, B.ptr(loss_out), B.ptr(grad),
+                                      float(gscale), B.ptr(self.scratch)))
+
+    def tv(self, img, weight, loss_out, grad, gscale=1.0):
+        n, c, h, w = img.shape
+        B.check(B.lib().gi_loss_tv(self.ctx, B.ptr(img), n * c, h, w, float(weight), B.ptr(loss_out), B.ptr(grad), float(gscale),
+                                   B.ptr(self.scratch)))
+
+    def cross_entropy(self, logits, labels, class_weight, loss_out2, grad, gscale=1.0):
+        import ctypes as C
+        n, k = logits.shape[0], logits.shape[1]
+        hw = logits.numel() // (n * k)
+        cw = (C.c_float * k)(*[float(v) for v in class_weight]) if class_weight is not None else None
+        B.check(B.lib().gi_loss_cross_entropy(self.ctx, B.ptr(logits), B.ptr(labels), n, k, hw, C.cast(cw, C.c_void_p) if cw is not None else None,
+                                              -100, B.ptr(loss_out2), B.ptr(grad), float(gscale), B.ptr(self.scratch)))
 
 
 BCE, LSGAN, MEAN = 0, 1, 2
@@ -252,8 +271,7 @@ class WGANStep(_StepBase):
             main.wait_event(self._evD[k])
             d_adv.record_stream(main)
             self.optG.zero_grad()
-            o.recon(self.recon, inp, ground, self._loss("recon"), self.g_rec)
-            o.add(d_adv, self.g_rec, self.tmp1)
+            o.add(d_adv, self._g_losses(inp, ground), self.tmp1)
             o.mul(self.tmp1, self.mask_c, self.g_gen)
             self._bwd_G(gtok, self.g_gen)
             self.optG.step()
@@ -286,12 +304,72 @@ class WGANStep(_StepBase):
             p, t = self._fwd(self.D, self.inpainted)
             o.adv(p, MEAN, 0.0, self._loss("g_adv"), self.dpred, +1.0)
             d_adv = self._bwd(self.D, t, self.dpred, True, False)
-            o.recon(self.recon, self.inpainted, ground, self._loss("recon"), self.g_rec)
-            o.add(d_adv, self.g_rec, self.tmp1)
+            o.add(d_adv, self._g_losses(self.inpainted, ground), self.tmp1)
             o.mul(self.tmp1, self.mask_c, self.g_gen)
             self._bwd_G(gtok, self.g_gen)
             self.optG.step()
         return self.L
+
+    def _g_losses(self, inp, ground):
+        """Every non-adversarial generator loss: records the scalars, returns d(sum)/d(inpainted)."""
+        self.ops.recon(self.recon, inp, ground, self._loss("recon"), self.g_rec)
+        return self.g_rec
+
+
+class WGANPerceptualStep(WGANStep):
+    """experiment_list/wgan_perceptual_style_faceparsing.py:136-232 (BASELINE config 5): the WGAN schedule with
+        g_loss = g_adv + recon_global + recon_local + perceptual + style + face_parsing + tv          (:222)
+    recon_global = RMSELoss(ground, inpainted) (:206), recon_local = LocalLoss RMSE on the mask (:207; the file adds
+    an undefined `recon_loss`: the sum of the two terms it computes is the evident intent), perceptual / style =
+    loss.perceptual_and_style_loss(weight_p = weight_s = 0.01) (:216; constants, the reference runs them under
+    no_grad), face_parsing = 0.01 * CrossEntropy(w=[0,1.2,0.7,0.7])(segment_model(inpainted), segment) (:212-213,
+    frozen eval network: input gradient only), tv = tv_loss(inpainted, 1) (:219).
+    `vgg` (networks.VGG19Wrapper) and `segment_model` (frozen UnetGenerator(1,4,7,ngf=32)) are optional: a missing
+    one drops its term (the pretrained weights of both are not redistributable / not available here)."""
+
+    def __init__(self, net_G, net_D, opt_G, opt_D, vgg=None, segment_model=None, weight_p=0.01, weight_s=0.01, weight_fp=0.01,
+                 tv_weight=1.0, ce_weight=(0, 1.2, 0.7, 0.7), **kw):
+        super().__init__(net_G, net_D, opt_G, opt_D, recon="rmse", **kw)
+        self.recon_weight = 2.0
+        self.vgg, self.weight_p, self.weight_s = vgg, weight_p, weight_s
+        self.tv_weight, self.weight_fp, self.ce_weight = tv_weight, weight_fp, list(ce_weight)
+        self.seg = getattr(segment_model, "phys", segment_model)      # EmbeddedUnetGenerator -> the physical network
+        self.segment = None
+        if self.seg is not None:
+            self.seg.eval()
+            for p in self.seg.parameters():
+                p.requires_grad_(False)
+            self._ce2 = torch.zeros(2, dtype=torch.float32, device=net_G.device)
+            self._zero1 = torch.zeros(1, dtype=torch.float32, device=net_G.device)
+            self._dseg = None
+
+    def __call__(self, ground, mask, update_g, segment=None):
+        self.segment = segment
+        return super().__call__(ground, mask, update_g)
+
+    def _g_losses(self, inp, ground):
+        o = self.ops
+        o.recon("rmse", inp, ground, self._loss("recon_global"), self.g_rec)                   # :206
+        o.local("rmse", inp, ground, self.mask_c, self._loss("recon_local"), self.tmp2)        # :207
+        o.add(self.g_rec, self.tmp2, self.g_rec)
+        o.tv(inp, self.tv_weight, self._loss("tv"), self.tmp2)                                 # :219
+        o.add(self.g_rec, self.tmp2, self.g_rec)
+        if self.vgg is not None:                                                               # :216 (no gradient)
+            p, s = self.vgg.perceptual_and_style(inp, ground, self.weight_p, self.weight_s)
+            self.L["perceptual"], self.L["style"] = p.view(1), s.view(1)
+        if self.seg is not None and self.segment is not None:                                  # :212-213
+            import math
+            n, _, h, w = inp.shape
+            if self.seg._dtype == B.GI_F16:   # gradient entering the frozen network ~ weight_fp / (n*h*w) per logit
+                self.seg.set_loss_scale(min(2.0 ** 24, 2.0 ** round(math.log2(0.03 * n * h * w / self.weight_fp))))
+            y, tok = self._fwd(self.seg, inp)
+            if self._dseg is None or self._dseg.shape != y.shape:
+                self._dseg = torch.empty_like(y)
+            o.cross_entropy(y, self.segment, self.ce_weight, self._ce2, self._dseg, self.weight_fp)
+            o.add(self._zero1, self._ce2[:1], self._loss("face_parsing"), self.weight_fp)
+            dx = self._bwd(self.seg, tok, self._dseg, True, False)
+            o.add(self.g_rec, dx, self.g_rec)
+        return self.g_rec
 
 
 def wgan_update_g(batch_index, g_iter_count, update_g_every=5):

@@ -390,7 +390,7 @@ def minimax_step(PG, PD, optG, optD, ground, mask, num_downs, dropout_masks, rec
 
 
 def wgan_step(PG, PD, optG, optD, ground, mask, num_downs, dropout_masks, update_g, recon="l1",
-              clip=0.01):
+              clip=0.01, extra=None):
     """One batch of experiment_list/wgan_l1.py:110-186 with one=+1, mone=-1 (the file's
     torch.FloatTensor(1) is uninitialised memory). update_g is the
     cadence decision of wgan_l1.py:157-163, taken by the caller."""
@@ -417,11 +417,38 @@ def wgan_step(PG, PD, optG, optD, ground, mask, num_downs, dropout_masks, update
         g_adv = d_fake2.mean().view(1)
         rec = l1_loss(ground, inpainted) if recon == "l1" else rmse_loss(ground, inpainted)
         g_loss = g_adv + rec
+        if extra is not None:      # config-5 terms: callable(inpainted, ground, mask_c) -> (loss tensor, {name: float})
+            ex, named = extra(inpainted, ground, m)
+            g_loss = g_loss + ex
+            out.update(named)
         g_loss.backward()
         out.update(g_adv=float(g_adv), recon=float(rec), g_loss=float(g_loss),
                    g_grad_absmean=grad_absmean(PG))
         optG.step()
     return out
+
+
+def config5_extra(PV, PS, segment, weight_p=0.01, weight_s=0.01, weight_fp=0.01, tv_weight=1.0):
+    """The generator-loss terms wgan_perceptual_style_faceparsing.py adds to g_adv + recon_global (:206-222):
+    recon_local (LocalLoss RMSE, :207), face parsing (:212-213; PS = parameters of the frozen eval-mode
+    UnetGenerator(1,4,7,ngf=32)), perceptual + style (:216; PV = VGG-19 parameters; constants) and tv (:219).
+    Use with wgan_step(recon='rmse', extra=...)."""
+    def fn(inpainted, ground, m):
+        rl = local_loss(ground, inpainted, m, base="rmse")
+        tv = tv_loss(inpainted, tv_weight)
+        named = dict(recon_local=float(rl), tv=float(tv))
+        tot = rl + tv
+        if PS is not None:
+            fp = weight_fp * weighted_cross_entropy(unet_forward(PS, inpainted, 7, False, None), segment,
+                                                    torch.tensor([0, 1.2, 0.7, 0.7], dtype=inpainted.dtype))
+            tot = tot + fp
+            named["face_parsing"] = float(fp)
+        if PV is not None:
+            p, s, _, _ = perceptual_and_style_loss(PV, inpainted, ground, weight_p, weight_s)
+            tot = tot + p + s
+            named["perceptual"], named["style"] = float(p), float(s)
+        return tot, named
+    return fn
 
 
 def wgan_update_g(batch_index, g_iter_count, update_g_every=5):

@@ -588,6 +588,86 @@ def case_segnet(networks, name, seed, N, HW):
                 xgrad_full=x.grad.numpy().astype(np.float32), out_full=y.detach().numpy().astype(np.float16))
 
 
+def case_config5(networks, util, ref_root, name, seed, N, pattern):
+    """wgan_perceptual_style_faceparsing.py:136-232 replayed on the reference modules (generator, critic,
+    frozen face-parsing UnetGenerator(1,4,7,ngf=32).eval()), the reference's RMSELoss class and its
+    perceptual_and_style_loss / tv_loss functions (texts executed at generation time over the stand-in
+    VGG-19), torch's CrossEntropyLoss(weight=[0,1.2,0.7,0.7]) and RMSprop, one=+1 / mone=-1. Deviations forced
+    by the file itself: `recon_loss` (:222) is undefined -> recon_global + recon_local; LocalLoss(RMSELoss())
+    (:62) raises at construction -> the oracle's masked-RMSE extension."""
+    import functools
+    src = open(os.path.join(ref_root, "lib/models/loss.py")).read()
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(src[src.index("class RMSELoss"):src.index("def perceptual_loss")], "reference:loss.py", "exec"), ns)
+    exec(compile(src[src.index("def perceptual_loss"):], "reference:loss.py", "exec"), ns)
+    PG, PD = op.make_unet_params(seed), op.make_patchgan_params(seed + 1)
+    PS = op.make_unet_params(seed + 2, num_downs=7, ngf=32, in_c=1, out_c=4)
+    PV = op.make_vgg19_params(seed + 3)
+    ns["vgg"] = _VggStandIn(PV)
+    net_G = load(networks.get_network("generator", "unet"), PG)
+    net_D = load(networks.PatchGANDiscriminator(sigmoid=False), PD)
+    seg = load(networks.UnetGenerator(1, 4, 7, ngf=32, norm_layer=functools.partial(torch.nn.BatchNorm2d, affine=True, track_running_stats=True),
+                                      use_dropout='False'), PS)
+    seg.eval()
+    cap = MaskCapture(net_G, 7)
+    rmse_global = ns["RMSELoss"]()
+    ce_crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0, 1.2, 0.7, 0.7]))
+    G_opt = torch.optim.RMSprop(net_G.parameters(), lr=0.00005)
+    D_opt = torch.optim.RMSprop(net_D.parameters(), lr=0.00005)
+    one = torch.ones(1)
+    mone = one * -1
+    OG, OD = orc.to_torch(PG), orc.to_torch(PD)
+    OS = orc.to_torch(PS, requires_grad=False)
+    OV = {k: torch.from_numpy(v) for k, v in PV.items()}
+    oG, oD = orc.RMSprop(orc.trainable(OG)), orc.RMSprop(orc.trainable(OD))
+    fx = dict(seed=seed, N=N, pattern=np.array(pattern, np.int64))
+    for it, upd in enumerate(pattern):
+        g_np, m_np = op.synth_batch(seed * 100 + it, N, 128, 128)
+        seg_np, _ = op.synth_segmentation(seed * 100 + 50 + it, N, 4, 128, 128)
+        ground, mask, segment = torch.from_numpy(g_np), torch.ceil(torch.from_numpy(m_np)), torch.from_numpy(seg_np)
+        masked = ground * (1 - mask)
+        inpainted = masked + net_G(masked) * mask
+        util.set_requires_grad([net_D], True)
+        D_opt.zero_grad()
+        d_loss_real = torch.mean(net_D(ground)).view(1)
+        d_loss_real.backward(one)
+        d_loss_fake = torch.mean(net_D(inpainted.detach())).view(1)
+        d_loss_fake.backward(mone)
+        D_opt.step()
+        for p in net_D.parameters():
+            p.data.clamp_(-0.01, 0.01)
+        rec = dict(d_loss_real=float(d_loss_real), d_loss_fake=float(d_loss_fake))
+        if upd:
+            util.set_requires_grad([net_D], False)
+            G_opt.zero_grad()
+            g_adv = torch.mean(net_D(inpainted).view(-1)).view(1)
+            recon_global = rmse_global(ground, inpainted)
+            recon_local = orc.local_loss(ground, inpainted, mask, base="rmse")
+            face = 0.01 * ce_crit(seg(inpainted), segment)
+            g_p, g_s = ns["perceptual_and_style_loss"](inpainted, ground, weight_p=0.01, weight_s=0.01)
+            g_tv = ns["tv_loss"](inpainted, tv_weight=1)
+            g_loss = g_adv + recon_global + recon_local + g_p + g_s + face + g_tv
+            g_loss.backward()
+            _, g_absmean, _ = grad_stats(net_G)
+            G_opt.step()
+            rec.update(g_adv=float(g_adv), recon_global=float(recon_global), recon_local=float(recon_local), face_parsing=float(face),
+                       perceptual=float(g_p), style=float(g_s), tv=float(g_tv), g_loss=float(g_loss), g_grad_absmean=g_absmean)
+        rec.update(g_param_stats=param_stats(net_G), d_param_stats=param_stats(net_D))
+        _record_step(fx, it, rec)
+        fx.update({f"it{it}_{k}": v for k, v in pack_masks(cap.masks).items()})
+        o = orc.wgan_step(OG, OD, oG, oD, torch.from_numpy(g_np), torch.from_numpy(m_np), 7, dict(cap.masks), bool(upd), recon="rmse",
+                          extra=orc.config5_extra(OV, OS, segment))
+        keys = ("d_loss_real", "d_loss_fake") + (("g_adv", "recon", "recon_local", "face_parsing", "perceptual", "style", "tv", "g_loss") if upd else ())
+        for k in keys:
+            close(o[k], rec["recon_global" if k == "recon" else k], 5e-5, f"{name}.it{it}.{k}")
+        gnames = [n for n, _ in net_G.named_parameters()]
+        ostats = np.array([float(OG[n].double().abs().sum()) for n in gnames])
+        close(ostats, rec["g_param_stats"][:, 1], 1e-6, f"{name}.it{it}.g_params")
+        print(f"  {name} it{it}: upd={upd} " + " ".join(f"{k}={rec[k]:.6g}" for k in rec if isinstance(rec[k], float)))
+    fx["g_param_names"] = np.array([n for n, _ in net_G.named_parameters()])
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -610,6 +690,7 @@ def main():
         evalmetrics=lambda: case_evalmetrics(args.ref, "evalmetrics"),
         auxloss=lambda: case_auxloss(args.ref, "auxloss"),
         segnet=lambda: case_segnet(networks, "segnet", 95, 2, 128),
+        config5_steps=lambda: case_config5(networks, util, args.ref, "config5_steps", 97, 2, [0, 1]),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):

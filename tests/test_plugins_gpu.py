@@ -9,13 +9,23 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("exp", ["minimaxgan_l1", "wgan_rmse", "experiment1_global_local_D"])
+@pytest.mark.parametrize("exp", ["minimaxgan_l1", "wgan_rmse", "experiment1_global_local_D", "wgan_perceptual_style_faceparsing"])
 def test_plugin_runs_and_checkpoints(tmp_path, exp):
     import gan_inpainting_amd  # noqa: F401
     from gan_inpainting_amd import train
     # config 1 of BASELINE.json: 64x64, bs=4 (num_downs=6, generalised critic head)
-    train.main(["-exp", exp, "-ep", "1", "-b", "4", "--imagedim", "64", "--saveevery", "1", "--evalevery", "1",
-                "--samples", "16", "--outdir", str(tmp_path), "--dtype", "fp32"])
+    if exp == "wgan_perceptual_style_faceparsing":
+        # config 5 needs the 7-level face-parsing network: 128x128; 6 batches so that batch 5 updates the generator
+        train.main(["-exp", exp, "-ep", "1", "-b", "2", "--imagedim", "128", "--saveevery", "1", "--evalevery", "1",
+                    "--samples", "12", "--outdir", str(tmp_path), "--dtype", "fp16", "--face-parsing", "random", "--g-every", "2"])
+        import pickle
+        with open(os.path.join(str(tmp_path), "model", exp, "training_epoch_history.obj"), "rb") as h:
+            hist = pickle.load(h)
+        assert {"recon_global", "recon_local", "tv", "face_parsing", "perceptual", "style", "g_adv"} <= set(hist[-1]["losses"])
+        assert all(v == v for v in hist[-1]["losses"].values())      # no NaN
+    else:
+        train.main(["-exp", exp, "-ep", "1", "-b", "4", "--imagedim", "64", "--saveevery", "1", "--evalevery", "1",
+                    "--samples", "16", "--outdir", str(tmp_path), "--dtype", "fp32"])
     ck = os.path.join(str(tmp_path), "model", exp, "epoch1_G.pt")
     assert os.path.exists(ck)
     sd = torch.load(ck)

@@ -116,6 +116,49 @@ def test_wgan_steps_vs_reference(dtype, overlap):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_config5_steps_vs_reference(dtype):
+    """wgan_perceptual_style_faceparsing.py:136-232: critic batch, then a batch with the generator update
+    (adversarial + global/local RMSE + face parsing through the frozen ngf=32 network + TV; perceptual /
+    style as logged constants) against the replay on the reference modules (case_config5)."""
+    import functools
+    fx = load("config5_steps")
+    seed, N = int(fx["seed"]), int(fx["N"])
+    G, (D,) = build(seed, [seed + 1], False, dtype)
+    seg = networks.UnetGenerator(1, 4, 7, ngf=32, norm_layer=functools.partial(torch.nn.BatchNorm2d, affine=True, track_running_stats=True),
+                                 use_dropout='False', dtype=dtype)
+    seg.load_state_dict(sd(op.make_unet_params(seed + 2, num_downs=7, ngf=32, in_c=1, out_c=4)))
+    seg = seg.cuda()
+    vgg = networks.VGG19Wrapper(max_pairs=N).cuda()
+    vgg.load_state_dict(sd(op.make_vgg19_params(seed + 3)))
+    oG = optim.RMSprop(G.parameters(), lr=0.00005)
+    oD = optim.RMSprop(D.parameters(), lr=0.00005)
+    step = trainer.WGANPerceptualStep(G, D, oG, oD, vgg=vgg, segment_model=seg, clip=0.01)
+    for it, upd in enumerate(int(v) for v in fx["pattern"]):
+        g, m = op.synth_batch(seed * 100 + it, N, 128, 128)
+        segm, _ = op.synth_segmentation(seed * 100 + 50 + it, N, 4, 128, 128)
+        G.impose_dropout_masks(unpack_masks(fx, f"it{it}_"))
+        L = step(torch.from_numpy(g).cuda(), torch.from_numpy(m).cuda(), bool(upd), segment=torch.from_numpy(segm).cuda())
+        torch.cuda.synchronize()
+        keys = ("d_loss_real", "d_loss_fake") + (("g_adv", "recon_global", "recon_local", "face_parsing", "tv") if upd else ())
+        for k in keys:
+            check_loss(f"config5 it{it}", k, L[k].item(), fx[f"it{it}_{k}"], dtype, floor=2e-3)
+        if upd:
+            # fp16 MFMA feature network in both cases (tests/test_auxloss_gpu.py for its own tolerances)
+            check_loss(f"config5 it{it}", "perceptual", L["perceptual"].item(), fx[f"it{it}_perceptual"], dtype, floor=1e-12, tol=1e-2)
+            check_loss(f"config5 it{it}", "style", L["style"].item(), fx[f"it{it}_style"], dtype, floor=1e-18, tol=3e-2)
+        assert relerr(abs_sums(D), fx[f"it{it}_d_param_stats"][:, 1]) <= STAT_TOL[dtype]
+        assert relerr(abs_sums(G), fx[f"it{it}_g_param_stats"][:, 1]) <= STAT_TOL[dtype]
+    # the generator update saw the face-parsing and TV gradients: per-tensor mean |grad| against the reference
+    names = [str(s) for s in fx["g_param_names"]]
+    ref = {n: float(v) for n, v in zip(names, fx["it1_g_grad_absmean"])}
+    gflow = util.GradFlow(G)
+    gflow.measure()
+    for n, v in gflow.as_dict().items():
+        tol = 5e-3 if dtype == "fp32" else 8e-2
+        assert abs(v - ref[n]) <= tol * abs(ref[n]) + 1e-12, f"absmean {n}: {v} vs {ref[n]}"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_dual_d_step_vs_reference(dtype):
     fx = load("dual_d_step")
     seed, N = int(fx["seed"]), int(fx["N"])
