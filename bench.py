@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512"],
+    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512", "config5_512"],
                     help="ssim_256 = the per-batch SSIM metric of experiment1_global_local_D.py:209 at 256x256 bs=32 (SURVEY 8f rank 2); wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
@@ -180,10 +180,14 @@ def main():
     from gan_inpainting_amd.lib.models import networks
     global H, W, BS
     gp = args.workload == "wgan_gp_128"
+    c5 = args.workload == "config5_512"
     if gp:
         H = W = 128
         BS = 16
         args.dtype = "fp32"
+    if c5:      # BASELINE configs[4]: wgan_perceptual_style_faceparsing 512x512 bs=8/GPU fp16
+        H = W = 512
+        BS = 8
 
     rank, world = parallel.init_from_env()
     if world != args.gpus and rank == 0:
@@ -215,8 +219,20 @@ def main():
         torch.distributed.broadcast(G.flat_params(), 0)
         torch.distributed.broadcast(D.flat_params(), 0)
         G.mark_dirty(), D.mark_dirty()
-    step = trainer.WGANStep(G, D, oG, oD, recon="l1" if gp else "rmse", clip=0.01, sync=sync, gp_lambda=10.0 if gp else 0.0,
-                            overlap=bool(args.overlap))
+    if c5:
+        import functools
+        torch.manual_seed(777)
+        seg = networks.UnetGenerator(1, 4, 7, ngf=32, norm_layer=functools.partial(torch.nn.BatchNorm2d, affine=True, track_running_stats=True),
+                                     use_dropout='False', dtype=args.dtype).to(dev).eval()
+        vgg = networks.VGG19Wrapper(max_pairs=BS).to(dev)
+        step = trainer.WGANPerceptualStep(G, D, oG, oD, vgg=vgg, segment_model=seg, clip=0.01, sync=sync, overlap=bool(args.overlap))
+        segments = [torch.randint(0, 4, (BS, H // 8, W // 8), device=dev).repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous()
+                    for _ in range(4)]
+        step_fn = lambda g, m, u, i: step(g, m, u, segment=segments[i % 4])   # noqa: E731
+    else:
+        step = trainer.WGANStep(G, D, oG, oD, recon="l1" if gp else "rmse", clip=0.01, sync=sync, gp_lambda=10.0 if gp else 0.0,
+                                overlap=bool(args.overlap))
+        step_fn = lambda g, m, u, i: step(g, m, u)   # noqa: E731
     batches = [synth(BS, 0x5EED0000 + rank * 1000 + i, dev) for i in range(4)]
     torch.cuda.synchronize()
     step.inputs_resident = True    # batches are resident in HBM before the first step is issued
@@ -230,13 +246,13 @@ def main():
     it = 0
     for _ in range(args.warmup):
         g, m = batches[it % len(batches)]
-        step(g, m, it % G_EVERY == G_EVERY - 1)
+        step_fn(g, m, it % G_EVERY == G_EVERY - 1, it)
         it += 1
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         g, m = batches[it % len(batches)]
-        step(g, m, it % G_EVERY == G_EVERY - 1)
+        step_fn(g, m, it % G_EVERY == G_EVERY - 1, it)
         it += 1
     barrier()
     dt = time.perf_counter() - t0
@@ -247,6 +263,15 @@ def main():
     losses = {k: float(v.item()) for k, v in step.L.items()}
 
     if rank != 0:
+        return
+    if c5:   # secondary workload: plain line
+        print(json.dumps({"metric": "training images/sec at 512x512 bs=8/GPU (wgan_perceptual_style_faceparsing)",
+                          "value": world * BS * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                          "config": {"workload": "wgan_perceptual_style_faceparsing 512x512 bs=8/GPU fp16 (BASELINE.json configs[4]): WGAN + "
+                                                 "global/local RMSE + frozen face-parsing U-Net (ngf=32, random init) + VGG-19 perceptual/style "
+                                                 "(random init) + TV; G update every 5th batch"}, "losses": losses}))
         return
     if gp:   # secondary workload: plain line, no roofline / cpu legs
         print(json.dumps({"metric": "training images/sec at 128x128 bs=16/GPU (wgan_l1 + gradient penalty, fp32)",
