@@ -74,6 +74,10 @@ PROTOTYPES = {
     "gi_vgg19_sync_weights": (_i, [_vp]),
     "gi_vgg19_perceptual_style": (_i, [_vp, _vp, _vp, _i, _f, _f, _vp, _vp]),
     "gi_vgg19_features": (_i, [_vp, _vp, _i, _i, _vp]),
+    "gi_resize_output_size": (_i, [_i, _i, _i, _vp, _vp]),
+    "gi_resize_table_bytes": (_i64, [_i, _i, _i, _i]),
+    "gi_resize_build_tables": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "gi_resize_to_tensor": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_convT_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_wgrad_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f]),

@@ -57,6 +57,19 @@ def build_networks(state, device, n_disc=1, sigmoid=True):
     return G.to(device), Ds
 
 
+def to_device_images(t, device, state):
+    """Loader item -> (n,1,h,w) float32 on the device. Decoded 8-bit images (lib.data.dataset with transform=None)
+    go through the device Resize + ToTensor (train.py:69-72); float tensors are taken as they are."""
+    t = t.to(device, non_blocking=True)
+    if t.dtype == torch.uint8:
+        tf = state.get("_device_transform")
+        if tf is None:
+            from ..lib.data.dataset import DeviceResizeToTensor
+            tf = state["_device_transform"] = DeviceResizeToTensor(state["imagedim"])
+        return tf(t if t.dim() == 3 else t.reshape(-1, t.shape[-2], t.shape[-1]))
+    return t.float().contiguous()
+
+
 def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn, d_names, pass_extra=False):
     """batch_fn(batch_index, ground, mask[, extra]) -> (loss dict of device scalars, g_updated: bool); extra = the
     loader's third item (the segmentation labels of dataset.py:35-51) when pass_extra is set."""
@@ -71,8 +84,8 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
         acc_g = torch.zeros(len(flow_G.names), device=device)
         acc_d = [torch.zeros(len(f.names), device=device) for f in flows_D]
         for bi, (ground, mask, extra) in enumerate(loaders["train"]):
-            ground = ground.to(device, non_blocking=True).float().contiguous()
-            mask = mask.to(device, non_blocking=True).float().contiguous()
+            ground = to_device_images(ground, device, state)
+            mask = to_device_images(mask, device, state)
             if pass_extra:
                 L, g_updated = batch_fn(bi, ground, mask, extra.to(device, non_blocking=True).contiguous())
             else:
@@ -98,7 +111,8 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
             if state.get("eval_fn"):
                 eval_hist.append(state["eval_fn"](net_G, loaders.get("test"), epoch))
             else:                                                # minimaxgan_l1.py:235-240
-                rec_eval = {k: evaluate.calculate_metric(device, loaders[k], net_G, mode=k, epoch=epoch)
+                prep = lambda t: to_device_images(t, device, state)   # noqa: E731
+                rec_eval = {k: evaluate.calculate_metric(device, loaders[k], net_G, mode=k, epoch=epoch, prepare=prep)
                             for k in ("train", "test") if loaders.get(k) is not None}
                 eval_hist.append(rec_eval)
                 logger.info("VALIDATION: %s", ", ".join(f"{k} - {v}" for k, v in rec_eval.items()))

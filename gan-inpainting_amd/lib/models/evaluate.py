@@ -45,13 +45,17 @@ class ReconMeter:
 
 @torch.no_grad()
 def calculate_metric(device, loader, net, fid_stats=(-1, -1), mode="test", inception_model=None, epoch=None,
-                     is_flip_mask=False):
-    """evaluate.py:85-177. `loader` yields (input, mask, _) like the reference's datasets."""
+                     is_flip_mask=False, prepare=None):
+    """evaluate.py:85-177. `loader` yields (input, mask, _) like the reference's datasets; `prepare` (optional)
+    maps a loader item to a (n,1,h,w) float32 device tensor (the device Resize + ToTensor for decoded bytes)."""
     lib = B.lib()
     meter = ReconMeter(device)
     for inp, mask, *_ in loader:
-        inp = inp.to(device, non_blocking=True).float().contiguous()
-        mask = mask.to(device, non_blocking=True).float().contiguous()
+        if prepare is not None:
+            inp, mask = prepare(inp), prepare(mask)
+        else:
+            inp = inp.to(device, non_blocking=True).float().contiguous()
+            mask = mask.to(device, non_blocking=True).float().contiguous()
         m = torch.empty_like(mask)
         masked = torch.empty_like(inp)
         B.check(lib.gi_mask_apply(B.get_ctx(inp.device), B.ptr(inp), B.ptr(mask), B.ptr(m), B.ptr(masked), inp.numel(),

@@ -4,8 +4,9 @@
 on the HIP backend. The reference launcher does not run as written (wrong
 variable names at :173,:180,:183 and a hard-coded dataset path :64); this one iterates over
 --experiments as evidently intended and takes the data as --data synthetic (the benchmark's masked-
-image batches) or --data <dir> of .npy pairs. FID statistics / the face-segmentation
-model (train.py:157-175) are outside the backend's scope and are not loaded.
+image batches) or --data <dir> in the reference's dataset layout (csv/train_all_masks.csv, csv/test_all_masks.csv listing image
+files; decoded on the host with PIL, resized + normalised on the device). FID statistics (train.py:157-166) are
+outside the backend's scope; the face-segmentation checkpoint (:169-175) is not available (--face-parsing random).
 
     python gan-inpainting_amd/train.py -exp wgan_l1 -ep 2 -b 32 --imagedim 256 --data synthetic
     python -m torch.distributed.run --nproc-per-node 8 gan-inpainting_amd/train.py -exp wgan_rmse ...
@@ -79,11 +80,23 @@ def main(argv=None):
     if torch.cuda.is_available():
         torch.cuda.set_device(parallel.local_device())
     if args.data != "synthetic":
-        raise NotImplementedError("only --data synthetic is wired in round 1 (the input pipeline is SURVEY.md 8f rank 4)")
-    mk = lambda n, seed: torch.utils.data.DataLoader(   # noqa: E731
-        SyntheticInpainting(n, args.imagedim, seed + 100000 * rank), batch_size=args.batchsize, shuffle=True, num_workers=0,
-        drop_last=True)
-    loaders = {"train": mk(args.samples, 1), "test": mk(max(args.batchsize, 64), 2), "extra": mk(max(args.batchsize, 64), 3)}
+        # the reference's dataset layout (train.py:64-90): <dir>/csv/{train,test}_all_masks.csv with columns
+        # groundtruth_source, mask_source[, segment]; decode on the host, Resize + ToTensor on the device
+        import pandas as pd
+        from gan_inpainting_amd.lib.data import dataset
+
+        def mk_real(csv, shuffle):
+            df = pd.read_csv(os.path.join(args.data, "csv", csv))
+            if world > 1:
+                df = df.iloc[rank::world].reset_index(drop=True)          # one shard per rank
+            return torch.utils.data.DataLoader(dataset.InpaintingDataset(args.data, dataframe=df, transform=None),
+                                               batch_size=args.batchsize, shuffle=shuffle, num_workers=0, drop_last=True)
+        loaders = {"train": mk_real("train_all_masks.csv", True), "test": mk_real("test_all_masks.csv", True)}     # :75-90
+    else:
+        mk = lambda n, seed: torch.utils.data.DataLoader(   # noqa: E731
+            SyntheticInpainting(n, args.imagedim, seed + 100000 * rank), batch_size=args.batchsize, shuffle=True, num_workers=0,
+            drop_last=True)
+        loaders = {"train": mk(args.samples, 1), "test": mk(max(args.batchsize, 64), 2), "extra": mk(max(args.batchsize, 64), 3)}
     segmentation_model = None
     if args.face_parsing == "random":
         import functools

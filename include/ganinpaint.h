@@ -226,6 +226,18 @@ int gi_vgg19_perceptual_style(gi_vgg* v, const float* output, const float* targe
 /* feature map of tap 0..4 as (n,C,h,w) fp32 (parity checks) */
 int gi_vgg19_features(gi_vgg* v, const float* x, int n, int tap, float* out_nchw);
 
+/* ---- input transform: transforms.Resize(size) + ToTensor() of train.py:69-72 on decoded
+ *      8-bit grey images (lib/data/dataset.py:6-12). Bit-exact restatement of Pillow's antialiased bilinear
+ *      resampler (22-bit fixed point, horizontal pass first, uint8 intermediate), then /255. ------------- */
+int gi_resize_output_size(int in_h, int in_w, int size, int* out_h, int* out_w);   /* Resize(int): smaller edge */
+int64_t gi_resize_table_bytes(int in_h, int in_w, int out_h, int out_w);
+/* host-computed coefficient tables -> tables_dev (device, gi_resize_table_bytes); once per geometry; synchronises */
+int gi_resize_build_tables(gi_ctx* ctx, int in_h, int in_w, int out_h, int out_w, void* tables_dev);
+/* src: n x in_h x in_w uint8 (device). dst_f32 (n,out_h,out_w) in [0,1] and/or dst_u8 (either may be NULL).
+ * tmp: n*in_h*out_w bytes (device). */
+int gi_resize_to_tensor(gi_ctx* ctx, const void* tables_dev, const uint8_t* src, int n, int in_h, int in_w,
+                        int out_h, int out_w, float* dst_f32, uint8_t* dst_u8, uint8_t* tmp);
+
 /* ---- single-layer entry points (unit parity tests and kernel roofline measurements) -------- */
 /* out[n,y,x,a] = act( sum_{ky,kx,b} in[n,2y-1+ky,2x-1+kx,b] * w[a][ky][kx][b] ), NHWC, dtype T.
  * in: (n,H,W,cb) ld=ldin; out: (n,H/2,W/2,ca) ld=ldout. w_packed is T [ca][16*cb].

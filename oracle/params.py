@@ -194,3 +194,13 @@ def make_vgg19_params(seed, n_convs=16):
         P[f"features.{i}.bias"] = (rng.standard_normal(cout) * 0.05).astype(np.float32)
         cin = cout
     return P
+
+
+def synth_u8_image(seed, h, w):
+    """Photo-like uint8 grey image (smooth gradients + texture + saturated patches) for the input-pipeline tests."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = 127 + 90 * np.sin(xx / (7.0 + seed % 5)) * np.cos(yy / 11.0) + rng.normal(0, 25, (h, w))
+    img[: h // 5, : w // 4] = 255
+    img[-(h // 6 + 1):, -(w // 7 + 1):] = 0
+    return np.clip(img, 0, 255).astype(np.uint8)

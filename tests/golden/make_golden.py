@@ -668,6 +668,28 @@ def case_config5(networks, util, ref_root, name, seed, N, pattern):
     return fx
 
 
+RESIZE_CASES = [  # (seed, in_h, in_w, size)
+    (201, 218, 178, 128), (202, 1024, 1024, 256), (203, 200, 300, 64), (204, 50, 50, 128), (205, 100, 37, 16),
+    (206, 9, 1000, 7), (207, 128, 128, 128),
+]
+
+
+def case_resize(name):
+    """transforms.Resize(size) + ToTensor() (train.py:69-72) = Pillow's antialiased bilinear resize of the 'L'
+    image + /255. torchvision is absent; the arithmetic is Pillow's (importable here, 12.2.0): outputs recorded
+    from PIL.Image.resize itself, oracle/resize_ref.py asserted bit-equal."""
+    from PIL import Image
+    from oracle import resize_ref as rr
+    fx = {"cases": np.array(RESIZE_CASES, dtype=np.int64)}
+    for i, (seed, h, w, size) in enumerate(RESIZE_CASES):
+        a = op.synth_u8_image(seed, h, w)
+        nh, nw = rr.resized_output_size(h, w, size)
+        ref = np.asarray(Image.fromarray(a, mode="L").resize((nw, nh), Image.BILINEAR))
+        assert np.array_equal(rr.resize_bilinear_u8(a, nh, nw), ref), "oracle != Pillow for case %d" % i
+        fx["out_%d" % i] = ref
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -690,6 +712,7 @@ def main():
         evalmetrics=lambda: case_evalmetrics(args.ref, "evalmetrics"),
         auxloss=lambda: case_auxloss(args.ref, "auxloss"),
         segnet=lambda: case_segnet(networks, "segnet", 95, 2, 128),
+        resize=lambda: case_resize("resize"),
         config5_steps=lambda: case_config5(networks, util, args.ref, "config5_steps", 97, 2, [0, 1]),
     )
     for name, fn in cases.items():

@@ -171,3 +171,19 @@ def test_config5_losses():
     labels, logits = op.synth_segmentation(seed + 3, n, 4, hw, hw)
     ce = orc.weighted_cross_entropy(torch.tanh(torch.from_numpy(logits)), torch.from_numpy(labels), torch.tensor([0, 1.2, 0.7, 0.7]))
     assert relerr(float(ce), float(fx["ce_0"])) < 1e-6
+
+
+def test_resize_oracle_equals_pillow_fixture():
+    """oracle/resize_ref.py == PIL.Image.resize(BILINEAR) bytes recorded in the fixture (and == Pillow itself when
+    it is importable where the tests run)."""
+    from oracle import resize_ref as rr
+    fx = load("resize")
+    for i, (seed, h, w, size) in enumerate(fx["cases"].tolist()):
+        a = op.synth_u8_image(seed, h, w)
+        nh, nw = rr.resized_output_size(h, w, size)
+        assert np.array_equal(rr.resize_bilinear_u8(a, nh, nw), fx[f"out_{i}"]), i
+        try:
+            from PIL import Image
+        except ImportError:
+            continue
+        assert np.array_equal(np.asarray(Image.fromarray(a, mode="L").resize((nw, nh), Image.BILINEAR)), fx[f"out_{i}"])

@@ -44,3 +44,32 @@ def test_plugin_runs_and_checkpoints(tmp_path, exp):
         with open(os.path.join(str(tmp_path), "model", exp, "training_epoch_history.obj"), "rb") as h:
             hist = pickle.load(h)
         assert 0.0 < hist[-1]["losses"]["ssim"] <= 1.0                      # experiment1_global_local_D.py:209
+
+
+def test_real_data_layout_through_the_device_transform(tmp_path):
+    """--data <dir>: the reference's dataset layout (train.py:64-90) with PNG files of a different size than
+    --imagedim; decode on the host, Resize + ToTensor on the device, one epoch of minimaxgan_l1."""
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    import numpy as np
+    import pandas as pd
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import train
+    root = tmp_path / "data"
+    (root / "csv").mkdir(parents=True)
+    (root / "img").mkdir()
+    rng = np.random.Generator(np.random.PCG64(1))
+    rows = []
+    for i in range(8):
+        g = rng.integers(0, 256, (96, 96), dtype=np.uint8)
+        m = np.zeros((96, 96), np.uint8)
+        m[20 + i: 60 + i, 30: 70] = 255
+        Image.fromarray(g, mode="L").save(root / "img" / f"g{i}.png")
+        Image.fromarray(m, mode="L").save(root / "img" / f"m{i}.png")
+        rows.append({"groundtruth_source": f"img/g{i}.png", "mask_source": f"img/m{i}.png"})
+    pd.DataFrame(rows).to_csv(root / "csv" / "train_all_masks.csv", index=False)
+    pd.DataFrame(rows[:4]).to_csv(root / "csv" / "test_all_masks.csv", index=False)
+    out = tmp_path / "run"
+    train.main(["-exp", "minimaxgan_l1", "-ep", "1", "-b", "4", "--imagedim", "64", "--saveevery", "1", "--evalevery", "1",
+                "--data", str(root), "--outdir", str(out), "--dtype", "fp32"])
+    assert os.path.exists(os.path.join(str(out), "model", "minimaxgan_l1", "epoch1_G.pt"))
