@@ -9,6 +9,8 @@
 // ds_read_b64_tr_b16 (fp16) or directly (fp32, one value per lane). dW is [a][16*b] row-major
 // fp32 and is accumulated with global float atomics (split-K over pixel ranges fills the chip:
 // the shallow layers have only a handful of output tiles but 10^5 pixels).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -232,7 +234,9 @@ int run(hipStream_t st, const WgradArgs& a) {
   const int tiles = (a.ca / 128) * (16 * a.cb / 128);
   constexpr int BKP = F16 ? 64 : 32;
   const int ktiles = (p.P + BKP - 1) / BKP;
-  int split = (1024 + tiles - 1) / tiles;
+  static int target = -1;   // workgroups to aim for (GI_WGRAD_BLOCKS: tools only)
+  if (target < 0) { const char* e = getenv("GI_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }   // 2 workgroups per CU in one wave; 1024 measured 10-28 % slower (atomics)
+  int split = (target + tiles - 1) / tiles;
   if (split > ktiles / 8) split = ktiles / 8;
   if (split < 1) split = 1;
   p.tiles_per_split = (ktiles + split - 1) / split;
