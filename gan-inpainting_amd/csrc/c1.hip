@@ -154,13 +154,19 @@ __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __rest
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
   const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  h8_t af[MTC];   // A[row = channel mt*16 + lr][k = tap 8*kq + j], zero for kq >= 2
+  // A[row lr of tile mt][k = tap 8*kq + j] (zero for kq >= 2) holds the weights of channel
+  //   ch(mt, lr) = (mt >> 2) * 64 + (lr >> 2) * 16 + (mt & 3) * 4 + (lr & 3)
+  // D row i of a tile lands in lane group kq = i >> 2, register r = i & 3, so after its four tiles a lane owns the
+  // 16 CONSECUTIVE channels (mt >> 2) * 64 + kq * 16 .. + 15 of its pixel: two 16-byte stores, and the four lanes
+  // of a pixel write its 128-byte row in one instruction (the natural order gave 8-byte pieces on 16 lines).
+  h8_t af[MTC];
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
     af[mt] = zero;
     if (kq < 2) {
+      const int ch = (mt >> 2) * 64 + (lr >> 2) * 16 + (mt & 3) * 4 + (lr & 3);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) af[mt][j] = (half_t)w[(mt * 16 + lr) * 16 + kq * 8 + j];
+      for (int j = 0; j < 8; ++j) af[mt][j] = (half_t)w[ch * 16 + kq * 8 + j];
     }
   }
   const int H = 2 * Hs, W = 2 * Ws;
@@ -195,13 +201,17 @@ __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __rest
     const int64_t pix = g * 16 + lr;
     char* dst = out + ((pix * ldout + coffout) << 1);
 #pragma unroll
-    for (int mt = 0; mt < MTC; ++mt) {
-      f4_t acc = {0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf, acc, 0, 0, 0);
-      h4_t o;
+    for (int mq = 0; mq < MTC / 4; ++mq) {
+      h8_t o[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (half_t)act_f(acc[r], act);
-      *(h4_t*)(dst + ((mt * 16 + kq * 4) << 1)) = o;    // D[row = channel][col = pixel]: rows 4*kq + r
+      for (int m4 = 0; m4 < 4; ++m4) {
+        f4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mq * 4 + m4], bf, acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[m4 >> 1][(m4 & 1) * 4 + r] = (half_t)act_f(acc[r], act);
+      }
+      *(h8_t*)(dst + ((mq * 64 + kq * 16) << 1)) = o[0];         // channels mq*64 + kq*16 + 0..7
+      *(h8_t*)(dst + ((mq * 64 + kq * 16 + 8) << 1)) = o[1];     //                          + 8..15
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) bv[j] = bn[j];
@@ -683,7 +693,7 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
   GI_REQUIRE(c % 8 == 0 && c <= 1024, "c1_gather: c=%d", c);
   const int64_t total = (int64_t)n * Hs * Ws * (c / 8);
   const int groups = c / 8;
-  if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 4 == 0 && coffout % 4 == 0) {
+  if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 8 == 0 && coffout % 8 == 0) {
     const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
     const int grid = grid_for(ngroups, 4, 256 * 8);
     if (c == 64)

@@ -456,7 +456,9 @@ int run(hipStream_t st, IgemmArgs& a) {
   int splitk = 1;
   if (a.force_splitk > 0) splitk = a.force_splitk;
   else if (tiles < 128 && kp.nk >= 8) {
-    splitk = (384 + tiles - 1) / tiles;
+    static int target = -1;   // workgroups to aim for (GI_IGEMM_SPLIT_BLOCKS: tools only)
+    if (target < 0) { const char* e = getenv("GI_IGEMM_SPLIT_BLOCKS"); target = e ? atoi(e) : 384; }
+    splitk = (target + tiles - 1) / tiles;
     if (splitk > kp.nk / 4) splitk = kp.nk / 4;
     if (splitk > 64) splitk = 64;
     if (splitk < 1) splitk = 1;
