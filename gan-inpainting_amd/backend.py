@@ -35,6 +35,7 @@ PROTOTYPES = {
     "gi_net_sync_weights": (_i, [_vp]),
     "gi_net_set_train": (_i, [_vp, _i]),
     "gi_net_set_loss_scale": (_i, [_vp, _f]),
+    "gi_net_set_bn_groups": (_i, [_vp, _i]),
     "gi_net_set_dropout_seed": (_i, [_vp, _u64]),
     "gi_net_dropout_mask": (_i, [_vp, _i, _i, _vp, _i64]),
     "gi_net_set_dropout_mask": (_i, [_vp, _i, _i, _vp]),

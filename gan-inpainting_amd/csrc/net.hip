@@ -52,6 +52,7 @@ struct gi_net {
   uint64_t drop_seed = 0x5EED0000ull, drop_counter = 0;
   // unet
   int nd = 0, ngf = 0;
+  int bn_groups = 1;                 // discriminator: the batch holds this many independent BatchNorm groups (stacked real|fake)
   int bwd_eval = 0;                  // (transient) the backward in progress differentiates an eval-mode forward
   int out_c = 1;                     // output channels; > 1: u1 runs on the generic kernels with b zero-padded to 64
   int64_t oU1 = -1, oUp1Pad = -1, oUp1Packed = -1, oUp1Phase = -1;
@@ -82,7 +83,7 @@ struct gi_net {
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
   int64_t oD2 = -1, oTZ = -1, oGimg = -1, oVimg = -1, oGPs = -1, oGPpart = -1, oGPsums = -1, oTh = -1;
   int gp_slot = -1;
-  std::vector<int> slot_n, slot_train;
+  std::vector<int> slot_n, slot_train, slot_groups;
   std::vector<std::vector<const uint8_t*>> ext_mask;  // [slot][level]
 
   float* params = nullptr;
@@ -305,7 +306,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
     const int64_t pix = N * (H >> i) * (W >> i);
     net->ogA[i] = A.take(pix * chans[i] * T);
     maxD = max64(maxD, pix * chans[i] * T);
-    maxPart = max64(maxPart, part_rows(pix) * 2 * chans[i]);
+    maxPart = max64(maxPart, part_rows(pix) * 2 * chans[i] * 3);   // x3: room for the per-group column pass (BN groups)
     if (pix <= 32768) maxSplit = max64(maxSplit, pix * chans[i] * 4);
   }
   net->oD = A.take(maxD);
@@ -341,13 +342,14 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oOut = S.take(N * 4);
   net->oX = S.take(N * H * W * 4);
   int64_t stat_floats = 0;
-  for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 4 * net->dbn[i].c; }
+  for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 2 * 4 * net->dbn[i].c; }   // x2: BN groups
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
   net->gp_slot = n_slots;                      // one private activation set for the gradient penalty
   net->slot_base = A.take(S.size * (n_slots + 1));
   net->slot_n.assign(n_slots + 1, 0);
   net->slot_train.assign(n_slots + 1, 0);
+  net->slot_groups.assign(n_slots + 1, 1);
   *out = net;
   return GI_OK;
 }
@@ -439,6 +441,12 @@ extern "C" int gi_net_set_train(gi_net* net, int train) {
   net->train = train ? 1 : 0;
   return GI_OK;
 }
+extern "C" int gi_net_set_bn_groups(gi_net* net, int groups) {
+  GI_REQUIRE(net && net->kind == 1, "set_bn_groups: discriminator handle required");
+  GI_REQUIRE(groups == 1 || groups == 2, "set_bn_groups: groups=%d (1 or 2)", groups);
+  net->bn_groups = groups;
+  return GI_OK;
+}
 extern "C" int gi_net_set_loss_scale(gi_net* net, float scale) {
   GI_REQUIRE(net && scale > 0.f, "set_loss_scale: scale must be > 0");
   net->loss_scale = scale;
@@ -470,20 +478,43 @@ extern "C" int gi_net_set_dropout_mask(gi_net* net, int slot, int level, const u
 namespace {
 
 struct BNPtrs { float *scale, *shift, *mean, *inv; };
-BNPtrs bn_ptrs(const gi_net* net, int slot, const BN& b) {
-  float* base = (float*)net->slot(slot, net->oStats) + b.stat_off;
+BNPtrs bn_ptrs(const gi_net* net, int slot, const BN& b, int group = 0) {
+  float* base = (float*)net->slot(slot, net->oStats) + b.stat_off + (int64_t)group * 4 * b.c;
   return {base, base + b.c, base + 2 * b.c, base + 3 * b.c};
 }
 
-// raw (pixels,c) conv output with per-tile partial statistics -> normalise + activation into dst
+// raw (pixels,c) conv output with per-tile partial statistics -> normalise + activation into dst.
+// With bn_groups = g the batch is g consecutive groups of pixels/g pixels, each normalised with its OWN batch
+// statistics (the reference calls the critic separately on the real and on the fake batch: two BatchNorm
+// populations, running statistics updated group by group in that order).
 int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixels, int ntiles, void* dst, int ldy,
                int coffy, int act, const uint8_t* drop, float drop_scale, int train) {
   hipStream_t st = net->ctx->stream;
-  BNPtrs p = bn_ptrs(net, slot, b);
-  GI_TRY(op_bn_finalize(st, (const float*)net->shared(net->oPart), ntiles, b.c, pixels, net->params + b.gamma_off,
-                        net->params + b.beta_off, net->buffers + b.rmean_off, net->buffers + b.rvar_off, p.scale, p.shift,
-                        p.mean, p.inv, train, 0.1f, 1e-5f));
-  return op_bn_apply(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, p.scale, p.shift, act, drop, drop_scale);
+  const int g = net->kind == 1 ? net->bn_groups : 1;
+  const int64_t pg = pixels / g;
+  const size_t T = net->tsz();
+  // the GEMM epilogue's partial rows can be split between the groups when a group is a whole number of tiles
+  // (tile heights are 256, 128 or a power of two <= 64); otherwise each group's statistics come from a column pass
+  const bool aligned = g == 1 || (pg % 256 == 0 && ntiles % g == 0);
+  for (int j = 0; j < g; ++j) {
+    BNPtrs p = bn_ptrs(net, slot, b, j);
+    const char* rj = (const char*)raw + (int64_t)j * pg * b.c * T;
+    const float* part = (const float*)net->shared(net->oPart);
+    int rows = ntiles / g;
+    if (aligned) {
+      part += (int64_t)j * rows * 2 * b.c;
+    } else {
+      float* scratch = (float*)net->shared(net->oPart) + (int64_t)ntiles * 2 * b.c;
+      GI_REQUIRE((int64_t)ntiles * 2 * b.c + (pg / 32 + 8) * 2 * b.c <= net->part_floats, "internal: partials buffer too small for a column pass");
+      GI_TRY(op_col_stats(st, net->dtype, rj, pg, b.c, scratch, &rows));
+      part = scratch;
+    }
+    GI_TRY(op_bn_finalize(st, part, rows, b.c, pg, net->params + b.gamma_off, net->params + b.beta_off, net->buffers + b.rmean_off,
+                          net->buffers + b.rvar_off, p.scale, p.shift, p.mean, p.inv, train, 0.1f, 1e-5f));
+    GI_TRY(op_bn_apply(st, net->dtype, rj, (char*)dst + (int64_t)j * pg * ldy * T, pg, b.c, ldy, coffy, p.scale, p.shift, act,
+                       drop ? drop + (int64_t)j * pg * b.c : nullptr, drop_scale));
+  }
+  return GI_OK;
 }
 
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
@@ -517,24 +548,32 @@ int wgrad(gi_net* net, const void* S, int ca, int ldS, int coffS, int relu_S, co
 int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, const void* g2, int ldg2, int coffg2,
                const void* y, int ldy, int coffy, const void* x, void* dx, int64_t pixels, int c, int act, float drop_scale,
                const BN* bn, int need_wgrad) {
-  ActBnBwdArgs a;
-  memset(&a, 0, sizeof(a));
-  a.g1 = g1; a.ldg1 = ldg1; a.coffg1 = coffg1;
-  a.g2 = g2; a.ldg2 = ldg2; a.coffg2 = coffg2;
-  a.y = y; a.ldy = ldy; a.coffy = coffy;
-  a.x = x; a.dx = dx; a.pixels = pixels; a.c = c; a.act = act; a.drop_scale = drop_scale;
-  a.has_bn = bn ? 1 : 0;
-  a.eval_bn = net->bwd_eval;
-  if (bn) {
-    BNPtrs p = bn_ptrs(net, slot, *bn);
-    a.gamma = net->params + bn->gamma_off; a.save_mean = p.mean; a.save_invstd = p.inv;
-    a.dgamma = need_wgrad ? net->grads + bn->gamma_off : nullptr;
-    a.dbeta = need_wgrad ? net->grads + bn->beta_off : nullptr;
+  const int g = (net->kind == 1 && bn) ? net->bn_groups : 1;   // BatchNorm groups: reductions per group
+  const int64_t pg = pixels / g;
+  const int64_t T = (int64_t)net->tsz();
+  for (int j = 0; j < g; ++j) {
+    ActBnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    const int64_t o = (int64_t)j * pg;
+    a.g1 = g1 ? (const char*)g1 + o * ldg1 * T : nullptr; a.ldg1 = ldg1; a.coffg1 = coffg1;
+    a.g2 = g2 ? (const char*)g2 + o * ldg2 * T : nullptr; a.ldg2 = ldg2; a.coffg2 = coffg2;
+    a.y = (const char*)y + o * ldy * T; a.ldy = ldy; a.coffy = coffy;
+    a.x = x ? (const char*)x + o * c * T : nullptr; a.dx = (char*)dx + o * c * T;
+    a.pixels = pg; a.c = c; a.act = act; a.drop_scale = drop_scale;
+    a.has_bn = bn ? 1 : 0;
+    a.eval_bn = net->bwd_eval;
+    if (bn) {
+      BNPtrs p = bn_ptrs(net, slot, *bn, j);
+      a.gamma = net->params + bn->gamma_off; a.save_mean = p.mean; a.save_invstd = p.inv;
+      a.dgamma = need_wgrad ? net->grads + bn->gamma_off : nullptr;
+      a.dbeta = need_wgrad ? net->grads + bn->beta_off : nullptr;
+    }
+    a.inv_loss_scale = 1.f / net->loss_scale;
+    a.partials = (float*)net->shared(net->oPart);
+    a.sums = (float*)net->shared(net->oSums);
+    GI_TRY(op_act_bn_bwd(net->ctx->stream, net->dtype, a));
   }
-  a.inv_loss_scale = 1.f / net->loss_scale;
-  a.partials = (float*)net->shared(net->oPart);
-  a.sums = (float*)net->shared(net->oSums);
-  return op_act_bn_bwd(net->ctx->stream, net->dtype, a);
+  return GI_OK;
 }
 
 __global__ void __launch_bounds__(256) fill_f32_kernel(float* dst, int count, float v) {
@@ -754,6 +793,8 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
 int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   hipStream_t st = net->ctx->stream;
   const int dt = net->dtype, train = net->train, H = net->H, W = net->W;
+  GI_REQUIRE(n % net->bn_groups == 0, "patchgan_forward: %d images do not split into %d BatchNorm groups", n, net->bn_groups);
+  net->slot_groups[s] = net->bn_groups;
   net->slot_n[s] = n;
   net->slot_train[s] = train;
   GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
@@ -780,6 +821,8 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   hipStream_t st = net->ctx->stream;
   const int dt = net->dtype, H = net->H, W = net->W, n = net->slot_n[s];
   GI_REQUIRE(n > 0 && net->slot_train[s], "patchgan_backward: slot %d holds no train-mode forward", s);
+  GI_REQUIRE(net->slot_groups[s] == net->bn_groups, "patchgan_backward: slot %d was produced with %d BatchNorm groups, the net is set to %d", s,
+             net->slot_groups[s], net->bn_groups);
   net->bwd_eval = 0;
   const float LS = net->loss_scale, iLS = 1.f / LS;
   void* D = net->shared(net->oD);

@@ -106,6 +106,7 @@ class HipNet(nn.Module):
         self._loss_scale = 65536.0 if self._dtype == B.GI_F16 else 1.0
         self._nbt_pending = 0
         self.always_sync = False
+        self._slot_groups = [1] * self.n_slots
 
     # ---- subclass hooks ----------------------------------------------------------------------
     def _create_handle(self, ctx, H, W, max_n):
@@ -292,9 +293,12 @@ class HipNet(nn.Module):
                                 self._ws.data_ptr() + off, nbytes))
         B.check(lib.gi_net_set_loss_scale(h, self._loss_scale))
         self._handle, self._geom = h, (H, W, n)
+        self._groups_set = 1
         self._dirty = True
 
-    def _forward_raw(self, x):
+    def _forward_raw(self, x, bn_groups=1):
+        """bn_groups = 2 (discriminators only): x stacks two equally sized batches that are normalised with
+        independent BatchNorm statistics, i.e. two reference forward calls in one launch sequence."""
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"expected (N,1,H,W) input, got {tuple(x.shape)}")
         if x.dtype != torch.float32 or not x.is_cuda:
@@ -307,13 +311,17 @@ class HipNet(nn.Module):
             B.check(lib.gi_net_sync_weights(self._handle))
             self._dirty = False
         B.check(lib.gi_net_set_train(self._handle, 1 if self.training else 0))
+        if bn_groups != 1 or self._groups_set != 1:
+            B.check(lib.gi_net_set_bn_groups(self._handle, bn_groups))
+            self._groups_set = bn_groups
         slot = self._next_slot
         self._next_slot = (slot + 1) % self.n_slots
         self._slot_gen[slot] += 1
+        self._slot_groups[slot] = bn_groups
         y = torch.empty(self._output_shape(n, H, W), dtype=torch.float32, device=x.device)
         B.check(lib.gi_net_forward(self._handle, slot, B.ptr(x), B.ptr(y), n))
         if self.training:
-            self._nbt_pending += 1   # num_batches_tracked is bookkeeping only: materialised lazily
+            self._nbt_pending += bn_groups   # num_batches_tracked is bookkeeping only: materialised lazily
         self._last_slot = slot
         return y, slot, self._slot_gen[slot]
 
@@ -325,6 +333,9 @@ class HipNet(nn.Module):
         n = dy.shape[0]
         dx = torch.empty((n, 1, self._geom[0], self._geom[1]), dtype=torch.float32, device=dy.device) if need_dx else None
         self._attach_grads()
+        if self._slot_groups[slot] != self._groups_set:
+            B.check(B.lib().gi_net_set_bn_groups(self._handle, self._slot_groups[slot]))
+            self._groups_set = self._slot_groups[slot]
         B.check(B.lib().gi_net_backward(self._handle, slot, B.ptr(dy), B.ptr(dx), 1 if need_wgrad else 0))
         return dx
 

@@ -149,8 +149,8 @@ class _StepBase:
         self.sync.wait(flat.device)
 
     @staticmethod
-    def _fwd(net, x):
-        y, slot, gen = net._forward_raw(x)
+    def _fwd(net, x, bn_groups=1):
+        y, slot, gen = net._forward_raw(x, bn_groups) if bn_groups != 1 else net._forward_raw(x)
         return y, (slot, gen)
 
     @staticmethod
@@ -198,9 +198,14 @@ class WGANStep(_StepBase):
     """clip > 0 applies the reference's weight clipping after the critic update. If opt_D is this
     package's RMSprop its `clamp` is set so the clip is fused into the optimizer kernel."""
 
-    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None, gp_lambda=0.0, overlap=False):
+    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", clip=0.01, sync=None, gp_lambda=0.0, overlap=False, stacked=True):
         super().__init__(net_G, [net_D], net_G.device, sync)
         self.D, self.optG, self.optD, self.recon, self.clip = net_D, opt_G, opt_D, recon, clip
+        # stacked=True: the critic's two calls of a batch, D(ground) and D(inpainted) (wgan_l1.py:134-135), run as ONE
+        # 2n batch with independent BatchNorm statistics per half (gi_net_set_bn_groups): same arithmetic per
+        # image, half the launches, and one weight-gradient GEMM over both halves instead of two accumulating ones.
+        self.stacked = stacked
+        self._x2 = None
         # overlap=True: the critic runs on a side HIP stream. Its real-image forward/backward does not depend
         # on the generator forward, and in critic-only batches the next batch's generator forward does not
         # depend on this batch's critic update, so the two networks' small / latency-bound kernels fill each
@@ -249,13 +254,17 @@ class WGANStep(_StepBase):
             if not self.inputs_resident:
                 sD.wait_event(e0)
             self.optD.zero_grad()
-            pr, tr = self._fwd(self.D, ground)
-            o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)
-            self._bwd(self.D, tr, self.dpred, False, True)
-            sD.wait_event(e_inp)
-            pf, tf = self._fwd(self.D, inp)
-            o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)
-            self._bwd(self.D, tf, self.dpred, False, True)
+            if self.stacked:
+                sD.wait_event(e_inp)
+                self._critic_stacked(ground, inp)
+            else:
+                pr, tr = self._fwd(self.D, ground)
+                o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)
+                self._bwd(self.D, tr, self.dpred, False, True)
+                sD.wait_event(e_inp)
+                pf, tf = self._fwd(self.D, inp)
+                o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)
+                self._bwd(self.D, tf, self.dpred, False, True)
             if self.gp_lambda > 0:
                 self.L["gp"] = self.D.gradient_penalty(ground, inp, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
             self._reduce(self.D)
@@ -287,12 +296,15 @@ class WGANStep(_StepBase):
         gen, gtok = self._fwd(self.G, self.masked)                              # every batch, :119
         o.composite(self.masked, gen, self.mask_c, self.inpainted)
         self.optD.zero_grad()
-        pr, tr = self._fwd(self.D, ground)                                      # :134
-        pf, tf = self._fwd(self.D, self.inpainted)                              # :135
-        o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)       # backward(one)  :137-138
-        self._bwd(self.D, tr, self.dpred, False, True)
-        o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)       # backward(mone) :140-141
-        self._bwd(self.D, tf, self.dpred, False, True)
+        if self.stacked:
+            self._critic_stacked(ground, self.inpainted)
+        else:
+            pr, tr = self._fwd(self.D, ground)                                      # :134
+            pf, tf = self._fwd(self.D, self.inpainted)                              # :135
+            o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)       # backward(one)  :137-138
+            self._bwd(self.D, tr, self.dpred, False, True)
+            o.adv(pf, MEAN, 0.0, self._loss("d_loss_fake"), self.dpred, -1.0)       # backward(mone) :140-141
+            self._bwd(self.D, tf, self.dpred, False, True)
         if self.gp_lambda > 0:
             self.L["gp"] = self.D.gradient_penalty(ground, self.inpainted, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
         self._reduce(self.D)
@@ -309,6 +321,19 @@ class WGANStep(_StepBase):
             self._bwd_G(gtok, self.g_gen)
             self.optG.step()
         return self.L
+
+    def _critic_stacked(self, ground, inp):
+        """D(ground) and D(inpainted) of wgan_l1.py:134-141 as one [ground | inpainted] batch, BatchNorm per half."""
+        o, n = self.ops, ground.shape[0]
+        if self._x2 is None or self._x2.shape[0] != 2 * n or self._x2.shape[2:] != ground.shape[2:]:
+            self._x2 = torch.empty((2 * n,) + tuple(ground.shape[1:]), dtype=torch.float32, device=ground.device)
+            self._dp2 = torch.empty((2 * n, 1), dtype=torch.float32, device=ground.device)
+        self._x2[:n].copy_(ground)
+        self._x2[n:].copy_(inp)
+        p, t = self._fwd(self.D, self._x2, bn_groups=2)
+        o.adv(p[:n], MEAN, 0.0, self._loss("d_loss_real"), self._dp2[:n], +1.0)     # backward(one)  :137-138
+        o.adv(p[n:], MEAN, 0.0, self._loss("d_loss_fake"), self._dp2[n:], -1.0)     # backward(mone) :140-141
+        self._bwd(self.D, t, self._dp2, False, True)
 
     def _g_losses(self, inp, ground):
         """Every non-adversarial generator loss: records the scalars, returns d(sum)/d(inpainted)."""

@@ -86,7 +86,11 @@ int gi_net_bind(gi_net* net, float* params, float* grads, float* buffers, void* 
 /* re-derive the packed (fp16 / transposed) weight copies after params were written by the caller */
 int gi_net_sync_weights(gi_net* net);
 int gi_net_set_train(gi_net* net, int train);
-int gi_net_set_loss_scale(gi_net* net, float scale);   /* fp16 backward scaling, default 65536 */
+int gi_net_set_loss_scale(gi_net* net, float scale);
+/* discriminator only: the next forward/backward batches hold `groups` (1 or 2) consecutive, equally sized image
+ * groups with INDEPENDENT BatchNorm batch statistics (running statistics updated group by group). groups = 2 runs
+ * the reference's two critic calls D(ground), D(inpainted) (wgan_l1.py:134-135) as one stacked batch. */
+int gi_net_set_bn_groups(gi_net* net, int groups);   /* fp16 backward scaling, default 65536 */
 int gi_net_set_dropout_seed(gi_net* net, uint64_t seed);
 /* keep-mask of dropout level `level` used by the last train-mode forward of `slot`,
  * as uint8 in (N,C,H,W) order (what the oracle consumes); count = N*C*H*W */

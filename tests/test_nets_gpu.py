@@ -209,3 +209,58 @@ def test_frozen_discriminator_gives_dx_only():
     net(x).sum().backward()
     assert float(net.flat_grads().abs().max()) == 0.0
     assert float(x.grad.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dtype,hw,n", [("fp32", 256, 2), ("fp16", 256, 4), ("fp32", 128, 2)])
+def test_patchgan_two_bn_groups_equal_two_calls(dtype, hw, n):
+    """gi_net_set_bn_groups(2): one stacked [a | b] batch with per-half BatchNorm statistics == the reference's two
+    separate critic calls (outputs, accumulated parameter gradients, running statistics after both updates).
+    256x256 takes the aligned path (GEMM-epilogue partial rows split between the groups), 128x128 with n=2 the
+    per-group column pass."""
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd.lib.models import networks
+    from oracle import params as op
+    P = op.make_patchgan_params(77, H=hw, W=hw)
+
+    def mk():
+        D = networks.PatchGANDiscriminator(sigmoid=False, image_size=hw, dtype=dtype)
+        D.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in P.items()})
+        D = D.cuda().train()
+        D.set_loss_scale(1.0 if dtype == "fp32" else 256.0)
+        return D
+    a, _ = op.synth_batch(501, n, hw, hw)
+    b, _ = op.synth_batch(502, n, hw, hw)
+    a, b = torch.from_numpy(a).cuda(), torch.from_numpy(b * 0.5 + 0.2).cuda()
+    da = torch.full((n, 1), 1.0 / n, device="cuda")
+    db = torch.full((n, 1), -1.0 / n, device="cuda")
+    D1 = mk()
+    D1.zero_grad()
+    ya, sa, ga = D1._forward_raw(a)
+    yb, sb, gb = D1._forward_raw(b)
+    D1._backward_raw(sa, ga, da, False, True)
+    D1._backward_raw(sb, gb, db, False, True)
+    D2 = mk()
+    D2.zero_grad()
+    y2, s2, g2 = D2._forward_raw(torch.cat([a, b]), 2)
+    D2._backward_raw(s2, g2, torch.cat([da, db]), False, True)
+    torch.cuda.synchronize()
+    tol = 1e-5 if dtype == "fp32" else 2e-3
+    assert (y2[:n] - ya).abs().max().item() <= tol * ya.abs().max().item() + 1e-7
+    assert (y2[n:] - yb).abs().max().item() <= tol * yb.abs().max().item() + 1e-7
+    # Gradients: the 2n-batch convolutions run with other tile / split-K shapes than the n-batch ones, so raw
+    # activations differ in the last fp32 bits; in a near-constant channel BatchNorm divides that noise by a tiny
+    # sigma and LeakyReLU slopes flip for whole channels (observed: 2 of 512 channels of the last norm layer,
+    # 0.5-2.5 % each, tools/dbg_groups2.py), which then spreads into every earlier layer at the 2e-3 level.
+    # So: overall agreement to 1e-2, and the per-channel BatchNorm gradients of the last norm layer agree tightly in >= 98 % (fp32) / 90 % (fp16) of channels.
+    g1, g2f = D1.flat_grads().double(), D2.flat_grads().double()
+    rel = float((g1 - g2f).norm() / g1.norm())
+    print(f"{dtype} {hw} n={n}: grad rel L2 {rel:.2e}")
+    assert rel <= 1e-2
+    p1, p2 = dict(D1.named_parameters()), dict(D2.named_parameters())
+    for name in ("model.9.bias", "model.9.weight"):   # the last norm layer: upstream of it the flipped channels have spread
+        a1, a2 = p1[name].grad.double(), p2[name].grad.double()
+        ok = ((a1 - a2).abs() <= (1e-5 if dtype == "fp32" else 5e-3) * a1.abs().max()).double().mean().item()
+        assert ok >= (0.98 if dtype == "fp32" else 0.9), (name, ok)   # fp16 activations: more channels sit at the flip threshold
+    for (k1, v1), (k2, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
+        if "running" in k1 or "num_batches" in k1:
+            assert torch.allclose(v1.float(), v2.float(), rtol=1e-5 if dtype == "fp32" else 1e-3, atol=1e-6), k1

@@ -93,15 +93,16 @@ def test_minimax_steps_vs_reference(dtype):
     assert np.array_equal(final[mc == 0], g[mc == 0])
 
 
-@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("overlap,stacked", [(False, False), (False, True), (True, False), (True, True)])
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_wgan_steps_vs_reference(dtype, overlap):
+def test_wgan_steps_vs_reference(dtype, overlap, stacked):
     fx = load("wgan_steps")
     seed, N = int(fx["seed"]), int(fx["N"])
     G, (D,) = build(seed, [seed + 1], False, dtype)
     oG = optim.RMSprop(G.parameters(), lr=0.00005)
     oD = optim.RMSprop(D.parameters(), lr=0.00005)
-    step = trainer.WGANStep(G, D, oG, oD, recon="l1", clip=0.01, overlap=overlap)   # overlap: critic on a side stream
+    # overlap: critic on a side stream; stacked: D(ground) | D(inpainted) as one batch with per-half BatchNorm
+    step = trainer.WGANStep(G, D, oG, oD, recon="l1", clip=0.01, overlap=overlap, stacked=stacked)
     for it, upd in enumerate(int(v) for v in fx["pattern"]):
         g, m = op.synth_batch(seed * 100 + it, N, 128, 128)
         G.impose_dropout_masks(unpack_masks(fx, f"it{it}_"))
