@@ -539,8 +539,11 @@ __global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n,
 }
 
 // ---- optimizers --------------------------------------------------------------------------------
+// guard (may be null): guard[1] != 0 means "the gradients of this update hold inf/NaN" (gi_check_finite): skip it whole
 __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t count, float lr,
-                                                   float b1, float b2, float eps, float bc1, float sqrt_bc2, float gs) {
+                                                   float b1, float b2, float eps, float bc1, float sqrt_bc2, float gs,
+                                                   const int* guard) {
+  if (guard && guard[1]) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const float gg = g[i] * gs;
     const float mm = b1 * m[i] + (1.f - b1) * gg;
@@ -552,7 +555,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, flo
   }
 }
 __global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, float* sq, int64_t count, float lr,
-                                                      float alpha, float eps, float clampv, float gs) {
+                                                      float alpha, float eps, float clampv, float gs, const int* guard) {
+  if (guard && guard[1]) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const float gg = g[i] * gs;
     const float s = alpha * sq[i] + (1.f - alpha) * gg * gg;
@@ -560,6 +564,24 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, 
     float w = p[i] - lr * (gg / (sqrtf(s) + eps));
     if (clampv > 0.f) w = fminf(fmaxf(w, -clampv), clampv);
     p[i] = w;
+  }
+}
+// flag[2] |= 1 when any element of g is inf or NaN
+__global__ void __launch_bounds__(256) check_finite_kernel(const float* __restrict__ g, int64_t count, int* flag) {
+  int bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const unsigned u = __float_as_uint(g[i]);
+    bad |= ((u & 0x7F800000u) == 0x7F800000u) ? 1 : 0;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag + 2, 1);
+}
+// flag[1] = this update's verdict, flag[0] += it (running count of skipped updates), flag[2] = 0
+__global__ void check_finite_finish_kernel(int* flag) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int b = flag[2];
+    flag[1] = b;
+    flag[0] += b;
+    flag[2] = 0;
   }
 }
 __global__ void __launch_bounds__(256) clamp_kernel(float* p, int64_t count, float lo, float hi) {
@@ -876,16 +898,33 @@ int gi_loss_adv(gi_ctx* ctx, const float* pred, int n, int kind, float target, f
 
 int gi_adam_step(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                  float eps, int step, float grad_scale) {
+  return gi_adam_step_guarded(ctx, p, g, m, v, count, lr, beta1, beta2, eps, step, grad_scale, nullptr);
+}
+int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                         float eps, int step, float grad_scale, const int* guard) {
   GI_REQUIRE(step >= 1, "adam: step=%d must be >= 1", step);
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, m, v, count, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2), grad_scale);
+                     (float)bc1, (float)sqrt(bc2), grad_scale, guard);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
 int gi_rmsprop_step(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps, float clamp,
                     float grad_scale) {
-  hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, sq, count, lr, alpha, eps, clamp, grad_scale);
+  return gi_rmsprop_step_guarded(ctx, p, g, sq, count, lr, alpha, eps, clamp, grad_scale, nullptr);
+}
+int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps,
+                            float clamp, float grad_scale, const int* guard) {
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, sq, count, lr, alpha, eps, clamp, grad_scale,
+                     guard);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
+  GI_REQUIRE(ctx && g && flag3 && count > 0, "check_finite: bad argument");
+  hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks(count, 8)), dim3(256), 0, ctx->stream, g, count, flag3);
+  GI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(check_finite_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, flag3);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

@@ -70,7 +70,7 @@ def to_device_images(t, device, state):
     return t.float().contiguous()
 
 
-def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn, d_names, pass_extra=False):
+def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn, d_names, pass_extra=False, step=None):
     """batch_fn(batch_index, ground, mask[, extra]) -> (loss dict of device scalars, g_updated: bool); extra = the
     loader's third item (the segmentation labels of dataset.py:35-51) when pass_extra is set."""
     num_epochs, save_every, evaluate_every = state["numepoch"], state["saveevery"], state["evalevery"]
@@ -99,6 +99,8 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
                 g_updates += 1
                 acc_g += flow_G.measure()
             if bi % log_every == 0:
+                if step is not None:
+                    step.poll_overflow(logger)                 # fp16 guard: back the loss scale off after skipped updates
                 logger.info("[epoch %d/%d][batch %d/%d] %s", epoch, num_epochs, bi, len(loaders["train"]),
                             " ".join(f"{k}: {float(v):.4f}" for k, v in L.items()))
         rec = {k: float(v) / max(batches, 1) for k, v in sums.items()}

@@ -24,4 +24,4 @@ def begin(state, loaders):
             L["ssim"] = pytorch_ssim.ssim(ground, step.gen)                      # :209
         return L, True
 
-    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_Dg, net_Dl], batch, ["avg_d_global", "avg_d_local"])
+    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_Dg, net_Dl], batch, ["avg_d_global", "avg_d_local"], step=step)

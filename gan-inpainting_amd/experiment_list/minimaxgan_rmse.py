@@ -13,4 +13,4 @@ def begin(state, loaders):
     def batch(bi, ground, mask):
         return step(ground, mask), True
 
-    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"])
+    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"], step=step)

@@ -21,4 +21,4 @@ def begin(state, loaders):
             counters["G_iter_count"] += 1
         return L, upd
 
-    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"])
+    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"], step=step)

@@ -42,4 +42,4 @@ def begin(state, loaders):
             counters["G_iter_count"] += 1
         return L, upd
 
-    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"], pass_extra=True)
+    return C.run_epochs(state, loaders, exp_dir, logger, device, net_G, [net_D], batch, ["avg_d"], pass_extra=True, step=step)

@@ -29,6 +29,29 @@ class _FlatOptimizer:
         self.nets = owners
         self.param_groups = [dict(params=params)]
         self.grad_scale = 1.0   # multiplies every gradient (e.g. 1/world_size after a SUM all-reduce)
+        # fp16 overflow guard: scan the gradients before every update and skip the whole update when they hold
+        # inf/NaN (like torch.cuda.amp.GradScaler.step). On by default for networks computing in fp16.
+        self.guard = any(getattr(n, "_dtype", None) == B.GI_F16 for n in owners)
+        self._flags = None
+        self._seen = 0
+
+    def _guard_ptr(self, i, net):
+        """Run the finite check on network i's gradients; returns the device flag pointer (None when the guard is off)."""
+        if not self.guard:
+            return None
+        if self._flags is None:
+            self._flags = [torch.zeros(3, dtype=torch.int32, device=n.flat_params().device) for n in self.nets]
+        g = net.flat_grads()
+        B.check(B.lib().gi_check_finite(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags[i])))
+        return B.ptr(self._flags[i])
+
+    def poll_skipped(self):
+        """Number of updates skipped since the last poll (one device read-back: call it at logging cadence)."""
+        if not self.guard or self._flags is None:
+            return 0
+        total = int(sum(int(f[0].item()) for f in self._flags))
+        new, self._seen = total - self._seen, total
+        return new
 
     def zero_grad(self, set_to_none=False):
         for n in self.nets:
@@ -50,11 +73,17 @@ class Adam(_FlatOptimizer):
     def step(self):
         self.t += 1
         lib = B.lib()
-        for n, st in zip(self.nets, self.state):
+        for i, (n, st) in enumerate(zip(self.nets, self.state)):
             p, g = n.flat_params(), n.flat_grads()
-            B.check(lib.gi_adam_step(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
-                                     self.lr, self.betas[0], self.betas[1], self.eps, self.t, self.grad_scale))
+            B.check(lib.gi_adam_step_guarded(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
+                                             self.lr, self.betas[0], self.betas[1], self.eps, self.t, self.grad_scale,
+                                             self._guard_ptr(i, n)))
         self._done()
+
+    def poll_skipped(self):
+        new = super().poll_skipped()
+        self.t -= new     # skipped updates do not advance the bias correction (applied when the host learns of them)
+        return new
 
 
 class RMSprop(_FlatOptimizer):
@@ -69,10 +98,10 @@ class RMSprop(_FlatOptimizer):
     @torch.no_grad()
     def step(self):
         lib = B.lib()
-        for n, st in zip(self.nets, self.state):
+        for i, (n, st) in enumerate(zip(self.nets, self.state)):
             p, g = n.flat_params(), n.flat_grads()
-            B.check(lib.gi_rmsprop_step(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["sq"]), p.numel(), self.lr,
-                                        self.alpha, self.eps, self.clamp, self.grad_scale))
+            B.check(lib.gi_rmsprop_step_guarded(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["sq"]), p.numel(), self.lr,
+                                                self.alpha, self.eps, self.clamp, self.grad_scale, self._guard_ptr(i, n)))
         self._done()
 
 

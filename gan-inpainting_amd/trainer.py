@@ -93,6 +93,7 @@ class _StepBase:
             n.always_sync = False
 
     def _bind_optimizers(self, *opts):
+        self._opts = opts
         if self.sync is not None:
             for o in opts:
                 o.grad_scale = self.sync.grad_scale()   # SUM all-reduce -> mean gradient
@@ -122,6 +123,21 @@ class _StepBase:
         for d in self.Ds:
             if d._dtype == B.GI_F16:
                 d.set_loss_scale(min(65536.0, 64.0 * n))
+
+    def poll_overflow(self, logger=None):
+        """fp16 only, call at logging cadence: when an optimizer skipped updates because its gradients held
+        inf/NaN, halve the loss scale of its networks (they re-derive it from the batch geometry otherwise)."""
+        out = 0
+        for opt in getattr(self, "_opts", ()):
+            new = opt.poll_skipped()
+            if new:
+                out += new
+                for net in opt.nets:
+                    if net._dtype == B.GI_F16:
+                        net.set_loss_scale(max(1.0, net._loss_scale / 2.0))
+                        if logger:
+                            logger.info("fp16 overflow: %d update(s) of %s skipped, loss scale -> %g", new, type(net).__name__, net._loss_scale)
+        return out
 
     def _loss(self, name):
         if name not in self.L:

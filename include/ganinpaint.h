@@ -159,6 +159,14 @@ int gi_adam_step(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int6
 int gi_rmsprop_step(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr,
                     float alpha, float eps, float clamp, float grad_scale);
 int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi);
+/* fp16 overflow guard (backend addition; the reference trains in fp32): gi_check_finite scans a flat gradient
+ * buffer; flag3 is 3 device ints {running count of bad updates, verdict of this scan (0/1), scratch}. The
+ * *_guarded optimizer steps do nothing when guard[1] != 0 (pass the same flag3, or NULL for the plain step). */
+int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
+int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
+                         float beta1, float beta2, float eps, int step, float grad_scale, const int* guard);
+int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr,
+                            float alpha, float eps, float clamp, float grad_scale, const int* guard);
 /* mean(|g|) of `nseg` segments [off[i], off[i]+len[i]) of g -> out[i]
  * (gradient-flow statistics, minimaxgan_l1.py:180-182); offsets/lengths are device int64 */
 int gi_grad_absmean(gi_ctx* ctx, const float* g, const int64_t* seg_off, const int64_t* seg_len,

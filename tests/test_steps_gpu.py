@@ -222,3 +222,28 @@ def test_autograd_surface_matches_fast_path():
     #  moves the rounding-level elements by +-lr)
     assert relerr(abs_sums(D2), abs_sums(D1)) <= 1e-4
     assert relerr(abs_sums(G2), abs_sums(G1)) <= 1e-4
+
+
+def test_fp16_overflow_guard_skips_the_update_and_backs_off():
+    """inf in the critic's gradients: the guarded RMSprop leaves parameters and state untouched, the skipped update is
+    counted on the device, poll_overflow halves the critic's loss scale; the next clean update goes through."""
+    G, (D,) = build(41, [42], False, "fp16")
+    oG = optim.RMSprop(G.parameters(), lr=0.00005)
+    oD = optim.RMSprop(D.parameters(), lr=0.00005)
+    assert oD.guard and oG.guard
+    step = trainer.WGANStep(G, D, oG, oD, recon="l1", clip=0.01)
+    g, m = op.synth_batch(4100, 2, 128, 128)
+    g, m = torch.from_numpy(g).cuda(), torch.from_numpy(m).cuda()
+    step(g, m, False)
+    assert step.poll_overflow() == 0
+    before, sq_before = D.flat_params().clone(), oD.state[0]["sq"].clone()
+    scale_before = D._loss_scale
+    D.flat_grads()[12345] = float("inf")
+    oD.step()                                            # poisoned gradients: must be a no-op
+    torch.cuda.synchronize()
+    assert torch.equal(D.flat_params(), before) and torch.equal(oD.state[0]["sq"], sq_before)
+    assert step.poll_overflow() == 1 and D._loss_scale == scale_before / 2 and G._loss_scale > 0
+    step(g, m, False)                                    # clean batch: the critic moves again
+    torch.cuda.synchronize()
+    assert not torch.equal(D.flat_params(), before) and step.poll_overflow() == 0
+    assert torch.isfinite(D.flat_params()).all()
