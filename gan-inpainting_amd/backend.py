@@ -43,6 +43,7 @@ PROTOTYPES = {
     "gi_net_backward": (_i, [_vp, _i, _vp, _vp, _i]),
     "gi_net_backward_phase": (_i, [_vp, _i, _vp, _vp, _i, _i]),
     "gi_net_phase_split": (_i64, [_vp]),
+    "gi_net_phase_split2": (_i64, [_vp]),
     "gi_patchgan_gradient_penalty": (_i, [_vp, _vp, _i, _f, _vp]),
     "gi_interpolate": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "gi_mask_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i]),

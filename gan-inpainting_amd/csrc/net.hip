@@ -714,7 +714,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   void* D = net->shared(net->oD);
   float* G0 = (float*)net->shared(net->oG0);
   const int64_t npx = (int64_t)n * H * W;
-  if (phase != 2) {
+  if (phase == 0 || phase == 1) {
   // tanh' and loss scaling
   GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx * net->out_c, LS));
   // u1: ConvTranspose2d(2ngf -> 1) + bias
@@ -752,8 +752,11 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   }
   }  // decoder half
   if (phase == 1) return GI_OK;
+  // the encoder half may be split once more: phase 3 = innermost .. level 5 (their parameter gradients, the bulk
+  // of the encoder's, are complete first), phase 4 = levels 4 .. 1; phase 2 (or 0) runs both
+  const bool run_inner = phase != 4, run_outer = phase != 3;
   // innermost conv (no norm): dz = gE * [E > 0]
-  {
+  if (run_inner) {
     const int c = net->ch[nd];
     const int64_t pix = (int64_t)n * net->Hk[nd] * net->Wk[nd];
     GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, net->shared(net->ogE), c, 0, net->slot(s, net->oE), c, 0, nullptr, D, pix, c, GI_ACT_NONE,
@@ -766,6 +769,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   }
   // encoder, innermost -> outermost
   for (int k = nd - 1; k >= 2; --k) {
+    if (k >= 5 ? !run_inner : !run_outer) continue;
     const int c = net->ch[k];
     const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
     GI_TRY(act_bn_bwd(net, s, gA(k), c, 0, gC(k), 2 * c, 0, C(k), 2 * c, 0, net->slot(s, net->oR[k]), D, pix, c, GI_ACT_LRELU, 1.f,
@@ -776,7 +780,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[k]), gA(k - 1), cb, cb, 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE,
                  false, nullptr));
   }
-  {
+  if (run_outer) {
     const int c = net->ch[1];
     const int64_t pix = (int64_t)n * net->Hk[1] * net->Wk[1];
     GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
@@ -817,7 +821,9 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   return GI_OK;
 }
 
-int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad) {
+// phase: 0 = whole backward; 1 = head + conv4 block (their gradients, 8.5 of the critic's 11 MB, are the tail of the
+// flat buffer and complete when this returns); 2 = conv3 .. conv1
+int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad, int phase = 0) {
   hipStream_t st = net->ctx->stream;
   const int dt = net->dtype, H = net->H, W = net->W, n = net->slot_n[s];
   GI_REQUIRE(n > 0 && net->slot_train[s], "patchgan_backward: slot %d holds no train-mode forward", s);
@@ -835,8 +841,9 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   hb.dbl = need_wgrad ? net->grads + net->bl_off : nullptr;
   hb.dh = (float*)net->shared(net->oDh);
   hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = net->sigmoid; hb.loss_scale = LS;
-  GI_TRY(op_head_backward(st, dt, hb));
+  if (phase != 2) GI_TRY(op_head_backward(st, dt, hb));
   for (int i = 4; i >= 2; --i) {
+    if (i == 4 ? phase == 2 : phase == 1) continue;
     const Conv& c = net->dconv[i];
     const int Hs = H >> i, Ws = W >> i;
     const int64_t pix = (int64_t)n * Hs * Ws;
@@ -847,6 +854,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
     GI_TRY(igemm(net, 1, D, c.ca, c.ca, 0, phase_ptr(net, c), net->shared(net->ogA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, 0, GI_ACT_NONE, false,
                  nullptr));
   }
+  if (phase == 1) return GI_OK;
   const int64_t pix = (int64_t)n * (H / 2) * (W / 2);
   GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[1]), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D, pix, 64, GI_ACT_LRELU,
                     1.f, nullptr, need_wgrad));
@@ -981,17 +989,24 @@ extern "C" int gi_net_backward_phase(gi_net* net, int slot, const float* dy, flo
   GI_REQUIRE(net && net->bound, "net_backward_phase: net not bound");
   GI_REQUIRE(dy, "net_backward_phase: dy is null");
   GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_backward_phase: slot=%d", slot);
-  GI_REQUIRE(phase >= 0 && phase <= 2, "net_backward_phase: phase=%d", phase);
+  GI_REQUIRE(phase >= 0 && phase <= 4, "net_backward_phase: phase=%d", phase);
   if (net->kind != 0) {
-    if (phase == 2) return GI_OK;   // discriminator: everything happens in phase 0/1
-    return patchgan_backward(net, slot, dy, dx, need_wgrad);
+    if (phase >= 3) return GI_OK;   // discriminator: two phases
+    return patchgan_backward(net, slot, dy, dx, need_wgrad, phase);
   }
   return unet_backward(net, slot, dy, dx, need_wgrad, phase);
 }
 
-// first float of the gradient region completed by phase 1 (generator: the innermost up-conv weight)
+// first float of the gradient region completed by phase 1 (generator: the innermost up-conv weight; discriminator:
+// the conv4 weight)
 extern "C" int64_t gi_net_phase_split(gi_net* net) {
   if (!net) return GI_ERR_INVALID;
-  if (net->kind != 0) return 0;
+  if (net->kind != 0) return net->dconv[4].w_off;
   return net->up[net->nd].w_off;
+}
+// generator: first float of the region completed by phase 3 (the level-5 down-conv weight); phases 3 + 4 == phase 2
+extern "C" int64_t gi_net_phase_split2(gi_net* net) {
+  if (!net) return GI_ERR_INVALID;
+  if (net->kind != 0) return 0;
+  return net->conv[net->nd < 5 ? net->nd : 5].w_off;
 }

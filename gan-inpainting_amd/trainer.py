@@ -149,18 +149,39 @@ class _StepBase:
             self.sync.all_reduce(net)
 
     def _bwd_G(self, gtok, dy):
-        """Generator backward; with a GradSync the decoder half's gradients start their all-reduce
-        while the encoder half is still being computed."""
+        """Generator backward; with a GradSync the gradients start their all-reduce in completion order while the
+        rest of the backward is still being computed: decoder, then the inner encoder levels (d7 .. d5, 82 % of the
+        encoder's gradients), then the outer ones."""
         if self.sync is None or self.sync.world == 1:
             return self._bwd(self.G, gtok, dy, False, True)
         G, lib = self.G, B.lib()
         if G._slot_gen[gtok[0]] != gtok[1]:
             raise B.BackendError("generator activations were overwritten before their backward")
         flat = G.flat_grads()
-        split = lib.gi_net_phase_split(G._handle)
+        split, split2 = lib.gi_net_phase_split(G._handle), lib.gi_net_phase_split2(G._handle)
         B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 1))
         self.sync.launch(flat, split, flat.numel())
-        B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 2))
+        B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 3))
+        self.sync.launch(flat, split2, split)
+        B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 4))
+        self.sync.launch(flat, 0, split2)
+        self.sync.wait(flat.device)
+
+    def _bwd_D_synced(self, net, tok, dy):
+        """Critic backward + gradient all-reduce: the conv4 block and the head (8.5 of 11 MB) are reduced while
+        conv3 .. conv1 are still in their backward. Returns with the reduced gradients visible to the current stream."""
+        lib = B.lib()
+        if net._slot_gen[tok[0]] != tok[1]:
+            raise B.BackendError("critic activations were overwritten before their backward")
+        dy = dy.contiguous()
+        if net._slot_groups[tok[0]] != net._groups_set:
+            B.check(lib.gi_net_set_bn_groups(net._handle, net._slot_groups[tok[0]]))
+            net._groups_set = net._slot_groups[tok[0]]
+        flat = net.flat_grads()
+        split = lib.gi_net_phase_split(net._handle)
+        B.check(lib.gi_net_backward_phase(net._handle, tok[0], B.ptr(dy), None, 1, 1))
+        self.sync.launch(flat, split, flat.numel())
+        B.check(lib.gi_net_backward_phase(net._handle, tok[0], B.ptr(dy), None, 1, 2))
         self.sync.launch(flat, 0, split)
         self.sync.wait(flat.device)
 
@@ -249,6 +270,7 @@ class WGANStep(_StepBase):
     @torch.no_grad()
     def _call_overlapped(self, ground, mask, update_g):
         o = self.ops
+        self._d_synced = False
         self._buffers(ground)
         main = torch.cuda.current_stream(ground.device)
         sD = self._sD
@@ -283,7 +305,8 @@ class WGANStep(_StepBase):
                 self._bwd(self.D, tf, self.dpred, False, True)
             if self.gp_lambda > 0:
                 self.L["gp"] = self.D.gradient_penalty(ground, inp, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
-            self._reduce(self.D)
+            if not self._d_synced:
+                self._reduce(self.D)
             self.optD.step()
             if self.clip > 0 and not self._fused_clip:
                 util.clamp_parameters(self.D, -self.clip, self.clip)
@@ -307,6 +330,7 @@ class WGANStep(_StepBase):
         if self.overlap:
             return self._call_overlapped(ground, mask, update_g)
         o = self.ops
+        self._d_synced = False
         self._buffers(ground)
         o.mask_apply(ground, mask, self.mask_c, self.masked, True)
         gen, gtok = self._fwd(self.G, self.masked)                              # every batch, :119
@@ -323,7 +347,8 @@ class WGANStep(_StepBase):
             self._bwd(self.D, tf, self.dpred, False, True)
         if self.gp_lambda > 0:
             self.L["gp"] = self.D.gradient_penalty(ground, self.inpainted, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
-        self._reduce(self.D)
+        if not self._d_synced:
+            self._reduce(self.D)
         self.optD.step()                                                        # :147
         if self.clip > 0 and not self._fused_clip:
             util.clamp_parameters(self.D, -self.clip, self.clip)                # :151-153
@@ -349,7 +374,11 @@ class WGANStep(_StepBase):
         p, t = self._fwd(self.D, self._x2, bn_groups=2)
         o.adv(p[:n], MEAN, 0.0, self._loss("d_loss_real"), self._dp2[:n], +1.0)     # backward(one)  :137-138
         o.adv(p[n:], MEAN, 0.0, self._loss("d_loss_fake"), self._dp2[n:], -1.0)     # backward(mone) :140-141
-        self._bwd(self.D, t, self._dp2, False, True)
+        if self.sync is not None and self.sync.world > 1 and self.gp_lambda <= 0:
+            self._bwd_D_synced(self.D, t, self._dp2)       # all-reduce overlapped with the tail of the backward
+            self._d_synced = True
+        else:
+            self._bwd(self.D, t, self._dp2, False, True)
 
     def _g_losses(self, inp, ground):
         """Every non-adversarial generator loss: records the scalars, returns d(sum)/d(inpainted)."""

@@ -105,12 +105,14 @@ int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n);
  * gradients are produced. Parameter gradients ACCUMULATE into the bound grads. */
 int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad);
 
-/* generator backward in two halves so the host can overlap a gradient all-reduce with compute:
- * phase 1 = decoder (its parameter gradients are the flat range [gi_net_phase_split(), end) and are
- * complete on return), phase 2 = encoder (range [0, split)); phase 0 = both. Discriminators run
- * entirely in phase 1 (split = 0). */
+/* backward in pieces so the host can overlap a gradient all-reduce with compute (phase 0 = everything).
+ * Generator: phase 1 = decoder (its parameter gradients are the flat range [gi_net_phase_split(), end), complete
+ * on return); phase 2 = encoder (range [0, split)), or split once more: phase 3 = innermost .. level 5 (range
+ * [gi_net_phase_split2(), split): 12.6 of the encoder's 15.3 M gradients, finished first), phase 4 = levels 4 .. 1.
+ * Discriminator: phase 1 = head + conv4 block (range [gi_net_phase_split(), end)), phase 2 = conv3 .. conv1. */
 int gi_net_backward_phase(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad, int phase);
 int64_t gi_net_phase_split(gi_net* net);
+int64_t gi_net_phase_split2(gi_net* net);
 
 /* WGAN-GP EXTENSION (not in the reference, which clips weights: wgan_l1.py:151-153): accumulates the
  * parameter gradient of  lam * mean_n (||grad_x D(xhat)_n||_2 - 1)^2  into the bound grads and writes the

@@ -264,3 +264,45 @@ def test_patchgan_two_bn_groups_equal_two_calls(dtype, hw, n):
     for (k1, v1), (k2, v2) in zip(D1.state_dict().items(), D2.state_dict().items()):
         if "running" in k1 or "num_batches" in k1:
             assert torch.allclose(v1.float(), v2.float(), rtol=1e-5 if dtype == "fp32" else 1e-3, atol=1e-6), k1
+
+
+@pytest.mark.parametrize("kind", ["unet7", "unet6", "patchgan"])
+def test_backward_in_phases_equals_whole_backward(kind):
+    """gi_net_backward_phase: generator phases 1 + 3 + 4 (and 1 + 2), critic phases 1 + 2 accumulate the same
+    parameter gradients as the single call, and the flat ranges announced by gi_net_phase_split / _split2 are
+    complete (non-zero exactly there) after their phase."""
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import backend as B
+    from gan_inpainting_amd.lib.models import networks
+    torch.manual_seed(11)
+    if kind == "patchgan":
+        net, hw = networks.PatchGANDiscriminator(sigmoid=False, image_size=128, dtype="fp32").cuda().train(), 128
+        dy = torch.randn((2, 1), device="cuda")
+        phase_sets = [(1, 2)]
+    else:
+        nd = 7 if kind == "unet7" else 6
+        hw = 128 if nd == 7 else 64
+        net = networks.UnetGenerator(1, 1, nd, ngf=64, use_dropout=False, dtype="fp32").cuda().train()
+        dy = torch.randn((2, 1, hw, hw), device="cuda") * 1e-2
+        phase_sets = [(1, 2), (1, 3, 4)]
+    x = torch.rand((2, 1, hw, hw), device="cuda")
+    lib = B.lib()
+    net.zero_grad()
+    _, s, g = net._forward_raw(x)
+    net._backward_raw(s, g, dy, False, True)
+    whole = net.flat_grads().clone()
+    split, split2 = lib.gi_net_phase_split(net._handle), lib.gi_net_phase_split2(net._handle)
+    assert 0 < split < whole.numel() and (kind == "patchgan" or 0 < split2 < split)
+    for phases in phase_sets:
+        net.zero_grad()
+        _, s, g = net._forward_raw(x)
+        for i, ph in enumerate(phases):
+            B.check(lib.gi_net_backward_phase(net._handle, s, B.ptr(dy), None, 1, ph))
+            torch.cuda.synchronize()
+            fg = net.flat_grads()
+            if i == 0:      # after phase 1 only the tail [split, end) holds gradients
+                assert float(fg[:split].abs().max()) == 0.0 and float(fg[split:].abs().max()) > 0.0
+            if ph == 3:     # after phase 3 the outer encoder range [0, split2) is still untouched
+                assert float(fg[:split2].abs().max()) == 0.0 and float(fg[split2:split].abs().max()) > 0.0
+        rel = float((net.flat_grads().double() - whole.double()).norm() / whole.double().norm())
+        assert rel <= 1e-5, (phases, rel)
