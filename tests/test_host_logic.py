@@ -56,3 +56,20 @@ def test_default_init_equals_reference_under_same_seed():
             assert abs(float(sd[k].double().abs().sum()) - fx[f"{tag}_abs"][i]) <= 1e-9 * (1 + fx[f"{tag}_abs"][i]), k
             head = sd[k].reshape(-1)[:4].numpy()
             assert np.array_equal(head, fx[f"{tag}_head"][i][:head.size]), k
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: no module of the shipped package may import it (bench.py's cpu_baseline
+    leg, __graft_entry__.smoke and tests/ are the only allowed users)."""
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gan-inpainting_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|^\s*from\s+\.+\s*import\s+oracle\b|importlib\.import_module\(\s*['\"]oracle")
+    bad = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith(".py"):
+                for i, line in enumerate(open(os.path.join(d, f), encoding="utf-8"), 1):
+                    if pat.search(line):
+                        bad.append(f"{os.path.join(d, f)}:{i}: {line.strip()}")
+    assert not bad, bad
