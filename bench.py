@@ -160,13 +160,51 @@ def vgg_workload(args, dev):
             "losses": {"perceptual": float(r[0]), "style": float(r[1])}}
 
 
+def dual_d_workload(args, dev):
+    """Secondary line: BASELINE configs[2], experiment1_global_local_D 256x256 bs=32 fp16 (generator + global and
+    local LSGAN discriminators, Adam, lambda = 300 on global / masked RMSE, SSIM metric per batch as in the plugin)."""
+    from gan_inpainting_amd import optim, trainer
+    from gan_inpainting_amd.lib import pytorch_ssim
+    from gan_inpainting_amd.lib.models import networks
+    torch.manual_seed(1234)
+    G = networks.get_network("generator", "unet", dtype=args.dtype).to(dev)
+    Dg = networks.PatchGANDiscriminator(sigmoid=True, image_size=H, dtype=args.dtype).to(dev)
+    Dl = networks.PatchGANDiscriminator(sigmoid=True, image_size=H, dtype=args.dtype).to(dev)
+    oG = optim.Adam(G.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    oD = optim.Adam(optim.chain(Dl.parameters(), Dg.parameters()), lr=0.0002, betas=(0.5, 0.999))
+    step = trainer.DualDStep(G, Dg, Dl, oG, oD)
+    batches = [synth(BS, 0x5EED0000 + i, dev) for i in range(4)]
+
+    def one(i):
+        g, m = batches[i % 4]
+        L = step(g, m)
+        L["ssim"] = pytorch_ssim.ssim(g, step.gen)
+        return L
+
+    for i in range(args.warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        L = one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"metric": "training images/sec at 256x256 bs=32/GPU (experiment1_global_local_D)", "value": BS * args.steps / dt,
+            "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32",
+            "data": "synthetic",
+            "config": {"workload": "experiment1_global_local_D 256x256 bs=32 fp16 (BASELINE.json configs[2]): G update + two LSGAN "
+                                   "discriminators every batch, SSIM metric per batch"},
+            "losses": {k: float(v.item()) for k, v in L.items()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512", "config5_512"],
+    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512", "config5_512", "dual_d_256"],
                     help="ssim_256 = the per-batch SSIM metric of experiment1_global_local_D.py:209 at 256x256 bs=32 (SURVEY 8f rank 2); wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
@@ -201,6 +239,9 @@ def main():
         return
     if args.workload == "vgg_512":
         print(json.dumps(vgg_workload(args, dev)))
+        return
+    if args.workload == "dual_d_256":
+        print(json.dumps(dual_d_workload(args, dev)))
         return
 
     if args.kernel_only:

@@ -167,6 +167,27 @@ class _StepBase:
         self.sync.launch(flat, 0, split2)
         self.sync.wait(flat.device)
 
+    def _d_pair(self, net, real, fake, kind, t_real, t_fake, name_real, name_fake, gs_real=1.0, gs_fake=1.0, synced=False):
+        """A discriminator's two calls of a batch, D(real) and D(fake), as ONE [real | fake] batch whose BatchNorm
+        layers are evaluated per half (gi_net_set_bn_groups): per image the reference's arithmetic, half the
+        launches, one weight-gradient GEMM over both halves. Losses go to L[name_*], gradients accumulate."""
+        o, n = self.ops, real.shape[0]
+        bufs = self.__dict__.setdefault("_pair_bufs", {})
+        key = (id(net), tuple(real.shape))
+        if key not in bufs:
+            bufs[key] = (torch.empty((2 * n,) + tuple(real.shape[1:]), dtype=torch.float32, device=real.device),
+                         torch.empty((2 * n, 1), dtype=torch.float32, device=real.device))
+        x2, dp2 = bufs[key]
+        x2[:n].copy_(real)
+        x2[n:].copy_(fake)
+        p, t = self._fwd(net, x2, bn_groups=2)
+        o.adv(p[:n], kind, t_real, self._loss(name_real), dp2[:n], gs_real)
+        o.adv(p[n:], kind, t_fake, self._loss(name_fake), dp2[n:], gs_fake)
+        if synced:
+            self._bwd_D_synced(net, t, dp2)
+        else:
+            self._bwd(net, t, dp2, False, True)
+
     def _bwd_D_synced(self, net, tok, dy):
         """Critic backward + gradient all-reduce: the conv4 block and the head (8.5 of 11 MB) are reduced while
         conv3 .. conv1 are still in their backward. Returns with the reduced gradients visible to the current stream."""
@@ -196,9 +217,10 @@ class _StepBase:
 
 
 class MinimaxStep(_StepBase):
-    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", sync=None):
+    def __init__(self, net_G, net_D, opt_G, opt_D, recon="l1", sync=None, stacked=True):
         super().__init__(net_G, [net_D], net_G.device, sync)
         self.D, self.optG, self.optD, self.recon = net_D, opt_G, opt_D, recon
+        self.stacked = stacked      # D(ground) | D(inpainted) as one batch with per-half BatchNorm (see _d_pair)
         self._bind_optimizers(opt_G, opt_D)
 
     @torch.no_grad()
@@ -210,12 +232,15 @@ class MinimaxStep(_StepBase):
         o.composite(self.masked, gen, self.mask_c, self.inpainted)             # :122
         # ---- D step :129-148
         self.optD.zero_grad()
-        p, t = self._fwd(self.D, ground)
-        o.adv(p, BCE, 1.0, self._loss("d_loss_real"), self.dpred)
-        self._bwd(self.D, t, self.dpred, False, True)
-        p, t = self._fwd(self.D, self.inpainted)
-        o.adv(p, BCE, 0.0, self._loss("d_loss_fake"), self.dpred)
-        self._bwd(self.D, t, self.dpred, False, True)
+        if self.stacked:
+            self._d_pair(self.D, ground, self.inpainted, BCE, 1.0, 0.0, "d_loss_real", "d_loss_fake")
+        else:
+            p, t = self._fwd(self.D, ground)
+            o.adv(p, BCE, 1.0, self._loss("d_loss_real"), self.dpred)
+            self._bwd(self.D, t, self.dpred, False, True)
+            p, t = self._fwd(self.D, self.inpainted)
+            o.adv(p, BCE, 0.0, self._loss("d_loss_fake"), self.dpred)
+            self._bwd(self.D, t, self.dpred, False, True)
         self._reduce(self.D)
         self.optD.step()
         # ---- G step :154-173 (D frozen: input gradient only)
@@ -242,7 +267,6 @@ class WGANStep(_StepBase):
         # 2n batch with independent BatchNorm statistics per half (gi_net_set_bn_groups): same arithmetic per
         # image, half the launches, and one weight-gradient GEMM over both halves instead of two accumulating ones.
         self.stacked = stacked
-        self._x2 = None
         # overlap=True: the critic runs on a side HIP stream. Its real-image forward/backward does not depend
         # on the generator forward, and in critic-only batches the next batch's generator forward does not
         # depend on this batch's critic update, so the two networks' small / latency-bound kernels fill each
@@ -364,21 +388,11 @@ class WGANStep(_StepBase):
         return self.L
 
     def _critic_stacked(self, ground, inp):
-        """D(ground) and D(inpainted) of wgan_l1.py:134-141 as one [ground | inpainted] batch, BatchNorm per half."""
-        o, n = self.ops, ground.shape[0]
-        if self._x2 is None or self._x2.shape[0] != 2 * n or self._x2.shape[2:] != ground.shape[2:]:
-            self._x2 = torch.empty((2 * n,) + tuple(ground.shape[1:]), dtype=torch.float32, device=ground.device)
-            self._dp2 = torch.empty((2 * n, 1), dtype=torch.float32, device=ground.device)
-        self._x2[:n].copy_(ground)
-        self._x2[n:].copy_(inp)
-        p, t = self._fwd(self.D, self._x2, bn_groups=2)
-        o.adv(p[:n], MEAN, 0.0, self._loss("d_loss_real"), self._dp2[:n], +1.0)     # backward(one)  :137-138
-        o.adv(p[n:], MEAN, 0.0, self._loss("d_loss_fake"), self._dp2[n:], -1.0)     # backward(mone) :140-141
-        if self.sync is not None and self.sync.world > 1 and self.gp_lambda <= 0:
-            self._bwd_D_synced(self.D, t, self._dp2)       # all-reduce overlapped with the tail of the backward
-            self._d_synced = True
-        else:
-            self._bwd(self.D, t, self._dp2, False, True)
+        """D(ground) and D(inpainted) of wgan_l1.py:134-141 as one [ground | inpainted] batch, BatchNorm per half;
+        backward(one) / backward(mone) are the gradient scales +1 / -1."""
+        synced = self.sync is not None and self.sync.world > 1 and self.gp_lambda <= 0
+        self._d_pair(self.D, ground, inp, MEAN, 0.0, 0.0, "d_loss_real", "d_loss_fake", +1.0, -1.0, synced=synced)
+        self._d_synced = synced   # the all-reduce already overlapped the tail of the backward
 
     def _g_losses(self, inp, ground):
         """Every non-adversarial generator loss: records the scalars, returns d(sum)/d(inpainted)."""
@@ -452,8 +466,9 @@ class DualDStep(_StepBase):
     """G step first, LSGAN losses, global + local (mask * x) discriminators, mask not ceil-ed,
     output not composited, one optimizer over both discriminators (:123)."""
 
-    def __init__(self, net_G, net_Dg, net_Dl, opt_G, opt_D, lam1=300.0, lam2=300.0, sync=None):
+    def __init__(self, net_G, net_Dg, net_Dl, opt_G, opt_D, lam1=300.0, lam2=300.0, sync=None, stacked=True):
         super().__init__(net_G, [net_Dg, net_Dl], net_G.device, sync)
+        self.stacked = stacked      # each discriminator's real | fake calls as one batch with per-half BatchNorm
         self.Dg, self.Dl, self.optG, self.optD, self.lam1, self.lam2 = net_Dg, net_Dl, opt_G, opt_D, lam1, lam2
         self.recon_weight = max(lam1, lam2)
         self._bind_optimizers(opt_G, opt_D)
@@ -487,6 +502,9 @@ class DualDStep(_StepBase):
         # ---- D step :178-200
         self.optD.zero_grad()
         for net, real, fake, tag in ((self.Dg, ground, gen, "global"), (self.Dl, self.tmp2, self.inpainted, "local")):
+            if self.stacked:
+                self._d_pair(net, real, fake, LSGAN, 1.0, 0.0, f"d_real_{tag}", f"d_fake_{tag}")
+                continue
             p, t = self._fwd(net, real)
             o.adv(p, LSGAN, 1.0, self._loss(f"d_real_{tag}"), self.dpred)
             self._bwd(net, t, self.dpred, False, True)
