@@ -61,7 +61,7 @@ def dominant_kernel(iters):
     B.check(B.lib().gi_time_convT_s2(B.get_ctx(), B.GI_F16, B.ptr(x), B.ptr(phase), B.ptr(out), n, hs, ws, ca, ca, cb, cb, iters,
                                      C.byref(ms)))
     flop = 2.0 * 4 * (n * hs * ws) * cb * (4 * ca)
-    return dict(name="igemm3_kernel<PHASE,128,8> fp16 LDS-DMA implicit GEMM (ConvTranspose2d 512->128, 32x32->64x64, bs=32; generator u3)", ms=ms.value, flop=flop)
+    return dict(name="igemm5_kernel<128> fp16 halo-resident LDS-DMA implicit GEMM (ConvTranspose2d 512->128, 32x32->64x64, bs=32; generator u3)", ms=ms.value, flop=flop)
 
 
 def cpu_baseline():

@@ -1,0 +1,331 @@
+// fp16 sub-pixel-phase implicit GEMM with an LDS-RESIDENT INPUT HALO (gfx950): ConvTranspose2d forward / Conv2d
+// input gradient of the 4x4 / stride-2 / pad-1 family, same contract as igemm3_kernel<PHASE>.
+//
+// igemm3 gathers the A operand tap by tap: every input row is fetched once per tap (4x in this mode), and the
+// hardware counters / ablations show the kernel bound by LDS-DMA issue, i.e. by loaded bytes per MAC
+// (48 KiB per 256x128x64 MAC step). Here a workgroup owns a TH x TW patch of the small grid (TH*TW = 256 output
+// pixels of ONE sub-pixel phase). Per 64-channel chunk it loads the (TH+1) x (TW+1) input halo ONCE (<= 40 KiB,
+// double buffered) and runs the four taps from it: the A fragment of tap (ty,tx) for pixel (y,x) is LDS row
+// (y+1-ty)*(TW+1) + (x+1-tx). Only the 16 KiB weight slice of each (chunk, tap) step still streams through a
+// three-stage ring: 25.5 instead of 48 KiB of LDS-DMA per step.
+//   LDS: A halo 2 x 40 KiB | B ring 3 x BN*128 B   (128 KiB for BN = 128); rows of 128 B, 16-byte chunk c of row
+//   r at physical chunk c ^ (r & 7) (applied to the per-lane DMA source address, as in igemm3).
+//   Step s = (chunk c, tap): counted vmcnt + ONE barrier; during its 2x16 MFMAs per wave the pieces of the next
+//   chunk's halo (5 per wave and chunk, split 2,1,1,1 over the four taps) and of B(s+2) are issued.
+#include <stdlib.h>
+
+#include "common.h"
+
+const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
+
+namespace {
+
+struct KP5 {
+  const char* in;
+  const char* w;      // [4 phases][cout][4*cin] (K order: tap, channel)
+  char* out;
+  const char* zero;
+  const float* bias;
+  float* partials;
+  int Hs, Ws, n;
+  int TH, TW;         // patch of the small grid, TH*TW = 256; TW a power of two
+  int tiles_x, tiles_per_img, mtiles;
+  int cin, ldin, coffin;
+  int cout, ldout, coffout;
+  int nchunk;         // cin / 64
+  int relu_in, relu_cend, act_out;
+  int ntiles;
+};
+
+__device__ __forceinline__ float act5(float v, int act) {
+  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ h8_t relu5(h8_t v) {
+  typedef short s8_t __attribute__((ext_vector_type(8)));
+  s8_t h = __builtin_bit_cast(s8_t, v);
+  const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  h = __builtin_elementwise_max(h, z);
+  return __builtin_bit_cast(h8_t, h);
+}
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm(int n) {   // n is wave-uniform
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+  }
+}
+
+template <int BN>
+__global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
+  constexpr int BM = 256, BK = 64, NW = 8;
+  constexpr int A_ROWS = 320, A_BYTES = A_ROWS * 128;   // 40 pieces of 8 rows: 5 per wave
+  constexpr int B_BYTES = BN * 128;
+  constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;
+  constexpr int AJ = 5, BJ = (BN / 8) / NW;             // pieces per wave: halo (per chunk) / weight slice (per step)
+  constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile order (as igemm3): the (N tile, phase) blocks of one patch run back to back on one XCD
+  const int nyz = p.ntiles * 4;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int mt_idx = (local / nyz) * 8 + xcd;
+  if (mt_idx >= p.mtiles) return;
+  const int yz = local % nyz;
+  const int nt_idx = yz % p.ntiles;
+  const int ph = yz / p.ntiles;
+  const int py = ph >> 1, px = ph & 1;
+  const int n0 = nt_idx * BN;
+  const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
+  const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
+  const int HC = p.TW + 1, HR = p.TH + 1;
+  const char* wptr = p.w + (int64_t)ph * p.cout * (4 * p.cin) * 2;
+  const int Ktot2 = 4 * p.cin * 2;   // bytes per weight row
+
+  // ---- per-lane DMA sources: halo rows (fixed for the whole K loop) and weight rows ------------------------
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ (lrow & 7);
+  const char* pa[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int r = (wave * AJ + j) * 8 + lrow;
+    const int hr = r / HC, hc = r - hr * HC;
+    const int iy = y0 + py - 1 + hr, ix = x0 + px - 1 + hc;
+    const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+    pa[j] = ok ? p.in + ((int64_t)((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16 : p.zero + lchunk * 16;
+  }
+  const char* pb[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) pb[j] = wptr + (int64_t)(n0 + (wave * BJ + j) * 8 + lrow) * Ktot2 + lchunk * 16;
+
+  auto issue_a = [&](int chunk, int buf, auto J) {   // halo piece J of `chunk` into A buffer `buf`
+    constexpr int j = decltype(J)::value;
+    glds16(pa[j] + chunk * (BK * 2), smem + A_OFF + buf * A_BYTES + (wave * AJ + j) * 1024);
+  };
+  auto issue_b = [&](int chunk, int tap, int stage, auto J) {
+    constexpr int j = decltype(J)::value;
+    glds16(pb[j] + (tap * p.cin + chunk * BK) * 2, smem + B_OFF + stage * B_BYTES + (wave * BJ + j) * 1024);
+  };
+
+  // ---- fragment read addresses -----------------------------------------------------------------------------
+  const int lr = lane & 15, lq = lane >> 4;
+  const int lgTW = 31 - __builtin_clz(p.TW);
+  int rdA[MT][4];   // byte offset inside an A buffer of (pixel row of tile mt, tap), k-half 0; k-half 1 = ^ 64
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = wm * 64 + mt * 16 + lr;
+    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int R = (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1));
+      rdA[mt][tap] = R * 128 + ((lq ^ (R & 7)) << 4);
+    }
+  }
+  const int rdB = (wn * WN + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+
+  f4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = p.nchunk, nsteps = nchunk * 4;
+  const int relu_cend = p.relu_in ? p.relu_cend : 0;
+
+  // ---- prologue: halo of chunk 0, weight slices of steps 0 and 1 ---------------------------------------------
+  static_for<AJ>([&](auto J) { issue_a(0, 0, J); });
+  static_for<BJ>([&](auto J) { issue_b(0, 0, 0, J); });
+  if (nsteps > 1) static_for<BJ>([&](auto J) { issue_b(0, 1, 1, J); });
+
+  int stage = 0;   // B ring stage of the current step
+  for (int c = 0; c < nchunk; ++c) {
+    const int abuf = c & 1;
+    const bool relu = c * BK < relu_cend;
+    const bool next_a = c + 1 < nchunk;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap) {
+      const int s = c * 4 + tap;
+      // outstanding issues that may remain: everything issued after the newest piece this step needs
+      //   tap 0 (needs the halo, whose last piece was the FIRST issue of the previous step): that step's B pieces
+      //   tap > 0 (needs B(s), the last issue of step s-2): all issues of step s-1
+      int nwait;
+      if (s == 0) nwait = nsteps > 1 ? BJ : 0;
+      else {
+        const int sp = s - 1;                                     // previous step
+        const int ib = (sp + 2 < nsteps) ? BJ : 0;
+        const int ia = ((sp >> 2) + 1 < nchunk) ? ((sp & 3) == 0 ? 2 : 1) : 0;
+        nwait = tap == 0 ? ib : ia + ib;
+      }
+      wait_vm(nwait);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+
+      const char* sa = smem + A_OFF + abuf * A_BYTES;
+      const bool more_b = s + 2 < nsteps;
+      int st2 = stage + 2;
+      if (st2 >= 3) st2 -= 3;
+      const int c2 = (s + 2) >> 2, tap2 = (s + 2) & 3;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        h8_t af[MT], bf[NT];
+        // k-half 1 = logical chunk 4 + lq: the physical chunk of half 0 with bit 2 flipped, i.e. byte offset ^ 64
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(sa + (rdA[mt][tap] ^ (k2 << 6)));
+        const char* sbh = smem + B_OFF + stage * B_BYTES + (rdB ^ (k2 << 6));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(sbh + nt * 2048);
+        if (relu) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) af[mt] = relu5(af[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+            const int idx = k2 * MT * NT + mt * NT + nt;
+            // halo pieces of the next chunk first (2 at tap 0, then 1 per tap), then the weight slice of step s+2
+            if (next_a) {
+              if (tap == 0) {
+                if (idx == 2) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 0>{});
+                if (idx == 8) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 1>{});
+              } else {
+                if (idx == 4) {
+                  if (tap == 1) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 2>{});
+                  if (tap == 2) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 3>{});
+                  if (tap == 3) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 4>{});
+                }
+              }
+            }
+            if (more_b) {
+              static_for<BJ>([&](auto Q) {
+                constexpr int q = decltype(Q)::value;
+                if (idx == 14 + q * (MT * NT * 2 - 16) / (BJ > 1 ? BJ : 1)) issue_b(c2, tap2, st2, Q);
+              });
+            }
+          }
+      }
+      ++stage;
+      if (stage == 3) stage = 0;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- epilogue (contract of igemm3) --------------------------------------------------------------------------
+  auto out_pixel = [&](int m) -> int {
+    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+    return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;
+  };
+  constexpr int SLD = BN + 8;
+  half_t* stg = (half_t*)smem;
+  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = wn * WN + nt * 16 + 4 * lq;
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][nt][r] + bs[r];
+        s[r] += v;
+        q[r] += v * v;
+        o[r] = (half_t)act5(v, p.act_out);
+      }
+      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
+    }
+    if (p.partials) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+      }
+    }
+  }
+  __syncthreads();
+  if (p.partials && tid < BN) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
+    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
+    p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
+    p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+  }
+  constexpr int CPRO = BN / 8;
+  const int oc = tid % CPRO;
+#pragma unroll 1
+  for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
+    const int64_t o = (int64_t)out_pixel(r) * p.ldout + p.coffout + n0 + oc * 8;
+    *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+  }
+}
+
+}  // namespace
+
+// PHASE mode only. Returns GI_ERR_UNSUPPORTED for shapes it does not serve (the caller falls back to igemm3).
+int op_igemm5(hipStream_t st, IgemmArgs& a) {
+  if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
+  if (!gi_is_pow2(a.Ws) || a.Ws < 8) return GI_ERR_UNSUPPORTED;
+  const int TW = a.Ws < 32 ? a.Ws : 32, TH = 256 / TW;
+  if (a.Hs % TH != 0) return GI_ERR_UNSUPPORTED;
+  if ((TH + 1) * (TW + 1) > 320) return GI_ERR_UNSUPPORTED;
+  const int BN = (a.cout % 128 == 0) ? 128 : 64;
+  const int tiles_x = a.Ws / TW, tiles_per_img = tiles_x * (a.Hs / TH);
+  const int mtiles = a.n * tiles_per_img;
+  if (mtiles * (a.cout / BN) * 4 < 128) return GI_ERR_UNSUPPORTED;
+  int dev = 0;
+  GI_HIP(hipGetDevice(&dev));
+  const char* zero = gi_igemm3_zero_page(dev);
+  if (!zero) return GI_ERR_HIP;
+  GI_REQUIRE((int64_t)a.n * a.Hs * a.Ws * a.ldin < (1ll << 31) && (int64_t)a.n * 4 * a.Hs * a.Ws * a.ldout < (1ll << 31),
+             "igemm5: tensor too large for 32-bit offsets");
+  KP5 kp;
+  kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = zero;
+  kp.bias = a.bias; kp.partials = a.partials;
+  kp.Hs = a.Hs; kp.Ws = a.Ws; kp.n = a.n; kp.TH = TH; kp.TW = TW;
+  kp.tiles_x = tiles_x; kp.tiles_per_img = tiles_per_img; kp.mtiles = mtiles;
+  kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
+  kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
+  kp.nchunk = a.cin / 64;
+  kp.relu_in = a.relu_in; kp.act_out = a.act_out;
+  kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
+  kp.ntiles = a.cout / BN;
+  const int nyz = kp.ntiles * 4;
+  const int grid = ((mtiles + 7) / 8) * 8 * nyz;
+  const int ring = 2 * 320 * 128 + 3 * BN * 128, epi = 256 * (BN + 8) * 2 + 4 * BN * 8;
+  const int LDS = ring > epi ? ring : epi;
+  static bool attr[2] = {false, false};
+  if (BN == 128) {
+    if (!attr[0]) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[0] = true; }
+    hipLaunchKernelGGL(igemm5_kernel<128>, dim3(grid), dim3(512), LDS, st, kp);
+  } else {
+    if (!attr[1]) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[1] = true; }
+    hipLaunchKernelGGL(igemm5_kernel<64>, dim3(grid), dim3(512), LDS, st, kp);
+  }
+  GI_LAUNCH_CHECK();
+  a.ntiles_out = mtiles * 4;
+  return GI_OK;
+}
