@@ -365,17 +365,17 @@ const char* gi_igemm3_zero_page(int dev) {
   return g_zero_page[dev & 15];
 }
 
-int op_igemm5(hipStream_t st, IgemmArgs& a);   // igemm5.hip: halo-resident sub-pixel-phase kernel
+int op_igemm5(hipStream_t st, int mode, IgemmArgs& a);   // igemm5.hip: halo-resident kernels (modes 0 and 1)
 
 // mode: 0 = Conv2d 4x4/s2/p1 gather, 1 = sub-pixel phases (ConvTranspose2d forward / Conv2d dgrad),
 //       2 = Conv2d 3x3/s1/p1 (VGG features; weights [cout][9*cin], tap-major).
 // returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
 int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
-  static int use5 = -1;   // GI_IGEMM5=0 disables the halo-resident kernel for the sub-pixel-phase mode (tools: A/B)
-  if (use5 < 0) { const char* e = getenv("GI_IGEMM5"); use5 = e ? atoi(e) : 1; }
-  if (mode == 1 && use5) {
-    const int rc = op_igemm5(st, a);
+  static int use5 = -1;   // GI_IGEMM5: bit 0 = halo-resident kernel for mode 1, bit 1 = for mode 0 (tools: A/B; default both)
+  if (use5 < 0) { const char* e = getenv("GI_IGEMM5"); use5 = e ? atoi(e) : 3; }
+  if ((mode == 1 && (use5 & 1)) || (mode == 0 && (use5 & 2))) {
+    const int rc = op_igemm5(st, mode, a);
     if (rc != GI_ERR_UNSUPPORTED) return rc;
   }
   const int M = a.n * a.Hs * a.Ws;

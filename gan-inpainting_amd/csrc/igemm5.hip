@@ -1,5 +1,6 @@
-// fp16 sub-pixel-phase implicit GEMM with an LDS-RESIDENT INPUT HALO (gfx950): ConvTranspose2d forward / Conv2d
-// input gradient of the 4x4 / stride-2 / pad-1 family, same contract as igemm3_kernel<PHASE>.
+// fp16 implicit GEMMs of the 4x4 / stride-2 / pad-1 family with an LDS-RESIDENT INPUT HALO (gfx950), same contract
+// as igemm3_kernel: MODE 1 = sub-pixel phases (ConvTranspose2d forward / Conv2d input gradient), MODE 0 = the
+// stride-2 gather (Conv2d forward / ConvTranspose2d input gradient).
 //
 // igemm3 gathers the A operand tap by tap: every input row is fetched once per tap (4x in this mode), and the
 // hardware counters / ablations show the kernel bound by LDS-DMA issue, i.e. by loaded bytes per MAC
@@ -8,6 +9,10 @@
 // double buffered) and runs the four taps from it: the A fragment of tap (ty,tx) for pixel (y,x) is LDS row
 // (y+1-ty)*(TW+1) + (x+1-tx). Only the 16 KiB weight slice of each (chunk, tap) step still streams through a
 // three-stage ring: 25.5 instead of 48 KiB of LDS-DMA per step.
+// MODE 0 uses the polyphase view of a stride-2 convolution: restricted to the input pixels of one parity class
+// q = (qy,qx) it is a 2x2 / stride-1 convolution (input row 2y-1+ky has parity qy for ky = 2*ty + 1 - qy... i.e.
+// ky = qy ? 2*ty : 2*ty+1), so per channel chunk FOUR halos (one per parity class, rows picked with stride 2 from
+// the large tensor) are loaded in turn and each serves four taps: the same pipeline with 4x as many halo groups.
 //   LDS: A halo 2 x 40 KiB | B ring 3 x BN*128 B   (128 KiB for BN = 128); rows of 128 B, 16-byte chunk c of row
 //   r at physical chunk c ^ (r & 7) (applied to the per-lane DMA source address, as in igemm3).
 //   Step s = (chunk c, tap): counted vmcnt + ONE barrier; during its 2x16 MFMAs per wave the pieces of the next
@@ -27,7 +32,7 @@ struct KP5 {
   const char* zero;
   const float* bias;
   float* partials;
-  int Hs, Ws, n;
+  int Hs, Ws, n;      // the small grid (MODE 1: input, MODE 0: output)
   int TH, TW;         // patch of the small grid, TH*TW = 256; TW a power of two
   int tiles_x, tiles_per_img, mtiles;
   int cin, ldin, coffin;
@@ -63,8 +68,9 @@ __device__ __forceinline__ void wait_vm(int n) {   // n is wave-uniform
   }
 }
 
-template <int BN>
+template <int MODE, int BN>
 __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
+  constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups per channel chunk
   constexpr int BM = 256, BK = 64, NW = 8;
   constexpr int A_ROWS = 320, A_BYTES = A_ROWS * 128;   // 40 pieces of 8 rows: 5 per wave
   constexpr int B_BYTES = BN * 128;
@@ -78,7 +84,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- XCD-aware tile order (as igemm3): the (N tile, phase) blocks of one patch run back to back on one XCD
-  const int nyz = p.ntiles * 4;
+  const int nyz = p.ntiles * (MODE == 1 ? 4 : 1);
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
   const int mt_idx = (local / nyz) * 8 + xcd;
@@ -91,32 +97,65 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
   const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
   const int HC = p.TW + 1, HR = p.TH + 1;
-  const char* wptr = p.w + (int64_t)ph * p.cout * (4 * p.cin) * 2;
-  const int Ktot2 = 4 * p.cin * 2;   // bytes per weight row
+  const char* wptr = p.w + (MODE == 1 ? (int64_t)ph * p.cout * (4 * p.cin) * 2 : 0);
+  const int Ktot2 = (MODE == 1 ? 4 : 16) * p.cin * 2;   // bytes per weight row
+  const int Win = 2 * p.Ws, Hin = 2 * p.Hs;             // MODE 0: the large (input) grid
 
   // ---- per-lane DMA sources: halo rows (fixed for the whole K loop) and weight rows ------------------------
   const int lrow = lane >> 3;
   const int lchunk = (lane & 7) ^ (lrow & 7);
-  const char* pa[AJ];
+  const char* pa[AJ];   // MODE 1: final source (or the zero page); MODE 0: source for parity class (0,0)
+  unsigned amask[AJ];   // MODE 0: bit q set = this halo row exists in parity class q
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
     const int r = (wave * AJ + j) * 8 + lrow;
     const int hr = r / HC, hc = r - hr * HC;
-    const int iy = y0 + py - 1 + hr, ix = x0 + px - 1 + hc;
-    const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
-    pa[j] = ok ? p.in + ((int64_t)((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16 : p.zero + lchunk * 16;
+    amask[j] = 0;
+    if constexpr (MODE == 1) {
+      const int iy = y0 + py - 1 + hr, ix = x0 + px - 1 + hc;
+      const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+      pa[j] = ok ? p.in + ((int64_t)((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16 : p.zero + lchunk * 16;
+    } else {
+      // halo (hr,hc) of parity class (qy,qx) is input pixel (2*(y0+hr) - qy, 2*(x0+hc) - qx)
+      const int iy0 = 2 * (y0 + hr), ix0 = 2 * (x0 + hc);
+      pa[j] = p.in + ((int64_t)((img * Hin + iy0) * Win + ix0) * p.ldin + p.coffin) * 2 + lchunk * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int iy = iy0 - (q >> 1), ix = ix0 - (q & 1);
+        if (hr < HR && iy >= 0 && iy < Hin && ix >= 0 && ix < Win) amask[j] |= 1u << q;
+      }
+    }
   }
   const char* pb[BJ];
 #pragma unroll
   for (int j = 0; j < BJ; ++j) pb[j] = wptr + (int64_t)(n0 + (wave * BJ + j) * 8 + lrow) * Ktot2 + lchunk * 16;
 
-  auto issue_a = [&](int chunk, int buf, auto J) {   // halo piece J of `chunk` into A buffer `buf`
+  // halo piece J of group g = chunk * NQ + q into A buffer `buf`
+  auto issue_a = [&](int g, int buf, auto J) {
     constexpr int j = decltype(J)::value;
-    glds16(pa[j] + chunk * (BK * 2), smem + A_OFF + buf * A_BYTES + (wave * AJ + j) * 1024);
+    char* dst = smem + A_OFF + buf * A_BYTES + (wave * AJ + j) * 1024;
+    if constexpr (MODE == 1) {
+      glds16(pa[j] + g * (BK * 2), dst);
+    } else {
+      const int chunk = g >> 2, q = g & 3;
+      const int64_t back = (int64_t)((q >> 1) * Win + (q & 1)) * p.ldin * 2;      // wave-uniform
+      const char* src = ((amask[j] >> q) & 1u) ? pa[j] - back + chunk * (BK * 2) : p.zero + lchunk * 16;
+      glds16(src, dst);
+    }
   };
-  auto issue_b = [&](int chunk, int tap, int stage, auto J) {
+  // weight slice of step s = g * 4 + tap into ring stage `stage`
+  auto issue_b = [&](int s, int stage, auto J) {
     constexpr int j = decltype(J)::value;
-    glds16(pb[j] + (tap * p.cin + chunk * BK) * 2, smem + B_OFF + stage * B_BYTES + (wave * BJ + j) * 1024);
+    const int g = s >> 2, tap = s & 3;
+    int koff;
+    if constexpr (MODE == 1) {
+      koff = tap * p.cin + g * BK;
+    } else {
+      const int chunk = g >> 2, q = g & 3;
+      const int ky = (q >> 1) ? 2 * (tap >> 1) : 2 * (tap >> 1) + 1, kx = (q & 1) ? 2 * (tap & 1) : 2 * (tap & 1) + 1;
+      koff = (ky * 4 + kx) * p.cin + chunk * BK;
+    }
+    glds16(pb[j] + koff * 2, smem + B_OFF + stage * B_BYTES + (wave * BJ + j) * 1024);
   };
 
   // ---- fragment read addresses -----------------------------------------------------------------------------
@@ -129,7 +168,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
-      const int R = (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1));
+      const int R = MODE == 1 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1)) : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
       rdA[mt][tap] = R * 128 + ((lq ^ (R & 7)) << 4);
     }
   }
@@ -141,19 +180,19 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunk = p.nchunk, nsteps = nchunk * 4;
+  const int ngroups = p.nchunk * NQ, nsteps = ngroups * 4;
   const int relu_cend = p.relu_in ? p.relu_cend : 0;
 
-  // ---- prologue: halo of chunk 0, weight slices of steps 0 and 1 ---------------------------------------------
+  // ---- prologue: halo of group 0, weight slices of steps 0 and 1 ---------------------------------------------
   static_for<AJ>([&](auto J) { issue_a(0, 0, J); });
-  static_for<BJ>([&](auto J) { issue_b(0, 0, 0, J); });
-  if (nsteps > 1) static_for<BJ>([&](auto J) { issue_b(0, 1, 1, J); });
+  static_for<BJ>([&](auto J) { issue_b(0, 0, J); });
+  if (nsteps > 1) static_for<BJ>([&](auto J) { issue_b(1, 1, J); });
 
   int stage = 0;   // B ring stage of the current step
-  for (int c = 0; c < nchunk; ++c) {
+  for (int c = 0; c < ngroups; ++c) {      // c: halo group (MODE 1: channel chunk; MODE 0: chunk * 4 + parity class)
     const int abuf = c & 1;
-    const bool relu = c * BK < relu_cend;
-    const bool next_a = c + 1 < nchunk;
+    const bool relu = (c / NQ) * BK < relu_cend;
+    const bool next_a = c + 1 < ngroups;
 #pragma unroll
     for (int tap = 0; tap < 4; ++tap) {
       const int s = c * 4 + tap;
@@ -165,7 +204,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
       else {
         const int sp = s - 1;                                     // previous step
         const int ib = (sp + 2 < nsteps) ? BJ : 0;
-        const int ia = ((sp >> 2) + 1 < nchunk) ? ((sp & 3) == 0 ? 2 : 1) : 0;
+        const int ia = ((sp >> 2) + 1 < ngroups) ? ((sp & 3) == 0 ? 2 : 1) : 0;
         nwait = tap == 0 ? ib : ia + ib;
       }
       wait_vm(nwait);
@@ -176,7 +215,6 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
       const bool more_b = s + 2 < nsteps;
       int st2 = stage + 2;
       if (st2 >= 3) st2 -= 3;
-      const int c2 = (s + 2) >> 2, tap2 = (s + 2) & 3;
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
         h8_t af[MT], bf[NT];
@@ -212,7 +250,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
             if (more_b) {
               static_for<BJ>([&](auto Q) {
                 constexpr int q = decltype(Q)::value;
-                if (idx == 14 + q * (MT * NT * 2 - 16) / (BJ > 1 ? BJ : 1)) issue_b(c2, tap2, st2, Q);
+                if (idx == 14 + q * (MT * NT * 2 - 16) / (BJ > 1 ? BJ : 1)) issue_b(s + 2, st2, Q);
               });
             }
           }
@@ -227,7 +265,8 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   // ---- epilogue (contract of igemm3) --------------------------------------------------------------------------
   auto out_pixel = [&](int m) -> int {
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
-    return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;
+    if constexpr (MODE == 1) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;
+    else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;
   };
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
@@ -270,7 +309,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
-    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
+    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * (MODE == 1 ? ph : 0);
     p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
     p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
   }
@@ -285,23 +324,26 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
 
 }  // namespace
 
-// PHASE mode only. Returns GI_ERR_UNSUPPORTED for shapes it does not serve (the caller falls back to igemm3).
-int op_igemm5(hipStream_t st, IgemmArgs& a) {
+// mode 1 (sub-pixel phases) and mode 0 (stride-2 gather). Returns GI_ERR_UNSUPPORTED for shapes it does not serve
+// (the caller falls back to igemm3).
+int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
+  if (mode != 0 && mode != 1) return GI_ERR_UNSUPPORTED;
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
   if (!gi_is_pow2(a.Ws) || a.Ws < 8) return GI_ERR_UNSUPPORTED;
   const int TW = a.Ws < 32 ? a.Ws : 32, TH = 256 / TW;
   if (a.Hs % TH != 0) return GI_ERR_UNSUPPORTED;
   if ((TH + 1) * (TW + 1) > 320) return GI_ERR_UNSUPPORTED;
   const int BN = (a.cout % 128 == 0) ? 128 : 64;
+  const int nph = mode == 1 ? 4 : 1;
   const int tiles_x = a.Ws / TW, tiles_per_img = tiles_x * (a.Hs / TH);
   const int mtiles = a.n * tiles_per_img;
-  if (mtiles * (a.cout / BN) * 4 < 128) return GI_ERR_UNSUPPORTED;
+  if (mtiles * (a.cout / BN) * nph < 128) return GI_ERR_UNSUPPORTED;
   int dev = 0;
   GI_HIP(hipGetDevice(&dev));
   const char* zero = gi_igemm3_zero_page(dev);
   if (!zero) return GI_ERR_HIP;
-  GI_REQUIRE((int64_t)a.n * a.Hs * a.Ws * a.ldin < (1ll << 31) && (int64_t)a.n * 4 * a.Hs * a.Ws * a.ldout < (1ll << 31),
-             "igemm5: tensor too large for 32-bit offsets");
+  const int64_t in_px = (int64_t)a.n * a.Hs * a.Ws * (mode == 1 ? 1 : 4), out_px = (int64_t)a.n * a.Hs * a.Ws * (mode == 1 ? 4 : 1);
+  GI_REQUIRE(in_px * a.ldin < (1ll << 31) && out_px * a.ldout < (1ll << 31), "igemm5: tensor too large for 32-bit offsets");
   KP5 kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = zero;
   kp.bias = a.bias; kp.partials = a.partials;
@@ -313,19 +355,22 @@ int op_igemm5(hipStream_t st, IgemmArgs& a) {
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
   kp.ntiles = a.cout / BN;
-  const int nyz = kp.ntiles * 4;
+  const int nyz = kp.ntiles * nph;
   const int grid = ((mtiles + 7) / 8) * 8 * nyz;
   const int ring = 2 * 320 * 128 + 3 * BN * 128, epi = 256 * (BN + 8) * 2 + 4 * BN * 8;
   const int LDS = ring > epi ? ring : epi;
-  static bool attr[2] = {false, false};
-  if (BN == 128) {
-    if (!attr[0]) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[0] = true; }
-    hipLaunchKernelGGL(igemm5_kernel<128>, dim3(grid), dim3(512), LDS, st, kp);
-  } else {
-    if (!attr[1]) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[1] = true; }
-    hipLaunchKernelGGL(igemm5_kernel<64>, dim3(grid), dim3(512), LDS, st, kp);
+  static bool attr[4] = {false, false, false, false};
+  const void* fn[4] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<0, 64>,
+                       (const void*)igemm5_kernel<1, 64>};
+  const int vi = (BN == 64 ? 2 : 0) + mode;
+  if (!attr[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[vi] = true; }
+  switch (vi) {
+    case 0: hipLaunchKernelGGL((igemm5_kernel<0, 128>), dim3(grid), dim3(512), LDS, st, kp); break;
+    case 1: hipLaunchKernelGGL((igemm5_kernel<1, 128>), dim3(grid), dim3(512), LDS, st, kp); break;
+    case 2: hipLaunchKernelGGL((igemm5_kernel<0, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
+    default: hipLaunchKernelGGL((igemm5_kernel<1, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
   }
   GI_LAUNCH_CHECK();
-  a.ntiles_out = mtiles * 4;
+  a.ntiles_out = mtiles * nph;
   return GI_OK;
 }
