@@ -372,9 +372,9 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a);   // igemm5.hip: halo-res
 // returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
 int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
-  static int use5 = -1;   // GI_IGEMM5: bit 0 = halo-resident kernel for mode 1, bit 1 = for mode 0 (tools: A/B; default both)
-  if (use5 < 0) { const char* e = getenv("GI_IGEMM5"); use5 = e ? atoi(e) : 3; }
-  if ((mode == 1 && (use5 & 1)) || (mode == 0 && (use5 & 2))) {
+  static int use5 = -1;   // GI_IGEMM5: bit 0 / 1 / 2 = halo-resident kernel for mode 1 / 0 / 2 (tools: A/B; default all)
+  if (use5 < 0) { const char* e = getenv("GI_IGEMM5"); use5 = e ? atoi(e) : 7; }
+  if ((mode == 1 && (use5 & 1)) || (mode == 0 && (use5 & 2)) || (mode == 2 && (use5 & 4))) {
     const int rc = op_igemm5(st, mode, a);
     if (rc != GI_ERR_UNSUPPORTED) return rc;
   }

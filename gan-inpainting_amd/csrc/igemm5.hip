@@ -1,6 +1,7 @@
 // fp16 implicit GEMMs of the 4x4 / stride-2 / pad-1 family with an LDS-RESIDENT INPUT HALO (gfx950), same contract
 // as igemm3_kernel: MODE 1 = sub-pixel phases (ConvTranspose2d forward / Conv2d input gradient), MODE 0 = the
-// stride-2 gather (Conv2d forward / ConvTranspose2d input gradient).
+// stride-2 gather (Conv2d forward / ConvTranspose2d input gradient), MODE 2 = Conv2d 3x3 / stride 1 / pad 1 (VGG
+// features: a (TH+2) x (TW+2) halo serves nine taps).
 //
 // igemm3 gathers the A operand tap by tap: every input row is fetched once per tap (4x in this mode), and the
 // hardware counters / ablations show the kernel bound by LDS-DMA issue, i.e. by loaded bytes per MAC
@@ -71,11 +72,14 @@ __device__ __forceinline__ void wait_vm(int n) {   // n is wave-uniform
 template <int MODE, int BN>
 __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups per channel chunk
+  constexpr int NTAP = MODE == 2 ? 9 : 4;               // taps (steps) per halo group
+  constexpr int PAD = MODE == 2 ? 2 : 1;                // halo = (TH + PAD) x (TW + PAD)
   constexpr int BM = 256, BK = 64, NW = 8;
-  constexpr int A_ROWS = 320, A_BYTES = A_ROWS * 128;   // 40 pieces of 8 rows: 5 per wave
+  constexpr int AJ = MODE == 2 ? 6 : 5;                 // halo pieces (8 rows x 128 B) per wave and group
+  constexpr int A_ROWS = AJ * 64, A_BYTES = A_ROWS * 128;   // 40 / 48 KiB per buffer
   constexpr int B_BYTES = BN * 128;
   constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;
-  constexpr int AJ = 5, BJ = (BN / 8) / NW;             // pieces per wave: halo (per chunk) / weight slice (per step)
+  constexpr int BJ = (BN / 8) / NW;                     // weight-slice pieces per wave and step
   constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -96,9 +100,9 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   const int n0 = nt_idx * BN;
   const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
   const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
-  const int HC = p.TW + 1, HR = p.TH + 1;
+  const int HC = p.TW + PAD, HR = p.TH + PAD;
   const char* wptr = p.w + (MODE == 1 ? (int64_t)ph * p.cout * (4 * p.cin) * 2 : 0);
-  const int Ktot2 = (MODE == 1 ? 4 : 16) * p.cin * 2;   // bytes per weight row
+  const int Ktot2 = (MODE == 1 ? 4 : (MODE == 2 ? 9 : 16)) * p.cin * 2;   // bytes per weight row
   const int Win = 2 * p.Ws, Hin = 2 * p.Hs;             // MODE 0: the large (input) grid
 
   // ---- per-lane DMA sources: halo rows (fixed for the whole K loop) and weight rows ------------------------
@@ -111,8 +115,8 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     const int r = (wave * AJ + j) * 8 + lrow;
     const int hr = r / HC, hc = r - hr * HC;
     amask[j] = 0;
-    if constexpr (MODE == 1) {
-      const int iy = y0 + py - 1 + hr, ix = x0 + px - 1 + hc;
+    if constexpr (MODE != 0) {
+      const int iy = y0 + (MODE == 1 ? py : 0) - 1 + hr, ix = x0 + (MODE == 1 ? px : 0) - 1 + hc;
       const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
       pa[j] = ok ? p.in + ((int64_t)((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16 : p.zero + lchunk * 16;
     } else {
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   auto issue_a = [&](int g, int buf, auto J) {
     constexpr int j = decltype(J)::value;
     char* dst = smem + A_OFF + buf * A_BYTES + (wave * AJ + j) * 1024;
-    if constexpr (MODE == 1) {
+    if constexpr (MODE != 0) {
       glds16(pa[j] + g * (BK * 2), dst);
     } else {
       const int chunk = g >> 2, q = g & 3;
@@ -143,12 +147,12 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
       glds16(src, dst);
     }
   };
-  // weight slice of step s = g * 4 + tap into ring stage `stage`
+  // weight slice of step s = g * NTAP + tap into ring stage `stage`
   auto issue_b = [&](int s, int stage, auto J) {
     constexpr int j = decltype(J)::value;
-    const int g = s >> 2, tap = s & 3;
+    const int g = s / NTAP, tap = s - g * NTAP;
     int koff;
-    if constexpr (MODE == 1) {
+    if constexpr (MODE != 0) {
       koff = tap * p.cin + g * BK;
     } else {
       const int chunk = g >> 2, q = g & 3;
@@ -161,14 +165,16 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   // ---- fragment read addresses -----------------------------------------------------------------------------
   const int lr = lane & 15, lq = lane >> 4;
   const int lgTW = 31 - __builtin_clz(p.TW);
-  int rdA[MT][4];   // byte offset inside an A buffer of (pixel row of tile mt, tap), k-half 0; k-half 1 = ^ 64
+  int rdA[MT][NTAP];   // byte offset inside an A buffer of (pixel row of tile mt, tap), k-half 0; k-half 1 = ^ 64
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = wm * 64 + mt * 16 + lr;
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
 #pragma unroll
-    for (int tap = 0; tap < 4; ++tap) {
-      const int R = MODE == 1 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1)) : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int R = MODE == 1 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1))
+                  : MODE == 0 ? (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1))
+                              : (ty_l + tap / 3) * HC + (tx_l + tap % 3);
       rdA[mt][tap] = R * 128 + ((lq ^ (R & 7)) << 4);
     }
   }
@@ -180,8 +186,14 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int ngroups = p.nchunk * NQ, nsteps = ngroups * 4;
+  const int ngroups = p.nchunk * NQ, nsteps = ngroups * NTAP;
   const int relu_cend = p.relu_in ? p.relu_cend : 0;
+  // halo pieces of the NEXT group issued during tap t of the current one (halo pieces first, then the weight
+  // slice of step s+2). Rule: before step s everything but the issues of step s-1 must have landed (B(s) was the
+  // last issue of step s-2), see nwait below.
+  // 4-tap modes: 2,1,1,1 (measured 3 % faster than 2,2,1,0); 9-tap mode: one piece in each of the first six taps
+  auto a_pieces = [](int tap) -> int { return MODE == 2 ? (tap < 6 ? 1 : 0) : (tap == 0 ? 2 : 1); };
+  auto a_first = [](int tap) -> int { return MODE == 2 ? tap : (tap == 0 ? 0 : tap + 1); };   // index of a tap's first piece
 
   // ---- prologue: halo of group 0, weight slices of steps 0 and 1 ---------------------------------------------
   static_for<AJ>([&](auto J) { issue_a(0, 0, J); });
@@ -189,23 +201,22 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   if (nsteps > 1) static_for<BJ>([&](auto J) { issue_b(1, 1, J); });
 
   int stage = 0;   // B ring stage of the current step
-  for (int c = 0; c < ngroups; ++c) {      // c: halo group (MODE 1: channel chunk; MODE 0: chunk * 4 + parity class)
+  for (int c = 0; c < ngroups; ++c) {      // c: halo group (channel chunk; MODE 0: chunk * 4 + parity class)
     const int abuf = c & 1;
     const bool relu = (c / NQ) * BK < relu_cend;
     const bool next_a = c + 1 < ngroups;
 #pragma unroll
-    for (int tap = 0; tap < 4; ++tap) {
-      const int s = c * 4 + tap;
-      // outstanding issues that may remain: everything issued after the newest piece this step needs
-      //   tap 0 (needs the halo, whose last piece was the FIRST issue of the previous step): that step's B pieces
-      //   tap > 0 (needs B(s), the last issue of step s-2): all issues of step s-1
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int s = c * NTAP + tap;
+      // outstanding issues that may remain: those of step s-1 (B(s) was the last issue of step s-2)
       int nwait;
       if (s == 0) nwait = nsteps > 1 ? BJ : 0;
       else {
-        const int sp = s - 1;                                     // previous step
-        const int ib = (sp + 2 < nsteps) ? BJ : 0;
-        const int ia = ((sp >> 2) + 1 < ngroups) ? ((sp & 3) == 0 ? 2 : 1) : 0;
-        nwait = tap == 0 ? ib : ia + ib;
+        const int sp = s - 1, gp = sp / NTAP, tp = sp - gp * NTAP;
+        nwait = ((sp + 2 < nsteps) ? BJ : 0) + ((gp + 1 < ngroups) ? a_pieces(tp) : 0);
+        // 4-tap modes: the halo's last piece is the FIRST issue of step s-1 (tap 3), so at tap 0 only that step's
+        // weight pieces may still be in flight
+        if (MODE != 2 && tap == 0) nwait = (sp + 2 < nsteps) ? BJ : 0;
       }
       wait_vm(nwait);
       __builtin_amdgcn_s_barrier();
@@ -234,18 +245,13 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
           for (int nt = 0; nt < NT; ++nt) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
             const int idx = k2 * MT * NT + mt * NT + nt;
-            // halo pieces of the next chunk first (2 at tap 0, then 1 per tap), then the weight slice of step s+2
+            // halo pieces of the next group first, then the weight slice of step s+2
             if (next_a) {
-              if (tap == 0) {
-                if (idx == 2) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 0>{});
-                if (idx == 8) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 1>{});
-              } else {
-                if (idx == 4) {
-                  if (tap == 1) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 2>{});
-                  if (tap == 2) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 3>{});
-                  if (tap == 3) issue_a(c + 1, abuf ^ 1, std::integral_constant<int, 4>{});
-                }
-              }
+              static_for<AJ>([&](auto J) {
+                constexpr int j = decltype(J)::value;
+                const int k = j - a_first(tap);            // position of piece j among this tap's pieces
+                if (k >= 0 && k < a_pieces(tap) && idx == 2 + 6 * k) issue_a(c + 1, abuf ^ 1, J);
+              });
             }
             if (more_b) {
               static_for<BJ>([&](auto Q) {
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   auto out_pixel = [&](int m) -> int {
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
     if constexpr (MODE == 1) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;
-    else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;
+    else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;   // MODE 0 / 2: the tile's own pixels
   };
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
@@ -327,22 +333,22 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
 // mode 1 (sub-pixel phases) and mode 0 (stride-2 gather). Returns GI_ERR_UNSUPPORTED for shapes it does not serve
 // (the caller falls back to igemm3).
 int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
-  if (mode != 0 && mode != 1) return GI_ERR_UNSUPPORTED;
+  if (mode < 0 || mode > 2) return GI_ERR_UNSUPPORTED;
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
   if (!gi_is_pow2(a.Ws) || a.Ws < 8) return GI_ERR_UNSUPPORTED;
   const int TW = a.Ws < 32 ? a.Ws : 32, TH = 256 / TW;
   if (a.Hs % TH != 0) return GI_ERR_UNSUPPORTED;
-  if ((TH + 1) * (TW + 1) > 320) return GI_ERR_UNSUPPORTED;
+  if (mode == 2 ? (TH + 2) * (TW + 2) > 384 : (TH + 1) * (TW + 1) > 320) return GI_ERR_UNSUPPORTED;
   const int BN = (a.cout % 128 == 0) ? 128 : 64;
   const int nph = mode == 1 ? 4 : 1;
   const int tiles_x = a.Ws / TW, tiles_per_img = tiles_x * (a.Hs / TH);
   const int mtiles = a.n * tiles_per_img;
-  if (mtiles * (a.cout / BN) * nph < 128) return GI_ERR_UNSUPPORTED;
+  if (mode != 2 && mtiles * (a.cout / BN) * nph < 128) return GI_ERR_UNSUPPORTED;
   int dev = 0;
   GI_HIP(hipGetDevice(&dev));
   const char* zero = gi_igemm3_zero_page(dev);
   if (!zero) return GI_ERR_HIP;
-  const int64_t in_px = (int64_t)a.n * a.Hs * a.Ws * (mode == 1 ? 1 : 4), out_px = (int64_t)a.n * a.Hs * a.Ws * (mode == 1 ? 4 : 1);
+  const int64_t in_px = (int64_t)a.n * a.Hs * a.Ws * (mode == 0 ? 4 : 1), out_px = (int64_t)a.n * a.Hs * a.Ws * (mode == 1 ? 4 : 1);
   GI_REQUIRE(in_px * a.ldin < (1ll << 31) && out_px * a.ldout < (1ll << 31), "igemm5: tensor too large for 32-bit offsets");
   KP5 kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = zero;
@@ -357,18 +363,20 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.ntiles = a.cout / BN;
   const int nyz = kp.ntiles * nph;
   const int grid = ((mtiles + 7) / 8) * 8 * nyz;
-  const int ring = 2 * 320 * 128 + 3 * BN * 128, epi = 256 * (BN + 8) * 2 + 4 * BN * 8;
+  const int ring = 2 * (mode == 2 ? 384 : 320) * 128 + 3 * BN * 128, epi = 256 * (BN + 8) * 2 + 4 * BN * 8;
   const int LDS = ring > epi ? ring : epi;
-  static bool attr[4] = {false, false, false, false};
-  const void* fn[4] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<0, 64>,
-                       (const void*)igemm5_kernel<1, 64>};
-  const int vi = (BN == 64 ? 2 : 0) + mode;
+  static bool attr[6] = {false, false, false, false, false, false};
+  const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
+                       (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
+  const int vi = (BN == 64 ? 3 : 0) + mode;
   if (!attr[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[vi] = true; }
   switch (vi) {
     case 0: hipLaunchKernelGGL((igemm5_kernel<0, 128>), dim3(grid), dim3(512), LDS, st, kp); break;
     case 1: hipLaunchKernelGGL((igemm5_kernel<1, 128>), dim3(grid), dim3(512), LDS, st, kp); break;
-    case 2: hipLaunchKernelGGL((igemm5_kernel<0, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
-    default: hipLaunchKernelGGL((igemm5_kernel<1, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
+    case 2: hipLaunchKernelGGL((igemm5_kernel<2, 128>), dim3(grid), dim3(512), LDS, st, kp); break;
+    case 3: hipLaunchKernelGGL((igemm5_kernel<0, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
+    case 4: hipLaunchKernelGGL((igemm5_kernel<1, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
+    default: hipLaunchKernelGGL((igemm5_kernel<2, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
   }
   GI_LAUNCH_CHECK();
   a.ntiles_out = mtiles * nph;
