@@ -32,7 +32,7 @@ def stats(path, title, out):
 
 
 def pmc(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if "igemm3_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter]
+    rows = [r for r in csv.DictReader(open(path)) if ("igemm5_kernel" in r["Kernel_Name"] or "igemm3_kernel" in r["Kernel_Name"]) and r["Counter_Name"] == counter]
     vals = [float(r["Counter_Value"]) for r in rows]
     return sum(vals) / len(vals), len(vals)
 
@@ -46,7 +46,7 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
     stats(newest(f"{src}/bench/runc/*_kernel_stats.csv"), "B. `python bench.py --steps 10 --warmup 5 --no-cpu-baseline` — whole benchmark process", out)
     fetch, nf = pmc(newest(f"{src}/pmc_fetch/runc/*_counter_collection.csv"), "FETCH_SIZE")
     write, nw = pmc(newest(f"{src}/pmc_write/runc/*_counter_collection.csv"), "WRITE_SIZE")
-    dom = [r for r in ko if "igemm3_kernel" in r["Name"]][0]
+    dom = [r for r in ko if ("igemm5_kernel" in r["Name"] or "igemm3_kernel" in r["Name"])][0]
     avg_ms = float(dom["AverageNs"]) / 1e6
     flop = 2.0 * 4 * 32768 * 128 * 2048
     traffic = (2 * fetch + write) * 1024
