@@ -77,8 +77,25 @@ int gi_wgrad_s2(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW,
   a.S = S; a.L = L; a.dW = dW; a.n = n; a.Hs = Hs; a.Ws = Ws;
   a.ca = ca; a.ldS = ldS; a.coffS = 0; a.cb = cb; a.ldL = ldL; a.coffL = 0;
   a.relu_S = relu_S; a.scale = scale;
+  a.scratch = nullptr; a.scratch_bytes = 0;      // atomics across the pixel-range splits
   return op_wgrad(ctx->stream, dtype, a);
 }
+
+int64_t gi_wgrad_s2_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb) {
+  return op_wgrad_scratch_bytes(dtype, n, Hs, Ws, ca, cb);
+}
+
+int gi_wgrad_s2_ws(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW, int n, int Hs, int Ws, int ca, int ldS, int cb, int ldL,
+                   int relu_S, float scale, float* scratch, int64_t scratch_bytes) {
+  GI_REQUIRE(ctx && S && L && dW, "wgrad_s2_ws: null pointer");
+  WgradArgs a;
+  a.S = S; a.L = L; a.dW = dW; a.n = n; a.Hs = Hs; a.Ws = Ws;
+  a.ca = ca; a.ldS = ldS; a.coffS = 0; a.cb = cb; a.ldL = ldL; a.coffL = 0;
+  a.relu_S = relu_S; a.scale = scale;
+  a.scratch = scratch; a.scratch_bytes = scratch_bytes;
+  return op_wgrad(ctx->stream, dtype, a);
+}
+
 
 int gi_pack_weights(gi_ctx* ctx, int dtype, const float* w, int ca, int cb, void* w_packed, void* w_phase) {
   GI_REQUIRE(ctx && w, "pack_weights: null pointer");

@@ -105,14 +105,17 @@ int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
 struct WgradArgs {
   const void* S;   // small tensor (n,Hs,Ws,ca), ld=ldS, channel offset coffS
   const void* L;   // large tensor (n,2Hs,2Ws,cb), ld=ldL, channel offset coffL
-  float* dW;       // fp32 [ca][16][cb], accumulated with atomics
+  float* dW;       // fp32 [ca][16][cb], accumulated (+=)
   int n, Hs, Ws;
   int ca, ldS, coffS;
   int cb, ldL, coffL;
   int relu_S;
   float scale;
+  float* scratch;          // optional: op_wgrad_scratch_bytes() bytes; the pixel-range splits then write partial tiles
+  int64_t scratch_bytes;   // with plain stores and a fixed-order pass adds them to dW (deterministic); else atomics
 };
 int op_wgrad(hipStream_t st, int dtype, const WgradArgs& a);
+int64_t op_wgrad_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb);
 
 // single-channel-side kernels (generator first conv / last transposed conv, discriminator first
 // conv): weights fp32 [c][16] (= [a][ky][kx][b] with b == 1)

@@ -79,6 +79,7 @@ struct gi_net {
   std::vector<int64_t> ogC, ogA;
   int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1, oCol = -1;
   int64_t part_floats = 0, split_bytes = 0;
+  int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
   // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
   int64_t oD2 = -1, oTZ = -1, oGimg = -1, oVimg = -1, oGPs = -1, oGPpart = -1, oGPsums = -1, oTh = -1;
@@ -234,6 +235,11 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->oSums = A.take(2 * maxc * 4);
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit);
+  for (int k = 2; k <= nd; ++k) {
+    net->wg_bytes = max64(net->wg_bytes, op_wgrad_scratch_bytes(dtype, max_n, net->Hk[k], net->Wk[k], net->conv[k].ca, net->conv[k].cb));
+    net->wg_bytes = max64(net->wg_bytes, op_wgrad_scratch_bytes(dtype, max_n, net->Hk[k], net->Wk[k], net->up[k].ca, net->up[k].cb));
+  }
+  if (net->wg_bytes > 0) net->oWg = A.take(net->wg_bytes);
   // per-slot
   Arena S;
   net->oC.assign(nd + 1, -1); net->oR.assign(nd + 1, -1); net->oU.assign(nd + 1, -1); net->oMask.assign(nd + 1, -1);
@@ -315,6 +321,9 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oSums = A.take(2 * 512 * 4);
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
+  for (int i = 2; i <= 4; ++i)
+    net->wg_bytes = max64(net->wg_bytes, op_wgrad_scratch_bytes(dtype, max_n, H >> i, W >> i, net->dconv[i].ca, net->dconv[i].cb));
+  if (net->wg_bytes > 0) net->oWg = A.take(net->wg_bytes);
   net->oDh = A.take(N * net->P * 4);
   net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   {   // gradient penalty (fp32 critics): tangent / stacked-gradient tensors
@@ -542,6 +551,8 @@ int wgrad(gi_net* net, const void* S, int ca, int ldS, int coffS, int relu_S, co
   a.S = S; a.L = L; a.dW = dW; a.n = n; a.Hs = Hs; a.Ws = Ws;
   a.ca = ca; a.ldS = ldS; a.coffS = coffS; a.cb = cb; a.ldL = ldL; a.coffL = coffL;
   a.relu_S = relu_S; a.scale = 1.f / net->loss_scale;
+  a.scratch = net->wg_bytes > 0 ? (float*)net->shared(net->oWg) : nullptr;
+  a.scratch_bytes = net->wg_bytes;
   return op_wgrad(net->ctx->stream, net->dtype, a);
 }
 

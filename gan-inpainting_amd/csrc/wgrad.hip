@@ -19,6 +19,8 @@ struct WP {
   const char* S;
   const char* L;
   float* dW;
+  float* part;       // non-null: split ks writes its tile to part[ks][ca][16*cb] with plain stores (no atomics)
+  int direct;        // 1: a single split owns every output element: dW += acc without atomics
   int P;             // pixels = n*Hs*Ws
   int lgWs, lgHs;    // Hs, Ws powers of two
   int Hs, Ws, HL, WL;
@@ -207,9 +209,50 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
         int c;
         if constexpr (F16) c = wn * 64 + nt * 16 + (lane & 15);
         else c = wn * 64 + nt * 32 + (lane & 31);
-        atomicAdd(p.dW + (int64_t)(a0 + row) * ldw + n0 + c, acc[mt][nt][r] * p.scale);
+        const int64_t o = (int64_t)(a0 + row) * ldw + n0 + c;
+        const float v = acc[mt][nt][r] * p.scale;
+        if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
+        else if (p.direct) p.dW[o] += v;
+        else atomicAdd(p.dW + o, v);
       }
     }
+}
+
+// dW[i] += sum_k part[k][i] in a fixed order (deterministic): 64 float4 outputs per block, the splits divided among
+// the four waves (contiguous k ranges), combined through LDS in wave order
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int64_t count4, int split) {
+  __shared__ f4_t red[3][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+  const int per = (split + 3) / 4, k0 = ty * per, k1 = min(split, k0 + per);
+  f4_t s = f4_t{0.f, 0.f, 0.f, 0.f};
+  if (i < count4)
+    for (int k = k0; k < k1; ++k) s += *(const f4_t*)(part + ((int64_t)k * count4 + i) * 4);
+  if (ty > 0) red[ty - 1][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < count4) {
+    s += red[0][tx];
+    s += red[1][tx];
+    s += red[2][tx];
+    f4_t d = *(f4_t*)(dW + i * 4);
+    d += s;
+    *(f4_t*)(dW + i * 4) = d;
+  }
+}
+
+int wgrad_split(int dtype, int n, int Hs, int Ws, int ca, int cb, int* tiles_per_split) {
+  const int BKP = dtype == GI_F16 ? 64 : 32;
+  const int P = n * Hs * Ws;
+  const int tiles = (ca / 128) * (16 * cb / 128);
+  const int ktiles = (P + BKP - 1) / BKP;
+  static int target = -1;   // workgroups to aim for (GI_WGRAD_BLOCKS: tools only)
+  if (target < 0) { const char* e = getenv("GI_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }   // 2 workgroups per CU in one wave; 1024 measured 10-28 % slower
+  int split = (target + tiles - 1) / tiles;
+  if (split > ktiles / 8) split = ktiles / 8;
+  if (split < 1) split = 1;
+  const int tps = (ktiles + split - 1) / split;
+  if (tiles_per_split) *tiles_per_split = tps;
+  return (ktiles + tps - 1) / tps;
 }
 
 template <typename T>
@@ -231,16 +274,12 @@ int run(hipStream_t st, const WgradArgs& a) {
   p.relu_S = a.relu_S; p.scale = a.scale;
   GI_REQUIRE((int64_t)p.P * a.ldS < (1ll << 31) && (int64_t)a.n * p.HL * p.WL * a.ldL < (1ll << 31),
              "wgrad: tensor too large for 32-bit pixel math");
-  const int tiles = (a.ca / 128) * (16 * a.cb / 128);
+  int split = wgrad_split(F16 ? GI_F16 : GI_F32, a.n, a.Hs, a.Ws, a.ca, a.cb, &p.tiles_per_split);
   constexpr int BKP = F16 ? 64 : 32;
-  const int ktiles = (p.P + BKP - 1) / BKP;
-  static int target = -1;   // workgroups to aim for (GI_WGRAD_BLOCKS: tools only)
-  if (target < 0) { const char* e = getenv("GI_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }   // 2 workgroups per CU in one wave; 1024 measured 10-28 % slower (atomics)
-  int split = (target + tiles - 1) / tiles;
-  if (split > ktiles / 8) split = ktiles / 8;
-  if (split < 1) split = 1;
-  p.tiles_per_split = (ktiles + split - 1) / split;
-  split = (ktiles + p.tiles_per_split - 1) / p.tiles_per_split;
+  const int64_t out_floats = (int64_t)a.ca * 16 * a.cb;
+  p.part = nullptr;
+  p.direct = split == 1 ? 1 : 0;
+  if (split > 1 && a.scratch && a.scratch_bytes >= (int64_t)split * out_floats * 4) p.part = a.scratch;
   constexpr int LROW = F16 ? 256 + 32 : 512;
   constexpr int LDS = 2 * 2 * BKP * LROW;
   dim3 grid(a.ca / 128, 16 * a.cb / 128, split);
@@ -251,10 +290,22 @@ int run(hipStream_t st, const WgradArgs& a) {
   }
   hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), LDS, st, p);
   GI_LAUNCH_CHECK();
+  if (p.part) {
+    const int64_t c4 = out_floats / 4;
+    const int64_t nb = (c4 + 63) / 64;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const float*)p.part, a.dW, c4, split);
+    GI_LAUNCH_CHECK();
+  }
   return GI_OK;
 }
 
 }  // namespace
+
+int64_t op_wgrad_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb) {
+  if (ca % 128 != 0 || (16 * cb) % 128 != 0) return 0;
+  const int split = wgrad_split(dtype, n, Hs, Ws, ca, cb, nullptr);
+  return split > 1 ? (int64_t)split * ca * 16 * cb * 4 : 0;
+}
 
 int op_wgrad(hipStream_t st, int dtype, const WgradArgs& a) {
   if (dtype == GI_F16) return run<half_t>(st, a);

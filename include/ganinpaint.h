@@ -268,6 +268,12 @@ int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_ph
 /* dW[a][ky][kx][b] += scale * sum_{n,y,x} S[n,y,x,a] * L[n,2y-1+ky,2x-1+kx,b] */
 int gi_wgrad_s2(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW, int n, int Hs, int Ws,
                 int ca, int ldS, int cb, int ldL, int relu_S, float scale);
+/* the same with a scratch buffer of gi_wgrad_s2_scratch_bytes(...) bytes: the pixel-range splits write their partial
+ * tiles with plain stores and a fixed-order pass adds them to dW - deterministic and faster than the fp32 atomics
+ * gi_wgrad_s2 uses (scratch NULL or too small falls back to them) */
+int64_t gi_wgrad_s2_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb);
+int gi_wgrad_s2_ws(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW, int n, int Hs, int Ws,
+                   int ca, int ldS, int cb, int ldL, int relu_S, float scale, float* scratch, int64_t scratch_bytes);
 /* fp32 master [a][16][b] -> T [a][16*b] (w_packed) and T [4][b][4*a] (w_phase); either may be NULL */
 int gi_pack_weights(gi_ctx* ctx, int dtype, const float* w, int ca, int cb, void* w_packed, void* w_phase);
 int gi_convert(gi_ctx* ctx, int dtype, const float* src, void* dst, int64_t count);      /* fp32 -> T */

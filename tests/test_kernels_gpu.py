@@ -134,6 +134,36 @@ def test_wgrad_s2(code, case):
 
 
 @pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
+def test_wgrad_s2_scratch_path_is_deterministic_and_equal(code):
+    """gi_wgrad_s2_ws: the pixel-range splits write partial tiles, a fixed-order pass adds them to dW. Same values
+    as the atomics path (to rounding), accumulate semantic kept, and bit-identical from run to run."""
+    n, Hs, Ws, ca, cb = 8, 32, 32, 128, 64          # 8192 pixels: many splits
+    S = quant(_rand((n, ca, Hs, Ws), 17), code)
+    L = quant(_rand((n, cb, 2 * Hs, 2 * Ws), 18), code)
+    ref = torch.nn.grad.conv2d_weight(L, (ca, cb, 4, 4), S, stride=2, padding=1)
+    Sd, Ld = nhwc_dev(S, code), nhwc_dev(L, code)
+    lib, ctx = B.lib(), B.get_ctx()
+    nbytes = lib.gi_wgrad_s2_scratch_bytes(code, n, Hs, Ws, ca, cb)
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+    outs = []
+    for _ in range(2):
+        dW = torch.full((ca, 4, 4, cb), 1.0, dtype=torch.float32, device="cuda")      # pre-existing gradient: += semantic
+        B.check(lib.gi_wgrad_s2_ws(ctx, code, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), n, Hs, Ws, ca, ca, cb, cb, 0, 1.0, B.ptr(ws), nbytes))
+        torch.cuda.synchronize()
+        outs.append(dW.clone())
+    assert torch.equal(outs[0], outs[1])
+    got = (outs[0] - 1.0).cpu().permute(0, 3, 1, 2)
+    ok, msg = report(f"wgrad scratch dt={code}", got, ref, 5e-5 if code == B.GI_F32 else 2e-3)
+    assert ok, msg
+    small = torch.empty(16, dtype=torch.float32, device="cuda")                       # too small: falls back to the atomics
+    dW = torch.zeros((ca, 4, 4, cb), dtype=torch.float32, device="cuda")
+    B.check(lib.gi_wgrad_s2_ws(ctx, code, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), n, Hs, Ws, ca, ca, cb, cb, 0, 1.0, B.ptr(small), 64))
+    ok, msg = report(f"wgrad fallback dt={code}", dW.cpu().permute(0, 3, 1, 2), ref, 5e-5 if code == B.GI_F32 else 2e-3)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
 def test_convT_s2_relu_strided_large(code):
     """Decoder form at igemm3 size: ReLU on the input, input read from the first half of a wider
     buffer (channel offset 0, ld = 2*ca), output written into a wider buffer."""

@@ -28,7 +28,13 @@ def main():
         S = (torch.rand((n, hs, ws, ca), device="cuda") - 0.5).half()
         L = (torch.rand((n, 2 * hs, 2 * ws, cb), device="cuda") - 0.5).half()
         dW = torch.zeros(ca * 16 * cb, device="cuda")
-        call = lambda: B.check(lib.gi_wgrad_s2(ctx, B.GI_F16, B.ptr(S), B.ptr(L), B.ptr(dW), n, hs, ws, ca, ca, cb, cb, 0, 1.0))  # noqa: E731
+        if os.environ.get("WGRAD_SCRATCH", "1") == "1":
+            nb = lib.gi_wgrad_s2_scratch_bytes(B.GI_F16, n, hs, ws, ca, cb)
+            scr = torch.empty(max(nb // 4, 4), dtype=torch.float32, device="cuda")
+            call = lambda: B.check(lib.gi_wgrad_s2_ws(ctx, B.GI_F16, B.ptr(S), B.ptr(L), B.ptr(dW), n, hs, ws, ca, ca, cb, cb, 0, 1.0,  # noqa: E731
+                                                      B.ptr(scr), nb))
+        else:
+            call = lambda: B.check(lib.gi_wgrad_s2(ctx, B.GI_F16, B.ptr(S), B.ptr(L), B.ptr(dW), n, hs, ws, ca, ca, cb, cb, 0, 1.0))  # noqa: E731
         for _ in range(3):
             call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
