@@ -31,6 +31,7 @@ struct KP {
   int cin, ldin, coffin;
   int cout, ldout, coffout;
   int Ktot, nk, splitk, kt_per_split;
+  int64_t ws_stride;   // > 0: split ks stores its partial sums at ws + ks * ws_stride (plain stores); 0: atomics into one buffer
   int relu_in, act_out;
   int Hin, Win, Hout, Wout;
   int64_t in_elems;
@@ -302,8 +303,14 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
         const int m = m0 + elem_row(mt, r);
         if (m < p.M) {
           const int64_t o = (int64_t)out_pixel(m) * p.cout + n0;
+          if (p.ws_stride > 0) {
+            float* dst = p.ws + (int64_t)ks * p.ws_stride + o;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) atomicAdd(p.ws + o + elem_col(nt), acc[mt][nt][r]);
+            for (int nt = 0; nt < NT; ++nt) dst[elem_col(nt)] = acc[mt][nt][r];
+          } else {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) atomicAdd(p.ws + o + elem_col(nt), acc[mt][nt][r]);
+          }
         }
       }
     return;
@@ -366,7 +373,8 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
 template <typename T>
 __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, const float* bias, char* out,
                                                             float* partials, int64_t pixels, int cout,
-                                                            int ldout, int coffout, int act, int rows_per_block) {
+                                                            int ldout, int coffout, int act, int rows_per_block,
+                                                            int nsplit, int64_t ws_stride) {
   __shared__ float red[2 * 256 * 4];
   const int Q = cout / 4;            // column quads
   const int RL = 256 / Q;            // row lanes (cout <= 1024)
@@ -379,6 +387,7 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, con
   if (rl < RL) {
     for (int64_t r = r0 + rl; r < r1; r += RL) {
       f4_t v = *(const f4_t*)(ws + r * cout + q * 4) + b;
+      for (int k = 1; k < nsplit; ++k) v += *(const f4_t*)(ws + (int64_t)k * ws_stride + r * cout + q * 4);   // fixed order
       s += v;
       sq += v * v;
       T o[4];
@@ -467,8 +476,12 @@ int run(hipStream_t st, IgemmArgs& a) {
   kp.kt_per_split = (kp.nk + splitk - 1) / splitk;
   splitk = (kp.nk + kp.kt_per_split - 1) / kp.kt_per_split;
   kp.splitk = splitk;
+  kp.ws_stride = 0;
   if (splitk > 1) {
-    GI_HIP(hipMemsetAsync(a.ws, 0, out_pixels * a.cout * 4, st));
+    // scratch for one buffer per split: plain stores + a summing finish pass (deterministic, no memset);
+    // otherwise fp32 atomics into a single zeroed buffer
+    if (a.ws_bytes >= (int64_t)splitk * out_pixels * a.cout * 4) kp.ws_stride = out_pixels * a.cout;
+    else GI_HIP(hipMemsetAsync(a.ws, 0, out_pixels * a.cout * 4, st));
     kp.partials = nullptr;
   }
   dim3 grid(mt, nt, phases * splitk);
@@ -483,7 +496,7 @@ int run(hipStream_t st, IgemmArgs& a) {
     const int blocks = (int)((out_pixels + rpb - 1) / rpb);
     GI_REQUIRE(a.cout <= 1024, "igemm split-K finish: cout=%d > 1024", a.cout);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, st, a.ws, a.bias, (char*)a.out,
-                       a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb);
+                       a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb, kp.ws_stride > 0 ? splitk : 1, kp.ws_stride);
     GI_LAUNCH_CHECK();
     a.ntiles_out = blocks;
   }

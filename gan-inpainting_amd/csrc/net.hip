@@ -233,6 +233,8 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
   net->oSums = A.take(2 * maxc * 4);
+  // split-K scratch: one fp32 buffer per split (split x output ~ 384 tiles of 128 x 128) for the deterministic path
+  if (maxSplit > 0) maxSplit = max64(maxSplit, (int64_t)400 * 128 * 128 * 4);
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit);
   for (int k = 2; k <= nd; ++k) {
@@ -319,6 +321,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
   net->oSums = A.take(2 * 512 * 4);
+  if (maxSplit > 0) maxSplit = max64(maxSplit, (int64_t)400 * 128 * 128 * 4);
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
   for (int i = 2; i <= 4; ++i)
