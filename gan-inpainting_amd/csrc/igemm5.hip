@@ -1,7 +1,9 @@
 // fp16 implicit GEMMs of the 4x4 / stride-2 / pad-1 family with an LDS-RESIDENT INPUT HALO (gfx950), same contract
 // as igemm3_kernel: MODE 1 = sub-pixel phases (ConvTranspose2d forward / Conv2d input gradient), MODE 0 = the
 // stride-2 gather (Conv2d forward / ConvTranspose2d input gradient), MODE 2 = Conv2d 3x3 / stride 1 / pad 1 (VGG
-// features: a (TH+2) x (TW+2) halo serves nine taps).
+// features: a (TH+2) x (TW+2) halo serves nine taps), MODE 3 = MODE 1 for layers with 64 output channels per
+// N tile: BOTH px phases of a patch in one workgroup (the 128 columns are px 0 | px 1 of 64 channels, one halo of
+// TW+2 columns feeds both), so that those layers run on 64 x 64 wave tiles too.
 //
 // igemm3 gathers the A operand tap by tap: every input row is fetched once per tap (4x in this mode), and the
 // hardware counters / ablations show the kernel bound by LDS-DMA issue, i.e. by loaded bytes per MAC
@@ -71,9 +73,13 @@ __device__ __forceinline__ void wait_vm(int n) {   // n is wave-uniform
 
 template <int MODE, int BN>
 __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
+  constexpr bool DUAL = MODE == 3;                      // both px phases in this workgroup (BN = 2 x 64)
+  constexpr bool PH = MODE == 1 || MODE == 3;           // sub-pixel-phase algebra
   constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups per channel chunk
   constexpr int NTAP = MODE == 2 ? 9 : 4;               // taps (steps) per halo group
-  constexpr int PAD = MODE == 2 ? 2 : 1;                // halo = (TH + PAD) x (TW + PAD)
+  constexpr int PAD = MODE == 2 ? 2 : 1;                // halo = (TH + PAD) x (TW + PADX)
+  constexpr int PADX = DUAL ? 2 : PAD;
+  static_assert(!DUAL || BN == 128, "dual-px mode: 2 x 64 columns");
   constexpr int BM = 256, BK = 64, NW = 8;
   constexpr int AJ = MODE == 2 ? 6 : 5;                 // halo pieces (8 rows x 128 B) per wave and group
   constexpr int A_ROWS = AJ * 64, A_BYTES = A_ROWS * 128;   // 40 / 48 KiB per buffer
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- XCD-aware tile order (as igemm3): the (N tile, phase) blocks of one patch run back to back on one XCD
-  const int nyz = p.ntiles * (MODE == 1 ? 4 : 1);
+  const int nyz = p.ntiles * (DUAL ? 2 : (PH ? 4 : 1));
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
   const int mt_idx = (local / nyz) * 8 + xcd;
@@ -96,13 +102,14 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   const int yz = local % nyz;
   const int nt_idx = yz % p.ntiles;
   const int ph = yz / p.ntiles;
-  const int py = ph >> 1, px = ph & 1;
-  const int n0 = nt_idx * BN;
+  const int py = DUAL ? ph : (ph >> 1), px = DUAL ? 0 : (ph & 1);   // DUAL: px = wn, per wave
+  const int n0 = nt_idx * (DUAL ? 64 : BN);
   const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
   const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
-  const int HC = p.TW + PAD, HR = p.TH + PAD;
-  const char* wptr = p.w + (MODE == 1 ? (int64_t)ph * p.cout * (4 * p.cin) * 2 : 0);
-  const int Ktot2 = (MODE == 1 ? 4 : (MODE == 2 ? 9 : 16)) * p.cin * 2;   // bytes per weight row
+  const int HC = p.TW + PADX, HR = p.TH + PAD;
+  const int Ktot2 = (PH ? 4 : (MODE == 2 ? 9 : 16)) * p.cin * 2;   // bytes per weight row
+  const int64_t phase_bytes = (int64_t)p.cout * Ktot2;             // one sub-pixel phase of the packed weights
+  const char* wptr = p.w + (MODE == 1 ? ph * phase_bytes : (DUAL ? (py * 2) * phase_bytes : 0));
   const int Win = 2 * p.Ws, Hin = 2 * p.Hs;             // MODE 0: the large (input) grid
 
   // ---- per-lane DMA sources: halo rows (fixed for the whole K loop) and weight rows ------------------------
@@ -116,7 +123,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     const int hr = r / HC, hc = r - hr * HC;
     amask[j] = 0;
     if constexpr (MODE != 0) {
-      const int iy = y0 + (MODE == 1 ? py : 0) - 1 + hr, ix = x0 + (MODE == 1 ? px : 0) - 1 + hc;
+      const int iy = y0 + (PH ? py : 0) - 1 + hr, ix = x0 + (MODE == 1 ? px : 0) - 1 + hc;   // DUAL: columns x0-1 .. x0+TW
       const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
       pa[j] = ok ? p.in + ((int64_t)((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16 : p.zero + lchunk * 16;
     } else {
@@ -132,7 +139,11 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   }
   const char* pb[BJ];
 #pragma unroll
-  for (int j = 0; j < BJ; ++j) pb[j] = wptr + (int64_t)(n0 + (wave * BJ + j) * 8 + lrow) * Ktot2 + lchunk * 16;
+  for (int j = 0; j < BJ; ++j) {
+    const int rb = (wave * BJ + j) * 8 + lrow;                     // row of the B tile
+    if constexpr (DUAL) pb[j] = wptr + (rb >> 6) * phase_bytes + (int64_t)(n0 + (rb & 63)) * Ktot2 + lchunk * 16;   // rows 64.. = px 1
+    else pb[j] = wptr + (int64_t)(n0 + rb) * Ktot2 + lchunk * 16;
+  }
 
   // halo piece J of group g = chunk * NQ + q into A buffer `buf`
   auto issue_a = [&](int g, int buf, auto J) {
@@ -173,6 +184,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
       const int R = MODE == 1 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1))
+                  : MODE == 3 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + wn + 1 - (tap & 1))
                   : MODE == 0 ? (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1))
                               : (ty_l + tap / 3) * HC + (tx_l + tap % 3);
       rdA[mt][tap] = R * 128 + ((lq ^ (R & 7)) << 4);
@@ -271,7 +283,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   // ---- epilogue (contract of igemm3) --------------------------------------------------------------------------
   auto out_pixel = [&](int m) -> int {
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
-    if constexpr (MODE == 1) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;
+    if constexpr (PH) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;   // DUAL: + 1 for px 1, by the caller
     else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;   // MODE 0 / 2: the tile's own pixels
   };
   constexpr int SLD = BN + 8;
@@ -279,11 +291,11 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int ch = wn * WN + nt * 16 + 4 * lq;
+    const int ch = wn * WN + nt * 16 + 4 * lq;           // column of the tile (DUAL: px * 64 + channel)
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
     }
     float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -315,15 +327,17 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
-    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * (MODE == 1 ? ph : 0);
-    p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
-    p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+    const int phr = MODE == 1 ? ph : (DUAL ? py * 2 + (tid >> 6) : 0);       // sub-pixel phase of this column
+    const int col = DUAL ? (tid & 63) : tid;
+    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * phr;
+    p.partials[(trow * 2 + 0) * p.cout + n0 + col] = s;
+    p.partials[(trow * 2 + 1) * p.cout + n0 + col] = q;
   }
   constexpr int CPRO = BN / 8;
   const int oc = tid % CPRO;
 #pragma unroll 1
   for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
-    const int64_t o = (int64_t)out_pixel(r) * p.ldout + p.coffout + n0 + oc * 8;
+    const int64_t o = (int64_t)(out_pixel(r) + (DUAL ? (oc >> 3) : 0)) * p.ldout + p.coffout + n0 + (DUAL ? (oc & 7) : oc) * 8;
     *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
   }
 }
@@ -338,8 +352,9 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   if (!gi_is_pow2(a.Ws) || a.Ws < 8) return GI_ERR_UNSUPPORTED;
   const int TW = a.Ws < 32 ? a.Ws : 32, TH = 256 / TW;
   if (a.Hs % TH != 0) return GI_ERR_UNSUPPORTED;
-  if (mode == 2 ? (TH + 2) * (TW + 2) > 384 : (TH + 1) * (TW + 1) > 320) return GI_ERR_UNSUPPORTED;
+  if (mode == 2 ? (TH + 2) * (TW + 2) > 384 : (TH + 1) * (TW + ((mode == 1 && a.cout % 128 != 0) ? 2 : 1)) > 320) return GI_ERR_UNSUPPORTED;
   const int BN = (a.cout % 128 == 0) ? 128 : 64;
+  const bool dual = mode == 1 && BN == 64;     // 64-channel N tiles: both px phases per workgroup (MODE 3)
   const int nph = mode == 1 ? 4 : 1;
   const int tiles_x = a.Ws / TW, tiles_per_img = tiles_x * (a.Hs / TH);
   const int mtiles = a.n * tiles_per_img;
@@ -361,13 +376,22 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
   kp.ntiles = a.cout / BN;
-  const int nyz = kp.ntiles * nph;
+  const int nyz = kp.ntiles * (dual ? 2 : nph);
   const int grid = ((mtiles + 7) / 8) * 8 * nyz;
-  const int ring = 2 * (mode == 2 ? 384 : 320) * 128 + 3 * BN * 128, epi = 256 * (BN + 8) * 2 + 4 * BN * 8;
+  const int BNk = dual ? 128 : BN;             // columns of the workgroup tile
+  const int ring = 2 * (mode == 2 ? 384 : 320) * 128 + 3 * BNk * 128, epi = 256 * (BNk + 8) * 2 + 4 * BNk * 8;
   const int LDS = ring > epi ? ring : epi;
   static bool attr[6] = {false, false, false, false, false, false};
   const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
                        (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
+  if (dual) {
+    static bool attr_dual = false;
+    if (!attr_dual) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<3, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_dual = true; }
+    hipLaunchKernelGGL((igemm5_kernel<3, 128>), dim3(grid), dim3(512), LDS, st, kp);
+    GI_LAUNCH_CHECK();
+    a.ntiles_out = mtiles * nph;
+    return GI_OK;
+  }
   const int vi = (BN == 64 ? 3 : 0) + mode;
   if (!attr[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[vi] = true; }
   switch (vi) {

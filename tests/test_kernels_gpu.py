@@ -206,6 +206,27 @@ def test_igemm3_exact_integers():
     assert torch.equal(from_nhwc(outT), refT)
 
 
+@pytest.mark.parametrize("shape", [(8, 32, 32, 128, 64), (4, 64, 64, 64, 64), (16, 16, 16, 192, 64), (8, 32, 32, 64, 192)])
+def test_halo_kernels_exact_integers_64_channel_tiles(shape):
+    """ConvTranspose2d forward with 64-channel N tiles: the dual-px mode of the halo-resident kernel (both px
+    sub-pixel phases per workgroup, shared halo of TW+2 columns), ReLU on the input, output written at a channel
+    offset of a wider buffer, BatchNorm partial statistics rows per phase. Exact small integers."""
+    n, H, W, ca, cb = shape
+    g = torch.Generator().manual_seed(21)
+    xs = torch.randint(-2, 3, (n, ca, H, W), generator=g).float()
+    wt = torch.randint(-1, 2, (ca, cb, 4, 4), generator=g).float()
+    refT = F.conv_transpose2d(F.relu(xs), wt, None, stride=2, padding=1)
+    _, phase = pack(wt, B.GI_F16)
+    xsd = nhwc_dev(xs, B.GI_F16)
+    out = torch.full((n, 2 * H, 2 * W, cb + 64), 7.0, dtype=torch.float16, device="cuda")
+    # gi_convT_s2_forward writes at channel offset 0 of an ld = cb + 64 buffer; the tail must stay untouched
+    B.check(B.lib().gi_convT_s2_forward(B.get_ctx(), B.GI_F16, B.ptr(xsd), B.ptr(phase), B.ptr(out), n, H, W, ca, ca, cb, cb + 64, 1, 0,
+                                        None, 0))
+    torch.cuda.synchronize()
+    assert torch.equal(from_nhwc(out[..., :cb].contiguous()), refT)
+    assert float((out[..., cb:] - 7.0).abs().max()) == 0.0
+
+
 def test_mfma_layout_exact_integers():
     """Asymmetric small-integer data: every product and sum is exact in fp16/fp32, so any fragment
     or C-layout mix-up shows as a non-zero error (cdna guide: 'A=I-check with asymmetric B')."""
