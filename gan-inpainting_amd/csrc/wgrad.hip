@@ -301,13 +301,24 @@ int run(hipStream_t st, const WgradArgs& a) {
 
 }  // namespace
 
+int op_wgrad2(hipStream_t st, const WgradArgs& a);                        // wgrad2.hip: LDS-DMA ring + shared halo (fp16)
+int64_t op_wgrad2_scratch_bytes(int n, int Hs, int Ws, int ca, int cb);
+
 int64_t op_wgrad_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb) {
   if (ca % 128 != 0 || (16 * cb) % 128 != 0) return 0;
   const int split = wgrad_split(dtype, n, Hs, Ws, ca, cb, nullptr);
-  return split > 1 ? (int64_t)split * ca * 16 * cb * 4 : 0;
+  int64_t b = split > 1 ? (int64_t)split * ca * 16 * cb * 4 : 0;
+  if (dtype == GI_F16) { const int64_t b2 = op_wgrad2_scratch_bytes(n, Hs, Ws, ca, cb); if (b2 > b) b = b2; }
+  return b;
 }
 
 int op_wgrad(hipStream_t st, int dtype, const WgradArgs& a) {
+  static int use2 = -1;   // GI_WGRAD2=0: always the register-staged kernel of this file (tools: A/B)
+  if (use2 < 0) { const char* e = getenv("GI_WGRAD2"); use2 = e ? atoi(e) : 1; }
+  if (dtype == GI_F16 && use2) {
+    const int rc = op_wgrad2(st, a);
+    if (rc != GI_ERR_UNSUPPORTED) return rc;
+  }
   if (dtype == GI_F16) return run<half_t>(st, a);
   if (dtype == GI_F32) return run<float>(st, a);
   gi_set_error("wgrad: bad dtype %d", dtype);

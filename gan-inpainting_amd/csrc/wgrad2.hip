@@ -1,0 +1,279 @@
+// Weight-gradient GEMM of the 4x4 / stride-2 / pad-1 family, second generation (gfx950, fp16):
+//
+//   dW[a][ky][kx][b] += scale * sum_{n,y,x} S[n,y,x,a] * L[n,2y-1+ky,2x-1+kx,b]
+//
+// wgrad.hip gathers the L operand tap by tap through registers (32 KiB of loads per 128x128x64 MAC step). Here a
+// workgroup owns 128 S channels x 64 L channels x the FOUR kx taps of one ky (a 128 x 256 tile of dW, 8 waves =
+// 2 a-halves x 4 taps, 64 x 64 each). The K loop walks pixel tiles of 4 rows x 16 pixels of the small grid; per
+// tile the S pixels (64 x 128 channels) and ONE halo of the large tensor - for every tile row the 34 pixels
+// 2*x0-1 .. 2*x0+32 of row 2y-1+ky - arrive by LDS-DMA (three-stage ring, 5 pieces per wave) and all four taps
+// read it with a stride of two rows: tap kx of pixel (ry,rx) is halo row ry*34 + 2*rx + kx. 33 KiB of loads per
+// 128x256x64 MAC step, i.e. half of wgrad.hip per MAC, no register staging, no ds_write.
+// Both operands are pixel-major (K-major): fragments come from ds_read_b64_tr_b16. LDS rows are 128 B with the
+// 16-byte chunk c of row r at physical chunk c ^ (r & 7) (applied to the DMA source addresses): the four rows of
+// a transposing read (consecutive for S, stride 2 for the halo) then touch eight distinct chunks.
+// Pixel ranges are split over workgroups as in wgrad.hip: partial tiles to scratch + fixed-order reduction, or
+// direct / atomic accumulation.
+#include <stdlib.h>
+
+#include "common.h"
+
+const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
+
+namespace {
+
+struct WP2 {
+  const char* S;
+  const char* L;
+  const char* zero;
+  float* dW;
+  float* part;        // non-null: split ks writes part[ks][ca][16*cb]
+  int direct;         // single split: dW += acc without atomics
+  int n, Hs, Ws, lgWs, lgHs;
+  int ca, ldS, coffS;
+  int cb, ldL, coffL;
+  int relu_S;
+  float scale;
+  int ntile;          // pixel tiles = n * (Hs/4) * (Ws/16)
+  int tiles_per_split;
+};
+
+__device__ __forceinline__ void glds16w(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ h8_t tr16x2(const char* lo_p, const char* hi_p) {
+  fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)lo_p);
+  fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)hi_p);
+  h4_t l4 = __builtin_bit_cast(h4_t, lo), h4 = __builtin_bit_cast(h4_t, hi);
+  return h8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+__device__ __forceinline__ h8_t relu8(h8_t v) {
+  typedef short s8_t __attribute__((ext_vector_type(8)));
+  s8_t h = __builtin_bit_cast(s8_t, v);
+  const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  h = __builtin_elementwise_max(h, z);
+  return __builtin_bit_cast(h8_t, h);
+}
+
+// grid.x = (ca/128) * (cb/64) * 4 (ky) ; grid.y = splits
+__global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
+  constexpr int S_BYTES = 2 * 64 * 128;      // two 64-channel segments x 64 pixels x 128 B
+  constexpr int L_ROWS = 192, L_BYTES = L_ROWS * 128;   // 4 x 34 = 136 halo rows used, 24 pieces of 8 rows
+  constexpr int STAGE = S_BYTES + L_BYTES;   // 40 KiB
+  constexpr int SJ = 2, LJ = 3;              // pieces per wave and tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wa = wave >> 2, kx = wave & 3;
+
+  const int nbt = p.cb >> 6;
+  int bx = blockIdx.x;
+  const int ky = bx & 3; bx >>= 2;
+  const int b0 = (bx % nbt) * 64, a0 = (bx / nbt) * 128;
+  const int ks = blockIdx.y;
+  const int t0 = ks * p.tiles_per_split, t1 = min(p.ntile, t0 + p.tiles_per_split);
+  const int HL = 2 * p.Hs, WL = 2 * p.Ws;
+  const int txs = p.Ws >> 4, tys = p.Hs >> 2;          // pixel tiles per row / column of an image (powers of two)
+  const int lg_txs = p.lgWs - 4, lg_tys = p.lgHs - 2;
+
+  // ---- per-lane DMA source descriptions ------------------------------------------------------------------
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ (lrow & 7);
+  int64_t s_off[SJ];          // byte offset of this lane's S row relative to the tile's first pixel
+  int64_t l_off[LJ];          // byte offset of this lane's halo row relative to the halo's first pixel
+  int l_hr[LJ], l_hx[LJ];     // halo coordinates (hr >= 4: padding rows of the 192-row buffer)
+#pragma unroll
+  for (int j = 0; j < SJ; ++j) {
+    const int ps = wave * SJ + j;                        // 0..15: segment ps >> 3, pixel rows (ps & 7) * 8 ..
+    const int seg = ps >> 3, k = (ps & 7) * 8 + lrow;
+    const int ry = k >> 4, rx = k & 15;
+    s_off[j] = ((int64_t)(ry * p.Ws + rx) * p.ldS + p.coffS + a0 + seg * 64) * 2 + lchunk * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < LJ; ++j) {
+    const int hrow = (wave * LJ + j) * 8 + lrow;         // 0..191
+    const int hr = hrow / 34, hx = hrow - hr * 34;
+    l_hr[j] = hr; l_hx[j] = hx;
+    l_off[j] = ((int64_t)(2 * hr * WL + hx) * p.ldL + p.coffL + b0) * 2 + lchunk * 16;
+  }
+  auto issue = [&](int t, int stage) {
+    // tile t -> image n, tile row yb, tile column xb (all powers of two)
+    const int xb = t & (txs - 1), yb = (t >> lg_txs) & (tys - 1), nn = t >> (lg_txs + lg_tys);
+    const int y0 = yb * 4, x0 = xb * 16;
+    const char* sbase = p.S + (int64_t)((nn * p.Hs + y0) * p.Ws + x0) * p.ldS * 2;
+    const int Y0 = 2 * y0 - 1 + ky, X0 = 2 * x0 - 1;     // first halo pixel (may lie outside)
+    const char* lbase = p.L + ((int64_t)(nn * HL + Y0) * WL + X0) * p.ldL * 2;
+    char* dst = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) glds16w(sbase + s_off[j], dst + (wave * SJ + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < LJ; ++j) {
+      const int Y = Y0 + 2 * l_hr[j], X = X0 + l_hx[j];
+      const bool ok = l_hr[j] < 4 && Y >= 0 && Y < HL && X >= 0 && X < WL;
+      glds16w(ok ? lbase + l_off[j] : p.zero + lchunk * 16, dst + S_BYTES + (wave * LJ + j) * 1024);
+    }
+  };
+
+  // ---- fragment read offsets (per lane, tile independent) -------------------------------------------------
+  // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(channel) block; lane 4q+pp supplies the address of block row
+  // q, channels 4pp..4pp+3. lo / hi = k rows 8g+q / 8g+4+q of the 32-pixel k-step.
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
+  int aoff[2][2][4];   // [kstep][lo/hi][mt] byte offsets into the S part of a stage
+  int boff[2][2][4];   // [kstep][lo/hi][nt] byte offsets into the L part
+#pragma unroll
+  for (int ksx = 0; ksx < 2; ++ksx)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int k = ksx * 32 + 8 * g + 4 * h + q;        // pixel of the tile
+      const int srow = wa * 64 + k;                      // S row: segment wa (channels wa*64 ..), pixel k
+      const int ry = k >> 4, rx = k & 15;
+      const int lrw = ry * 34 + 2 * rx + kx;             // halo row of tap kx
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int chunk = t * 2 + (pp >> 1);             // 16 channels of tile t start at byte t*32; this lane's 4 at + pp*8
+        aoff[ksx][h][t] = srow * 128 + ((chunk ^ (srow & 7)) << 4) + (pp & 1) * 8;
+        boff[ksx][h][t] = S_BYTES + lrw * 128 + ((chunk ^ (lrw & 7)) << 4) + (pp & 1) * 8;
+      }
+    }
+
+  f4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nt_tiles = t1 - t0;
+  if (nt_tiles > 0) {
+    issue(t0, 0);
+    if (nt_tiles > 1) issue(t0 + 1, 1);
+    int stage = 0;
+    for (int i = 0; i < nt_tiles; ++i) {
+      if (i + 1 < nt_tiles) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const char* sb = smem + stage * STAGE;
+      int st2 = stage + 2;
+      if (st2 >= 3) st2 -= 3;
+      const bool more = i + 2 < nt_tiles;
+#pragma unroll
+      for (int ksx = 0; ksx < 2; ++ksx) {
+        h8_t af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          af[t] = tr16x2(sb + aoff[ksx][0][t], sb + aoff[ksx][1][t]);
+          bf[t] = tr16x2(sb + boff[ksx][0][t], sb + boff[ksx][1][t]);
+        }
+        if (p.relu_S) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) af[t] = relu8(af[t]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        if (ksx == 0 && more) issue(t0 + i + 2, st2);    // the next-but-one tile streams in behind the first k-step
+      }
+      ++stage;
+      if (stage == 3) stage = 0;
+    }
+  }
+
+  // ---- epilogue: acc[mt][nt][r] = dW[a0 + wa*64 + mt*16 + (lane>>4)*4 + r][(ky*4+kx)*cb + b0 + nt*16 + (lane&15)]
+  const int64_t ldw = (int64_t)16 * p.cb;
+  const int colb = (ky * 4 + kx) * p.cb + b0 + (lane & 15);
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = a0 + wa * 64 + mt * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int64_t o = (int64_t)row * ldw + colb + nt * 16;
+        const float v = acc[mt][nt][r] * p.scale;
+        if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
+        else if (p.direct) p.dW[o] += v;
+        else atomicAdd(p.dW + o, v);
+      }
+    }
+}
+
+// dW[i] += sum_k part[k][i] in a fixed order (as in wgrad.hip)
+__global__ void __launch_bounds__(256) wgrad2_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int64_t count4, int split) {
+  __shared__ f4_t red[3][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + tx;
+  const int per = (split + 3) / 4, k0 = ty * per, k1 = min(split, k0 + per);
+  f4_t s = f4_t{0.f, 0.f, 0.f, 0.f};
+  if (i < count4)
+    for (int k = k0; k < k1; ++k) s += *(const f4_t*)(part + ((int64_t)k * count4 + i) * 4);
+  if (ty > 0) red[ty - 1][tx] = s;
+  __syncthreads();
+  if (ty == 0 && i < count4) {
+    s += red[0][tx];
+    s += red[1][tx];
+    s += red[2][tx];
+    f4_t d = *(f4_t*)(dW + i * 4);
+    d += s;
+    *(f4_t*)(dW + i * 4) = d;
+  }
+}
+
+int wgrad2_split(int n, int Hs, int Ws, int ca, int cb, int* tiles_per_split) {
+  const int ntile = n * (Hs / 4) * (Ws / 16);
+  const int blocks = (ca / 128) * (cb / 64) * 4;
+  int split = (256 + blocks - 1) / blocks;             // one 8-wave workgroup per CU
+  if (split > ntile / 8) split = ntile / 8;
+  if (split < 1) split = 1;
+  const int tps = (ntile + split - 1) / split;
+  if (tiles_per_split) *tiles_per_split = tps;
+  return (ntile + tps - 1) / tps;
+}
+
+bool wgrad2_ok(int n, int Hs, int Ws, int ca, int cb) {
+  return ca % 128 == 0 && cb % 64 == 0 && gi_is_pow2(Hs) && gi_is_pow2(Ws) && Ws >= 16 && Hs >= 4 && n >= 1;
+}
+
+}  // namespace
+
+int64_t op_wgrad2_scratch_bytes(int n, int Hs, int Ws, int ca, int cb) {
+  if (!wgrad2_ok(n, Hs, Ws, ca, cb)) return 0;
+  const int split = wgrad2_split(n, Hs, Ws, ca, cb, nullptr);
+  return split > 1 ? (int64_t)split * ca * 16 * cb * 4 : 0;
+}
+
+// fp16 only. GI_ERR_UNSUPPORTED: shape not served (the caller uses wgrad.hip).
+int op_wgrad2(hipStream_t st, const WgradArgs& a) {
+  if (!wgrad2_ok(a.n, a.Hs, a.Ws, a.ca, a.cb)) return GI_ERR_UNSUPPORTED;
+  if (a.ldS % 8 != 0 || a.coffS % 8 != 0 || a.ldL % 8 != 0 || a.coffL % 8 != 0) return GI_ERR_UNSUPPORTED;
+  if ((int64_t)a.n * a.Hs * a.Ws * a.ldS >= (1ll << 31) || (int64_t)a.n * 4 * a.Hs * a.Ws * a.ldL >= (1ll << 31)) return GI_ERR_UNSUPPORTED;
+  int dev = 0;
+  GI_HIP(hipGetDevice(&dev));
+  const char* zero = gi_igemm3_zero_page(dev);
+  if (!zero) return GI_ERR_HIP;
+  WP2 p;
+  p.S = (const char*)a.S; p.L = (const char*)a.L; p.zero = zero; p.dW = a.dW;
+  p.n = a.n; p.Hs = a.Hs; p.Ws = a.Ws; p.lgWs = gi_ilog2(a.Ws); p.lgHs = gi_ilog2(a.Hs);
+  p.ca = a.ca; p.ldS = a.ldS; p.coffS = a.coffS; p.cb = a.cb; p.ldL = a.ldL; p.coffL = a.coffL;
+  p.relu_S = a.relu_S; p.scale = a.scale;
+  p.ntile = a.n * (a.Hs / 4) * (a.Ws / 16);
+  const int split = wgrad2_split(a.n, a.Hs, a.Ws, a.ca, a.cb, &p.tiles_per_split);
+  const int64_t out_floats = (int64_t)a.ca * 16 * a.cb;
+  p.part = nullptr;
+  p.direct = split == 1 ? 1 : 0;
+  if (split > 1 && a.scratch && a.scratch_bytes >= (int64_t)split * out_floats * 4) p.part = a.scratch;
+  constexpr int LDS = 3 * (2 * 64 * 128 + 192 * 128);
+  static bool attr = false;
+  if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
+  const dim3 grid((a.ca / 128) * (a.cb / 64) * 4, split);
+  hipLaunchKernelGGL(wgrad2_kernel, grid, dim3(512), LDS, st, p);
+  GI_LAUNCH_CHECK();
+  if (p.part) {
+    const int64_t c4 = out_floats / 4;
+    hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)((c4 + 63) / 64)), dim3(256), 0, st, (const float*)p.part, a.dW, c4, split);
+    GI_LAUNCH_CHECK();
+  }
+  return GI_OK;
+}
