@@ -98,22 +98,33 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
     l_hr[j] = hr; l_hx[j] = hx;
     l_off[j] = ((int64_t)(2 * hr * WL + hx) * p.ldL + p.coffL + b0) * 2 + lchunk * 16;
   }
-  auto issue = [&](int t, int stage) {
+  // LDS-DMA pieces of pixel tile t into ring stage `stage`: pieces 0..SJ-1 = S rows, SJ..SJ+LJ-1 = halo rows
+  const char* sbase = nullptr;
+  const char* lbase = nullptr;
+  int Y0 = 0, X0 = 0;
+  auto tile_bases = [&](int t) {
     // tile t -> image n, tile row yb, tile column xb (all powers of two)
     const int xb = t & (txs - 1), yb = (t >> lg_txs) & (tys - 1), nn = t >> (lg_txs + lg_tys);
     const int y0 = yb * 4, x0 = xb * 16;
-    const char* sbase = p.S + (int64_t)((nn * p.Hs + y0) * p.Ws + x0) * p.ldS * 2;
-    const int Y0 = 2 * y0 - 1 + ky, X0 = 2 * x0 - 1;     // first halo pixel (may lie outside)
-    const char* lbase = p.L + ((int64_t)(nn * HL + Y0) * WL + X0) * p.ldL * 2;
+    sbase = p.S + (int64_t)((nn * p.Hs + y0) * p.Ws + x0) * p.ldS * 2;
+    Y0 = 2 * y0 - 1 + ky; X0 = 2 * x0 - 1;               // first halo pixel (may lie outside)
+    lbase = p.L + ((int64_t)(nn * HL + Y0) * WL + X0) * p.ldL * 2;
+  };
+  auto issue_piece = [&](int stage, auto PIECE) {        // after tile_bases(t)
+    constexpr int j = decltype(PIECE)::value;
     char* dst = smem + stage * STAGE;
-#pragma unroll
-    for (int j = 0; j < SJ; ++j) glds16w(sbase + s_off[j], dst + (wave * SJ + j) * 1024);
-#pragma unroll
-    for (int j = 0; j < LJ; ++j) {
-      const int Y = Y0 + 2 * l_hr[j], X = X0 + l_hx[j];
-      const bool ok = l_hr[j] < 4 && Y >= 0 && Y < HL && X >= 0 && X < WL;
-      glds16w(ok ? lbase + l_off[j] : p.zero + lchunk * 16, dst + S_BYTES + (wave * LJ + j) * 1024);
+    if constexpr (j < SJ) {
+      glds16w(sbase + s_off[j], dst + (wave * SJ + j) * 1024);
+    } else {
+      constexpr int jl = j - SJ;
+      const int Y = Y0 + 2 * l_hr[jl], X = X0 + l_hx[jl];
+      const bool ok = l_hr[jl] < 4 && Y >= 0 && Y < HL && X >= 0 && X < WL;
+      glds16w(ok ? lbase + l_off[jl] : p.zero + lchunk * 16, dst + S_BYTES + (wave * LJ + jl) * 1024);
     }
+  };
+  auto issue = [&](int t, int stage) {
+    tile_bases(t);
+    static_for<SJ + LJ>([&](auto J) { issue_piece(stage, J); });
   };
 
   // ---- fragment read offsets (per lane, tile independent) -------------------------------------------------
@@ -158,6 +169,7 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
       int st2 = stage + 2;
       if (st2 >= 3) st2 -= 3;
       const bool more = i + 2 < nt_tiles;
+      if (more) tile_bases(t0 + i + 2);
 #pragma unroll
       for (int ksx = 0; ksx < 2; ++ksx) {
         h8_t af[4], bf[4];
@@ -173,8 +185,17 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-        if (ksx == 0 && more) issue(t0 + i + 2, st2);    // the next-but-one tile streams in behind the first k-step
+          for (int nt = 0; nt < 4; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+            // the five pieces of the next-but-one tile, one every six MFMAs
+            const int idx = ksx * 16 + mt * 4 + nt;
+            if (more) {
+              static_for<SJ + LJ>([&](auto Q) {
+                constexpr int qq = decltype(Q)::value;
+                if (idx == 3 + 6 * qq) issue_piece(st2, Q);
+              });
+            }
+          }
       }
       ++stage;
       if (stage == 3) stage = 0;
