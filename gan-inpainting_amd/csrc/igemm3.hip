@@ -380,10 +380,14 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   }
   const int M = a.n * a.Hs * a.Ws;
   const int nph = mode == 1 ? 4 : 1;
-  const int BN = (a.cout % 128 == 0) ? 128 : 64;
+  int BN = (a.cout % 128 == 0) ? 128 : 64;
   if (mode != 2) {   // too few tiles to fill 256 CUs: the split-K path of igemm.hip serves those layers
     const int tiles = ((M + 255) / 256) * (a.cout / BN) * nph;
     if (tiles < 128) return GI_ERR_UNSUPPORTED;
+    // 128..255 tiles leave CUs idle (one 8-wave workgroup per CU): 64-wide N tiles double the workgroups
+    static int narrow = -1;   // GI_IGEMM3_NARROW=0 keeps 128-wide tiles (tools: A/B)
+    if (narrow < 0) { const char* e = getenv("GI_IGEMM3_NARROW"); narrow = e ? atoi(e) : 1; }
+    if (narrow && BN == 128 && tiles < 256) BN = 64;
   }
   int dev = 0;
   GI_HIP(hipGetDevice(&dev));
