@@ -72,6 +72,19 @@ class GradSync:
     def grad_scale(self):
         return 1.0 / self.world
 
+    def broadcast_parameters(self, nets, src=0):
+        """Make every replica start from rank `src`'s weights (and BatchNorm running statistics)."""
+        if self.world == 1:
+            return
+        for net in nets:
+            flat = getattr(net, "flat_params", None)
+            tensors = [flat()] if flat is not None else [p.data for p in net.parameters()]
+            tensors += [b for b in getattr(net, "buffers", lambda: [])() if torch.is_tensor(b) and b.is_floating_point()]
+            for t in tensors:
+                dist.broadcast(t, src, group=self.group)
+            if hasattr(net, "mark_dirty"):
+                net.mark_dirty()
+
 
 def local_device():
     """CUDA device index of this rank: LOCAL_RANK, folded onto the visible devices."""

@@ -91,6 +91,8 @@ class _StepBase:
             # inside a step object parameters only change through the package's optimizers / clamp, which
             # mark the network dirty: re-derive packed weights once per update instead of once per forward
             n.always_sync = False
+        if sync is not None:
+            sync.broadcast_parameters([net_G] + self.Ds)    # replicas start identical whatever the ranks' RNG state
 
     def _bind_optimizers(self, *opts):
         self._opts = opts

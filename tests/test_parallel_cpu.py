@@ -39,6 +39,15 @@ def _worker(rank, world, port, q):
     expect = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
     ok = bool(torch.equal(flat, expect)) and abs(sync.grad_scale() - 1.0 / world) < 1e-12
     assert len(sync.buckets(0, n)) == 5
+    # replicas start from rank 0's weights and running statistics, whatever each rank's RNG did before
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4))
+    net[1].running_mean.normal_()
+    sync.broadcast_parameters([net])
+    torch.manual_seed(100)
+    want = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4))
+    want[1].running_mean.normal_()
+    ok = ok and all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), want.state_dict().values()))
     q.put((rank, ok))
     dist.destroy_process_group()
 
