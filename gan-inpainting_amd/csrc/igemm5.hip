@@ -353,12 +353,18 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   const int TW = a.Ws < 32 ? a.Ws : 32, TH = 256 / TW;
   if (a.Hs % TH != 0) return GI_ERR_UNSUPPORTED;
   if (mode == 2 ? (TH + 2) * (TW + 2) > 384 : (TH + 1) * (TW + ((mode == 1 && a.cout % 128 != 0) ? 2 : 1)) > 320) return GI_ERR_UNSUPPORTED;
-  const int BN = (a.cout % 128 == 0) ? 128 : 64;
-  const bool dual = mode == 1 && BN == 64;     // 64-channel N tiles: both px phases per workgroup (MODE 3)
+  int BN = (a.cout % 128 == 0) ? 128 : 64;
   const int nph = mode == 1 ? 4 : 1;
   const int tiles_x = a.Ws / TW, tiles_per_img = tiles_x * (a.Hs / TH);
   const int mtiles = a.n * tiles_per_img;
   if (mode != 2 && mtiles * (a.cout / BN) * nph < 128) return GI_ERR_UNSUPPORTED;
+  if (mode == 0 && BN == 128 && mtiles * (a.cout / BN) < 256) {
+    // 128..255 workgroups on 256 CUs (generator d4 at 256x256, bs=32): 64-wide N tiles double them
+    static int narrow = -1;   // GI_IGEMM5_NARROW=0 keeps 128-wide tiles (tools: A/B)
+    if (narrow < 0) { const char* e = getenv("GI_IGEMM5_NARROW"); narrow = e ? atoi(e) : 1; }
+    if (narrow) BN = 64;
+  }
+  const bool dual = mode == 1 && BN == 64;     // 64-channel N tiles: both px phases per workgroup (MODE 3)
   int dev = 0;
   GI_HIP(hipGetDevice(&dev));
   const char* zero = gi_igemm3_zero_page(dev);
