@@ -679,6 +679,215 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const 
   for (int e = 0; e < EPC; ++e) atomicAdd(dw5 + tap * c + cc * EPC + e, s[e]);
 }
 
+// ---- fp16 head at c = 512 (the PatchGAN of networks.py:331-363): one pixel row = 1 KiB = one wave load --------
+// Forward, one workgroup per image: t[px][tap] = a4[px][:] . w5[tap][:] on the MFMA (16 px x 16 taps x 32 channels
+// per instruction; w5 as fp16 fragments resident in registers, fp32 accumulation), so every activation is read once;
+// then h[p] = sum_tap t[p + (ky,kx)][tap], the Linear(P,1) and the optional sigmoid in the same workgroup.
+constexpr int HT_PITCH = 17;   // floats per pixel row of t in LDS (16 taps + 1: conflict-free column reads)
+__global__ void __launch_bounds__(256) head_fwd512_kernel(const char* __restrict__ a4, const float* __restrict__ w5,
+                                                          const float* __restrict__ wl, const float* __restrict__ bl,
+                                                          float* __restrict__ h, float* __restrict__ out, int Hh, int Wh,
+                                                          int sigmoid) {
+  extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] + 4
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nn = blockIdx.x, npx = Hh * Wh;
+  h8_t bf[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const float* src = w5 + (lane & 15) * 512 + ks * 32 + (lane >> 4) * 8;
+    const f4_t lo = *(const f4_t*)src, hi = *(const f4_t*)(src + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bf[ks][e] = (half_t)lo[e]; bf[ks][4 + e] = (half_t)hi[e]; }
+  }
+  const char* img = a4 + (int64_t)nn * npx * 1024;
+  for (int tile = wave; tile * 16 < npx; tile += 4) {
+    const int px = min(tile * 16 + (lane & 15), npx - 1);
+    const char* row = img + (int64_t)px * 1024 + (lane >> 4) * 16;
+    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const h8_t*)(row + ks * 64), bf[ks], acc, 0, 0, 0);
+    // D[row = pixel][col = tap]: lane holds tap (lane&15), pixels 4*(lane>>4) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = tile * 16 + 4 * (lane >> 4) + r;
+      if (q < npx) t_lds[q * HT_PITCH + (lane & 15)] = acc[r];
+    }
+  }
+  __syncthreads();
+  const int Ph = Hh - 3, Pw = Wh - 3, P = Ph * Pw;
+  float part = 0.f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const int py = p / Pw, px = p - py * Pw;
+    float sacc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) sacc += t_lds[((py + (tap >> 2)) * Wh + px + (tap & 3)) * HT_PITCH + tap];
+    h[(int64_t)nn * P + p] = sacc;
+    part = fmaf(sacc, wl[p], part);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  float* red = t_lds + npx * HT_PITCH;
+  if (lane == 0) red[wave] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float z = ((red[0] + red[1]) + (red[2] + red[3])) + bl[0];
+    out[nn] = sigmoid ? 1.f / (1.f + expf(-z)) : z;
+  }
+}
+
+// Backward in ONE launch, three roles by blockIdx (dh[n,p] = dz[n]*wl[p] is never materialised):
+//   [0, nb)        input gradient: da4[n,y,x,:] = loss_scale * sum_tap dh[n,y-ky,x-kx] * w5[tap][:], a lane owns 8
+//                  channels with its 16x8 weights in registers, a wave owns a pixel (one 1-KiB store);
+//   [nb, 2nb)      weight-gradient partial of the same pixel range: acc[tap][8ch] += dh[..] * a4[n,y,x,8ch], reduced over
+//                  the 4 waves in LDS and stored to part[block][16][512] (summed in fixed order by head_wsum512_kernel);
+//   last block     dwl[p] += sum_n dz[n]*h[n,p], dbl += sum_n dz[n].
+// Without parameter gradients (frozen critic) only the first nb blocks are launched.
+__global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restrict__ dy, const float* __restrict__ outv,
+                                                          const float* __restrict__ hsave, const float* __restrict__ wl,
+                                                          const float* __restrict__ w5, const char* __restrict__ a4,
+                                                          char* __restrict__ da4, float* __restrict__ part,
+                                                          float* __restrict__ dwl, float* __restrict__ dbl, int n, int Hh,
+                                                          int Wh, int bands, int sigmoid, float loss_scale) {
+  __shared__ float red[2 * 16 * 512];   // 64 KiB: two waves' accumulators at a time
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Ph = Hh - 3, Pw = Wh - 3, P = Ph * Pw, npx = Hh * Wh;
+  const int nb = n * bands;
+  int b = blockIdx.x;
+  if (b >= 2 * nb) {   // Linear(P,1) parameter gradients
+    for (int p = threadIdx.x; p < P; p += 256) {
+      float gw = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const float o = outv[i];
+        gw = fmaf(dy[i] * (sigmoid ? o * (1.f - o) : 1.f), hsave[(int64_t)i * P + p], gw);
+      }
+      dwl[p] += gw;
+    }
+    if (threadIdx.x == 0 && dbl) {
+      float gb = 0.f;
+      for (int i = 0; i < n; ++i) {
+        const float o = outv[i];
+        gb += dy[i] * (sigmoid ? o * (1.f - o) : 1.f);
+      }
+      dbl[0] += gb;
+    }
+    return;
+  }
+  const bool wgrad = b >= nb;
+  if (wgrad) b -= nb;
+  const int nn = b / bands, band = b - nn * bands;
+  const int ppb = (npx + bands - 1) / bands;               // pixels per block
+  const int q0 = band * ppb, q1 = min(npx, q0 + ppb);
+  const float o = outv[nn];
+  const float dz = dy[nn] * (sigmoid ? o * (1.f - o) : 1.f);
+  if (!wgrad) {
+    float w[16][8];
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const f4_t lo = *(const f4_t*)(w5 + tap * 512 + lane * 8), hi = *(const f4_t*)(w5 + tap * 512 + lane * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { w[tap][e] = lo[e]; w[tap][4 + e] = hi[e]; }
+    }
+    const float dzs = dz * loss_scale;
+    for (int q = q0 + wave; q < q1; q += 4) {
+      const int y = q / Wh, x = q - y * Wh;
+      float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap) {
+        const int py = y - (tap >> 2), px = x - (tap & 3);
+        if (py < 0 || py >= Ph || px < 0 || px >= Pw) continue;      // wave-uniform
+        const float g = dzs * wl[py * Pw + px];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc[e] = fmaf(g, w[tap][e], sacc[e]);
+      }
+      h8_t v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (half_t)sacc[e];
+      *(h8_t*)(da4 + ((int64_t)nn * npx + q) * 1024 + lane * 16) = v;
+    }
+    return;
+  }
+  float acc[16][8];
+#pragma unroll
+  for (int tap = 0; tap < 16; ++tap)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[tap][e] = 0.f;
+  for (int q = q0 + wave; q < q1; q += 4) {
+    const int y = q / Wh, x = q - y * Wh;
+    const h8_t v = *(const h8_t*)(a4 + ((int64_t)nn * npx + q) * 1024 + lane * 16);
+    float vf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vf[e] = (float)v[e];
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const int py = y - (tap >> 2), px = x - (tap & 3);
+      if (py < 0 || py >= Ph || px < 0 || px >= Pw) continue;        // wave-uniform
+      const float g = dz * wl[py * Pw + px];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[tap][e] = fmaf(g, vf[e], acc[tap][e]);
+    }
+  }
+  // waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the block's partial
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      float* d = red + slot * 8192 + tap * 512 + lane * 8;
+      *(f4_t*)d = f4_t{acc[tap][0], acc[tap][1], acc[tap][2], acc[tap][3]};
+      *(f4_t*)(d + 4) = f4_t{acc[tap][4], acc[tap][5], acc[tap][6], acc[tap][7]};
+    }
+  };
+  auto take = [&](int slot) {
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const float* d = red + slot * 8192 + tap * 512 + lane * 8;
+      const f4_t lo = *(const f4_t*)d, hi = *(const f4_t*)(d + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[tap][e] += lo[e]; acc[tap][4 + e] += hi[e]; }
+    }
+  };
+  if (wave >= 2) put(wave - 2);
+  __syncthreads();
+  if (wave < 2) take(wave);
+  __syncthreads();
+  if (wave == 1) put(0);
+  __syncthreads();
+  if (wave == 0) {
+    take(0);
+    float* dst = part + (int64_t)b * 8192;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      *(f4_t*)(dst + tap * 512 + lane * 8) = f4_t{acc[tap][0], acc[tap][1], acc[tap][2], acc[tap][3]};
+      *(f4_t*)(dst + tap * 512 + lane * 8 + 4) = f4_t{acc[tap][4], acc[tap][5], acc[tap][6], acc[tap][7]};
+    }
+  }
+}
+
+// dw5[i] += sum_b part[b][i], b ascending (deterministic)
+__global__ void __launch_bounds__(256) head_wsum512_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw5) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // < 8192
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= nb; b += 4) {
+    s0 += part[(int64_t)b * 8192 + i];
+    s1 += part[(int64_t)(b + 1) * 8192 + i];
+    s2 += part[(int64_t)(b + 2) * 8192 + i];
+    s3 += part[(int64_t)(b + 3) * 8192 + i];
+  }
+  for (; b < nb; ++b) s0 += part[(int64_t)b * 8192 + i];
+  dw5[i] += (s0 + s1) + (s2 + s3);
+}
+
+// row bands per image for the backward: ~256 workgroups, at least 32 pixels each
+static bool head_fast() {   // GI_HEAD_FAST=0: the generic kernels (tools: A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("GI_HEAD_FAST"); v = e ? atoi(e) : 1; }
+  return v != 0;
+}
+static int head_bands(int n, int npx) {
+  int bands = 1;
+  while (n * bands < 256 && npx / (bands * 2) >= 32) bands *= 2;
+  return bands;
+}
+
 int grid_for(int64_t work_items, int per_block, int cap) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b > cap) b = cap;
@@ -687,6 +896,11 @@ int grid_for(int64_t work_items, int per_block, int cap) {
 }
 
 }  // namespace
+
+int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh) {
+  (void)Hh; (void)Wh;   // n * head_bands(n, .) < 512 while bands > 1, = n otherwise
+  return (int64_t)(max_n > 512 ? max_n : 512) * 8192 * 4;
+}
 
 int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs, int Ws, int c,
                  int ldout, int coffout, int act_out, float in_scale) {
@@ -799,6 +1013,17 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
   const int Ph = a.Hh - 3, Pw = a.Wh - 3;
   GI_REQUIRE(Ph >= 1 && Pw >= 1, "head: feature map %dx%d too small", a.Hh, a.Wh);
   const int blocks = a.n * Ph * Pw;
+  if (dtype == GI_F16 && a.c == 512 && head_fast()) {
+    const int lds = (a.Hh * a.Wh * HT_PITCH + 4) * 4;
+    GI_REQUIRE(lds <= 160 * 1024, "head: feature map %dx%d too large", a.Hh, a.Wh);
+    if (lds > 64 * 1024) {
+      static bool attr = false;
+      if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    }
+    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(256), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.Hh, a.Wh, a.sigmoid);
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   if (dtype == GI_F16)
     hipLaunchKernelGGL(head_conv_kernel<half_t>, dim3(blocks), dim3(256), 0, st, (const char*)a.a4, a.w5, a.h, a.Hh, a.Wh, a.c);
   else
@@ -811,6 +1036,21 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
 
 int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
   const int Ph = a.Hh - 3, Pw = a.Wh - 3, P = Ph * Pw;
+  if (dtype == GI_F16 && a.c == 512 && head_fast()) {
+    const int bands = head_bands(a.n, a.Hh * a.Wh), nb = a.n * bands;
+    const bool wg = a.dw5 != nullptr;
+    if (!wg || (a.scratch && a.scratch_bytes >= (int64_t)nb * 8192 * 4)) {
+      GI_REQUIRE(!wg || a.dwl, "head: dw5 without dwl");
+      hipLaunchKernelGGL(head_bwd512_kernel, dim3(wg ? 2 * nb + 1 : nb), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.w5, (const char*)a.a4,
+                         (char*)a.da4, a.scratch, a.dwl, a.dbl, a.n, a.Hh, a.Wh, bands, a.sigmoid, a.loss_scale);
+      GI_LAUNCH_CHECK();
+      if (wg) {
+        hipLaunchKernelGGL(head_wsum512_kernel, dim3(32), dim3(256), 0, st, a.scratch, nb, a.dw5);
+        GI_LAUNCH_CHECK();
+      }
+      return GI_OK;
+    }
+  }
   hipLaunchKernelGGL(head_linear_bwd_kernel, dim3((P + 255) / 256), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.dh, a.dwl,
                      a.dbl, a.n, P, a.sigmoid);
   GI_LAUNCH_CHECK();

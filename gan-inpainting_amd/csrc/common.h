@@ -184,7 +184,9 @@ struct HeadBwdArgs {
   float* dh;           // scratch (n,P)
   int n, Hh, Wh, c, sigmoid;
   float loss_scale;
+  float* scratch = nullptr; int64_t scratch_bytes = 0;   // weight-gradient partials (op_head_scratch_bytes)
 };
+int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh);
 int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a);
 
 // weight packing / conversions

@@ -464,7 +464,7 @@ int run(hipStream_t st, IgemmArgs& a) {
   const int tiles = mt * nt * phases;
   int splitk = 1;
   if (a.force_splitk > 0) splitk = a.force_splitk;
-  else if (tiles < 128 && kp.nk >= 8) {
+  else if (tiles < 256 && kp.nk >= 8) {   // fewer workgroups than CUs: split the reduction
     static int target = -1;   // workgroups to aim for (GI_IGEMM_SPLIT_BLOCKS: tools only)
     if (target < 0) { const char* e = getenv("GI_IGEMM_SPLIT_BLOCKS"); target = e ? atoi(e) : 384; }
     splitk = (target + tiles - 1) / tiles;

@@ -79,6 +79,7 @@ struct gi_net {
   std::vector<int64_t> ogC, ogA;
   int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1, oCol = -1;
   int64_t part_floats = 0, split_bytes = 0;
+  int64_t oHw = -1, hw_bytes = 0;    // head weight-gradient partials
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
   // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
@@ -328,6 +329,8 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
     net->wg_bytes = max64(net->wg_bytes, op_wgrad_scratch_bytes(dtype, max_n, H >> i, W >> i, net->dconv[i].ca, net->dconv[i].cb));
   if (net->wg_bytes > 0) net->oWg = A.take(net->wg_bytes);
   net->oDh = A.take(N * net->P * 4);
+  net->hw_bytes = op_head_scratch_bytes((int)N, net->Hh, net->Wh);
+  net->oHw = A.take(net->hw_bytes);
   net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   {   // gradient penalty (fp32 critics): tangent / stacked-gradient tensors
     int64_t maxl = 0;
@@ -854,6 +857,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   hb.dwl = need_wgrad ? net->grads + net->wl_off : nullptr;
   hb.dbl = need_wgrad ? net->grads + net->bl_off : nullptr;
   hb.dh = (float*)net->shared(net->oDh);
+  hb.scratch = (float*)net->shared(net->oHw); hb.scratch_bytes = net->hw_bytes;
   hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = net->sigmoid; hb.loss_scale = LS;
   if (phase != 2) GI_TRY(op_head_backward(st, dt, hb));
   for (int i = 4; i >= 2; --i) {
