@@ -684,28 +684,33 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const 
 // per instruction; w5 as fp16 fragments resident in registers, fp32 accumulation), so every activation is read once;
 // then h[p] = sum_tap t[p + (ky,kx)][tap], the Linear(P,1) and the optional sigmoid in the same workgroup.
 constexpr int HT_PITCH = 17;   // floats per pixel row of t in LDS (16 taps + 1: conflict-free column reads)
-__global__ void __launch_bounds__(256) head_fwd512_kernel(const char* __restrict__ a4, const float* __restrict__ w5,
-                                                          const float* __restrict__ wl, const float* __restrict__ bl,
-                                                          float* __restrict__ h, float* __restrict__ out, int Hh, int Wh,
-                                                          int sigmoid) {
-  extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] + 4
+__global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restrict__ a4, const float* __restrict__ w5,
+                                                           const float* __restrict__ wl, const float* __restrict__ bl,
+                                                           float* __restrict__ h, float* __restrict__ out, int Hh, int Wh,
+                                                           int sigmoid) {
+  extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] | 16 partial sums | w5 as fp16 [16 taps][512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nn = blockIdx.x, npx = Hh * Wh;
+  float* red = t_lds + ((npx * HT_PITCH + 3) & ~3);   // 16-byte aligned
+  half_t* wh = (half_t*)(red + 16);
+  for (int i = threadIdx.x; i < 16 * 512 / 4; i += 1024) {
+    const f4_t v = *(const f4_t*)(w5 + i * 4);
+    *(h4_t*)(wh + i * 4) = h4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+  }
+  __syncthreads();
   h8_t bf[16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const float* src = w5 + (lane & 15) * 512 + ks * 32 + (lane >> 4) * 8;
-    const f4_t lo = *(const f4_t*)src, hi = *(const f4_t*)(src + 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { bf[ks][e] = (half_t)lo[e]; bf[ks][4 + e] = (half_t)hi[e]; }
-  }
+  for (int ks = 0; ks < 16; ++ks) bf[ks] = *(const h8_t*)(wh + (lane & 15) * 512 + ks * 32 + (lane >> 4) * 8);
   const char* img = a4 + (int64_t)nn * npx * 1024;
-  for (int tile = wave; tile * 16 < npx; tile += 4) {
+  for (int tile = wave; tile * 16 < npx; tile += 16) {
     const int px = min(tile * 16 + (lane & 15), npx - 1);
     const char* row = img + (int64_t)px * 1024 + (lane >> 4) * 16;
+    h8_t av[16];
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) av[ks] = *(const h8_t*)(row + ks * 64);
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const h8_t*)(row + ks * 64), bf[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[ks], bf[ks], acc, 0, 0, 0);
     // D[row = pixel][col = tap]: lane holds tap (lane&15), pixels 4*(lane>>4) + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -716,7 +721,7 @@ __global__ void __launch_bounds__(256) head_fwd512_kernel(const char* __restrict
   __syncthreads();
   const int Ph = Hh - 3, Pw = Wh - 3, P = Ph * Pw;
   float part = 0.f;
-  for (int p = threadIdx.x; p < P; p += 256) {
+  for (int p = threadIdx.x; p < P; p += 1024) {
     const int py = p / Pw, px = p - py * Pw;
     float sacc = 0.f;
 #pragma unroll
@@ -725,21 +730,23 @@ __global__ void __launch_bounds__(256) head_fwd512_kernel(const char* __restrict
     part = fmaf(sacc, wl[p], part);
   }
   for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-  float* red = t_lds + npx * HT_PITCH;
   if (lane == 0) red[wave] = part;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float z = ((red[0] + red[1]) + (red[2] + red[3])) + bl[0];
+    float z = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) z += red[w];
+    z += bl[0];
     out[nn] = sigmoid ? 1.f / (1.f + expf(-z)) : z;
   }
 }
 
-// Backward in ONE launch, three roles by blockIdx (dh[n,p] = dz[n]*wl[p] is never materialised):
+// Backward, two roles by blockIdx in one launch (dh[n,p] = dz[n]*wl[p] is never materialised):
 //   [0, nb)        input gradient: da4[n,y,x,:] = loss_scale * sum_tap dh[n,y-ky,x-kx] * w5[tap][:], a lane owns 8
 //                  channels with its 16x8 weights in registers, a wave owns a pixel (one 1-KiB store);
 //   [nb, 2nb)      weight-gradient partial of the same pixel range: acc[tap][8ch] += dh[..] * a4[n,y,x,8ch], reduced over
 //                  the 4 waves in LDS and stored to part[block][16][512] (summed in fixed order by head_wsum512_kernel);
-//   last block     dwl[p] += sum_n dz[n]*h[n,p], dbl += sum_n dz[n].
+//   The Linear's gradients dwl[p] += sum_n dz[n]*h[n,p], dbl += sum_n dz[n] ride in head_wsum512_kernel.
 // Without parameter gradients (frozen critic) only the first nb blocks are launched.
 __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restrict__ dy, const float* __restrict__ outv,
                                                           const float* __restrict__ hsave, const float* __restrict__ wl,
@@ -753,32 +760,21 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
   const int Ph = Hh - 3, Pw = Wh - 3, P = Ph * Pw, npx = Hh * Wh;
   const int nb = n * bands;
   int b = blockIdx.x;
-  if (b >= 2 * nb) {   // Linear(P,1) parameter gradients
-    for (int p = threadIdx.x; p < P; p += 256) {
-      float gw = 0.f;
-      for (int i = 0; i < n; ++i) {
-        const float o = outv[i];
-        gw = fmaf(dy[i] * (sigmoid ? o * (1.f - o) : 1.f), hsave[(int64_t)i * P + p], gw);
-      }
-      dwl[p] += gw;
-    }
-    if (threadIdx.x == 0 && dbl) {
-      float gb = 0.f;
-      for (int i = 0; i < n; ++i) {
-        const float o = outv[i];
-        gb += dy[i] * (sigmoid ? o * (1.f - o) : 1.f);
-      }
-      dbl[0] += gb;
-    }
-    return;
-  }
   const bool wgrad = b >= nb;
   if (wgrad) b -= nb;
   const int nn = b / bands, band = b - nn * bands;
   const int ppb = (npx + bands - 1) / bands;               // pixels per block
   const int q0 = band * ppb, q1 = min(npx, q0 + ppb);
   const float o = outv[nn];
-  const float dz = dy[nn] * (sigmoid ? o * (1.f - o) : 1.f);
+  const float dz = dy[nn] * (sigmoid ? o * (1.f - o) : 1.f) * (wgrad ? 1.f : loss_scale);
+  // gp[(py+3)*GW + px+3] = dz * wl[py*Pw+px] with a 3-wide zero border: dh of this image without bounds checks
+  const int GW = Pw + 6;
+  float* gp = red;
+  for (int i = threadIdx.x; i < (Ph + 6) * GW; i += 256) {
+    const int py = i / GW - 3, px = i - (py + 3) * GW - 3;
+    gp[i] = (py >= 0 && py < Ph && px >= 0 && px < Pw) ? dz * wl[py * Pw + px] : 0.f;
+  }
+  __syncthreads();
   if (!wgrad) {
     float w[16][8];
 #pragma unroll
@@ -787,18 +783,17 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) { w[tap][e] = lo[e]; w[tap][4 + e] = hi[e]; }
     }
-    const float dzs = dz * loss_scale;
     for (int q = q0 + wave; q < q1; q += 4) {
       const int y = q / Wh, x = q - y * Wh;
+      const float* gq = gp + (y + 3) * GW + x + 3;
+      float g[16];
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap) g[tap] = gq[-(tap >> 2) * GW - (tap & 3)];   // LDS broadcast reads
       float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int tap = 0; tap < 16; ++tap) {
-        const int py = y - (tap >> 2), px = x - (tap & 3);
-        if (py < 0 || py >= Ph || px < 0 || px >= Pw) continue;      // wave-uniform
-        const float g = dzs * wl[py * Pw + px];
+      for (int tap = 0; tap < 16; ++tap)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sacc[e] = fmaf(g, w[tap][e], sacc[e]);
-      }
+        for (int e = 0; e < 8; ++e) sacc[e] = fmaf(g[tap], w[tap][e], sacc[e]);
       h8_t v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (half_t)sacc[e];
@@ -811,21 +806,30 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
   for (int tap = 0; tap < 16; ++tap)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[tap][e] = 0.f;
-  for (int q = q0 + wave; q < q1; q += 4) {
-    const int y = q / Wh, x = q - y * Wh;
-    const h8_t v = *(const h8_t*)(a4 + ((int64_t)nn * npx + q) * 1024 + lane * 16);
-    float vf[8];
+  const char* arow = a4 + (int64_t)nn * npx * 1024 + lane * 16;
+  for (int qb = q0 + wave; qb < q1; qb += 32) {   // 8 pixel rows in flight per wave
+    h8_t v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) vf[e] = (float)v[e];
+    for (int jx = 0; jx < 8; ++jx) v[jx] = *(const h8_t*)(arow + (int64_t)min(qb + 4 * jx, npx - 1) * 1024);
 #pragma unroll
-    for (int tap = 0; tap < 16; ++tap) {
-      const int py = y - (tap >> 2), px = x - (tap & 3);
-      if (py < 0 || py >= Ph || px < 0 || px >= Pw) continue;        // wave-uniform
-      const float g = dz * wl[py * Pw + px];
+    for (int jx = 0; jx < 8; ++jx) {
+      const int q = qb + 4 * jx;
+      if (q >= q1) break;                          // wave-uniform
+      const int y = q / Wh, x = q - y * Wh;
+      const float* gq = gp + (y + 3) * GW + x + 3;
+      float g[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[tap][e] = fmaf(g, vf[e], acc[tap][e]);
+      for (int tap = 0; tap < 16; ++tap) g[tap] = gq[-(tap >> 2) * GW - (tap & 3)];
+      float vf[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vf[e] = (float)v[jx][e];
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[tap][e] = fmaf(g[tap], vf[e], acc[tap][e]);
     }
   }
+  __syncthreads();   // every wave is done with gp before red is reused
   // waves 2,3 -> LDS, waves 0,1 add; wave 1 -> LDS, wave 0 adds and stores the block's partial
   auto put = [&](int slot) {
 #pragma unroll
@@ -861,19 +865,49 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
   }
 }
 
-// dw5[i] += sum_b part[b][i], b ascending (deterministic)
-__global__ void __launch_bounds__(256) head_wsum512_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw5) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // < 8192
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= nb; b += 4) {
-    s0 += part[(int64_t)b * 8192 + i];
-    s1 += part[(int64_t)(b + 1) * 8192 + i];
-    s2 += part[(int64_t)(b + 2) * 8192 + i];
-    s3 += part[(int64_t)(b + 3) * 8192 + i];
+// dw5[i] += sum_b part[b][i] in a fixed order (deterministic): a workgroup owns 32 elements, 8 thread groups
+// each sum every 8th partial, LDS combines the groups. Workgroups 256 .. 256+P-1 compute dwl[p] (threads over the
+// batch, tree reduction), workgroup 256+P the Linear's bias gradient.
+__global__ void __launch_bounds__(256) head_wsum512_kernel(const float* __restrict__ part, int nb, float* __restrict__ dw5,
+                                                           const float* __restrict__ dy, const float* __restrict__ outv,
+                                                           const float* __restrict__ hsave, float* __restrict__ dwl,
+                                                           float* __restrict__ dbl, int n, int P, int sigmoid) {
+  __shared__ float red[8][32];
+  if (blockIdx.x >= 256) {
+    const int p = blockIdx.x - 256;
+    if (p == P && !dbl) return;
+    float g = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const float o = outv[i];
+      const float dz = dy[i] * (sigmoid ? o * (1.f - o) : 1.f);
+      g += p < P ? dz * hsave[(int64_t)i * P + p] : dz;
+    }
+    for (int off = 32; off > 0; off >>= 1) g += __shfl_xor(g, off);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = g;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float t = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      if (p < P) dwl[p] += t; else dbl[0] += t;
+    }
+    return;
   }
-  for (; b < nb; ++b) s0 += part[(int64_t)b * 8192 + i];
-  dw5[i] += (s0 + s1) + (s2 + s3);
+  const int e = threadIdx.x & 31, gq = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + e;   // < 8192
+  float s0 = 0.f, s1 = 0.f;
+  int b = gq;
+  for (; b + 8 < nb; b += 16) {
+    s0 += part[(int64_t)b * 8192 + i];
+    s1 += part[(int64_t)(b + 8) * 8192 + i];
+  }
+  if (b < nb) s0 += part[(int64_t)b * 8192 + i];
+  red[gq][e] = s0 + s1;
+  __syncthreads();
+  if (gq == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][e];
+    dw5[i] += t;
+  }
 }
 
 // row bands per image for the backward: ~256 workgroups, at least 32 pixels each
@@ -1014,13 +1048,13 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
   GI_REQUIRE(Ph >= 1 && Pw >= 1, "head: feature map %dx%d too small", a.Hh, a.Wh);
   const int blocks = a.n * Ph * Pw;
   if (dtype == GI_F16 && a.c == 512 && head_fast()) {
-    const int lds = (a.Hh * a.Wh * HT_PITCH + 4) * 4;
+    const int lds = (((a.Hh * a.Wh * HT_PITCH + 3) & ~3) + 16) * 4 + 16 * 512 * 2;
     GI_REQUIRE(lds <= 160 * 1024, "head: feature map %dx%d too large", a.Hh, a.Wh);
     if (lds > 64 * 1024) {
       static bool attr = false;
       if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     }
-    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(256), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.Hh, a.Wh, a.sigmoid);
+    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.Hh, a.Wh, a.sigmoid);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
@@ -1041,11 +1075,11 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
     const bool wg = a.dw5 != nullptr;
     if (!wg || (a.scratch && a.scratch_bytes >= (int64_t)nb * 8192 * 4)) {
       GI_REQUIRE(!wg || a.dwl, "head: dw5 without dwl");
-      hipLaunchKernelGGL(head_bwd512_kernel, dim3(wg ? 2 * nb + 1 : nb), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.w5, (const char*)a.a4,
+      hipLaunchKernelGGL(head_bwd512_kernel, dim3(wg ? 2 * nb : nb), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.w5, (const char*)a.a4,
                          (char*)a.da4, a.scratch, a.dwl, a.dbl, a.n, a.Hh, a.Wh, bands, a.sigmoid, a.loss_scale);
       GI_LAUNCH_CHECK();
       if (wg) {
-        hipLaunchKernelGGL(head_wsum512_kernel, dim3(32), dim3(256), 0, st, a.scratch, nb, a.dw5);
+        hipLaunchKernelGGL(head_wsum512_kernel, dim3(256 + P + 1), dim3(256), 0, st, a.scratch, nb, a.dw5, a.dy, a.out, a.h, a.dwl, a.dbl, a.n, P, a.sigmoid);
         GI_LAUNCH_CHECK();
       }
       return GI_OK;
