@@ -126,8 +126,8 @@ int gi_time_convT_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_phase
   float ms = 0.f;
   GI_HIP(hipEventElapsedTime(&ms, e0, e1));
   *ms_out_host = ms / iters;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   return GI_OK;
 }
 

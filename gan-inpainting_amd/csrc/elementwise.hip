@@ -630,6 +630,42 @@ __global__ void __launch_bounds__(256) pack_phase_kernel(const float* w, T* wph,
   }
 }
 
+// All layers of a network in one launch: a workgroup takes one 32x32 (a,b) tile of one tap of one layer, writes the
+// plain converted copy (same [a][16][b] layout) and the transposed sub-pixel-phase copy from a single read.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs P) {
+  __shared__ float tile[32][33];
+  int jb = 0;
+  while (jb + 1 < P.n && (int)blockIdx.x >= P.j[jb + 1].tile0) ++jb;
+  const float* w = P.j[jb].w;
+  T* packed = (T*)P.j[jb].packed;
+  T* wph = (T*)P.j[jb].phase;
+  const int ca = P.j[jb].ca, cb = P.j[jb].cb, tiles_a = (ca + 31) / 32, tiles_b = (cb + 31) / 32;
+  int t = (int)blockIdx.x - P.j[jb].tile0;
+  const int a0 = (t % tiles_a) * 32;
+  t /= tiles_a;
+  const int b0 = (t % tiles_b) * 32, k16 = t / tiles_b;   // k16 = ph*4 + tap
+  const int ph = k16 >> 2, tp = k16 & 3;
+  const int ky = 1 - (ph >> 1) + 2 * (tp >> 1), kx = 1 - (ph & 1) + 2 * (tp & 1);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int a = a0 + r, b = b0 + tx;
+    float v = 0.f;
+    if (a < ca && b < cb) {
+      const int64_t idx = ((int64_t)a * 16 + ky * 4 + kx) * cb + b;
+      v = w[idx];
+      if (packed) packed[idx] = (T)v;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  if (!wph) return;
+  for (int r = ty; r < 32; r += 8) {
+    const int b = b0 + r, a = a0 + tx;
+    if (a < ca && b < cb) wph[(((int64_t)ph * cb + b) * 4 + tp) * ca + a] = (T)tile[tx][r];
+  }
+}
+
 __global__ void __launch_bounds__(256) dropout_fill_kernel(uint8_t* mask, int64_t count, uint64_t seed, uint32_t thresh) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);   // splitmix64 of a counter
@@ -752,6 +788,20 @@ int op_pack_weights(hipStream_t st, int dtype, const float* w, int ca, int cb, v
     else hipLaunchKernelGGL(pack_phase_kernel<float>, grid, dim3(256), 0, st, w, (float*)w_phase, ca, cb);
     GI_LAUNCH_CHECK();
   }
+  return GI_OK;
+}
+
+int op_pack_weights_batch(hipStream_t st, int dtype, PackJobs& P) {
+  if (P.n <= 0) return GI_OK;
+  GI_REQUIRE(P.n <= 16, "pack_weights_batch: %d layers", P.n);
+  int tiles = 0;
+  for (int i = 0; i < P.n; ++i) {
+    P.j[i].tile0 = tiles;
+    tiles += ((P.j[i].ca + 31) / 32) * ((P.j[i].cb + 31) / 32) * 16;
+  }
+  if (dtype == GI_F16) hipLaunchKernelGGL(pack_batch_kernel<half_t>, dim3(tiles), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(tiles), dim3(256), 0, st, P);
+  GI_LAUNCH_CHECK();
   return GI_OK;
 }
 

@@ -424,19 +424,25 @@ __global__ void __launch_bounds__(256) pad_b_kernel(const float* __restrict__ sr
   }
 }
 
-int sync_conv(gi_net* net, const Conv& c) {
-  void* packed = c.packed_off >= 0 ? (void*)net->shared(c.packed_off) : nullptr;
-  return op_pack_weights(net->ctx->stream, net->dtype, net->params + c.w_off, c.ca, c.cb, packed, net->shared(c.phase_off));
-}
 }  // namespace
 
 extern "C" int gi_net_sync_weights(gi_net* net) {
   GI_REQUIRE(net && net->bound, "sync_weights: net not bound");
+  PackJobs P;
+  P.n = 0;
+  auto add = [&](const Conv& c) {
+    PackJob& J = P.j[P.n++];
+    J.w = net->params + c.w_off; J.ca = c.ca; J.cb = c.cb; J.tile0 = 0; J.pad_ = 0;
+    J.packed = c.packed_off >= 0 ? (void*)net->shared(c.packed_off) : nullptr;
+    J.phase = net->shared(c.phase_off);
+  };
   if (net->kind == 0) {
     for (int k = 2; k <= net->nd; ++k) {
-      GI_TRY(sync_conv(net, net->conv[k]));
-      GI_TRY(sync_conv(net, net->up[k]));
+      if (P.n + 2 > 16) { GI_TRY(op_pack_weights_batch(net->ctx->stream, net->dtype, P)); P.n = 0; }
+      add(net->conv[k]);
+      add(net->up[k]);
     }
+    GI_TRY(op_pack_weights_batch(net->ctx->stream, net->dtype, P));
     if (net->out_c > 1) {
       const int ca = net->up[1].ca;
       float* pad = (float*)net->shared(net->oUp1Pad);
@@ -447,7 +453,8 @@ extern "C" int gi_net_sync_weights(gi_net* net) {
                              net->shared(net->oUp1Phase)));
     }
   } else {
-    for (int i = 2; i <= 4; ++i) GI_TRY(sync_conv(net, net->dconv[i]));
+    for (int i = 2; i <= 4; ++i) add(net->dconv[i]);
+    GI_TRY(op_pack_weights_batch(net->ctx->stream, net->dtype, P));
   }
   return GI_OK;
 }
