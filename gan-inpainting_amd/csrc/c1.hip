@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float*
 
 // overlap-add of the 16 taps: out(2j+py, 2i+px) = post(bias + sum_{ty,tx} col[(j+py-ty, i+px-tx)][(1-py+2ty)*4 + 1-px+2tx])
 __global__ void __launch_bounds__(256) c1_col2im_kernel(const half_t* __restrict__ col, const float* __restrict__ bias,
-                                                        float* img, int n, int Hs, int Ws, int post, float out_scale) {
+                                                        float* img, float* img2, int n, int Hs, int Ws, int post, float out_scale) {
   const int64_t total = (int64_t)n * Hs * Ws;
   const int H = 2 * Hs, W = 2 * Ws;
   const float b = bias ? bias[0] : 0.f;
@@ -290,7 +290,9 @@ __global__ void __launch_bounds__(256) c1_col2im_kernel(const half_t* __restrict
     for (int py = 0; py < 2; ++py) {
       float v0 = o[py * 2] + b, v1 = o[py * 2 + 1] + b;
       if (post == 1) { v0 = tanhf(v0); v1 = tanhf(v1); }
-      *(float2*)(img + ((int64_t)nn * H + 2 * j + py) * W + 2 * i) = make_float2(v0 * out_scale, v1 * out_scale);
+      const int64_t oo = ((int64_t)nn * H + 2 * j + py) * W + 2 * i;
+      *(float2*)(img + oo) = make_float2(v0 * out_scale, v1 * out_scale);
+      if (img2) *(float2*)(img2 + oo) = make_float2(v0 * out_scale, v1 * out_scale);   // the caller's copy of the saved output
     }
   }
 }
@@ -686,8 +688,8 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const 
 constexpr int HT_PITCH = 17;   // floats per pixel row of t in LDS (16 taps + 1: conflict-free column reads)
 __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restrict__ a4, const float* __restrict__ w5,
                                                            const float* __restrict__ wl, const float* __restrict__ bl,
-                                                           float* __restrict__ h, float* __restrict__ out, int Hh, int Wh,
-                                                           int sigmoid) {
+                                                           float* __restrict__ h, float* __restrict__ out,
+                                                           float* __restrict__ out2, int Hh, int Wh, int sigmoid) {
   extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] | 16 partial sums | w5 as fp16 [16 taps][512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nn = blockIdx.x, npx = Hh * Wh;
@@ -737,7 +739,9 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
 #pragma unroll
     for (int w = 0; w < 16; ++w) z += red[w];
     z += bl[0];
-    out[nn] = sigmoid ? 1.f / (1.f + expf(-z)) : z;
+    z = sigmoid ? 1.f / (1.f + expf(-z)) : z;
+    out[nn] = z;
+    if (out2) out2[nn] = z;
   }
 }
 
@@ -977,7 +981,7 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
 }
 
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img, int n, int Hs,
-                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale, void* col_scratch) {
+                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale, void* col_scratch, float* img2) {
   if (dtype == GI_F16 && col_scratch && (c == 64 || c == 128) && ldx % 8 == 0 && coffx % 8 == 0) {
     const int64_t P = (int64_t)n * Hs * Ws;
     const int grid = grid_for((P + 15) / 16, 4, 256 * 8);
@@ -986,7 +990,7 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
     else
       hipLaunchKernelGGL(c1_col_kernel<2>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in);
     GI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(c1_col2im_kernel, dim3(grid_for(P, 256, 256 * 8)), dim3(256), 0, st, (const half_t*)col_scratch, bias, img, n, Hs,
+    hipLaunchKernelGGL(c1_col2im_kernel, dim3(grid_for(P, 256, 256 * 8)), dim3(256), 0, st, (const half_t*)col_scratch, bias, img, img2, n, Hs,
                        Ws, post, out_scale);
     GI_LAUNCH_CHECK();
     return GI_OK;
@@ -1003,6 +1007,7 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
     hipLaunchKernelGGL(c1_scatter_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)X, w, bias, img, n, Hs, Ws, c,
                        ldx, coffx, relu_in, post, out_scale);
   GI_LAUNCH_CHECK();
+  if (img2) GI_HIP(hipMemcpyAsync(img2, img, (size_t)n * 4 * Hs * Ws * 4, hipMemcpyDeviceToDevice, st));
   return GI_OK;
 }
 
@@ -1054,7 +1059,7 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
       static bool attr = false;
       if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     }
-    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.Hh, a.Wh, a.sigmoid);
+    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
@@ -1065,6 +1070,7 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
   GI_LAUNCH_CHECK();
   hipLaunchKernelGGL(head_linear_kernel, dim3(a.n), dim3(64), 0, st, a.h, a.wl, a.bl, a.out, Ph * Pw, a.sigmoid);
   GI_LAUNCH_CHECK();
+  if (a.out2) GI_HIP(hipMemcpyAsync(a.out2, a.out, (size_t)a.n * 4, hipMemcpyDeviceToDevice, st));
   return GI_OK;
 }
 

@@ -127,7 +127,7 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
 // col_scratch (fp16 path): >= n*Hs*Ws*16 halves; null selects the register-reduction kernel
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img,
                   int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale,
-                  void* col_scratch);
+                  void* col_scratch, float* img2 = nullptr);
 // dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx]
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws,
                 int c, int ldx, int coffx, int relu_in, float scale, float img_scale);
@@ -137,10 +137,12 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
 // updates running stats (momentum 0.1, unbiased variance), eval mode uses the running stats.
 int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64_t count, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, float* scale, float* shift,
-                   float* save_mean, float* save_invstd, int train, float momentum, float eps);
-// y[p*ldy+coffy+c] = drop( act( x[p*c+..]*scale[c] + shift[c] ) ) ; x dense (ld = c)
+                   float* save_mean, float* save_invstd, int train, float momentum, float eps, int groups = 1,
+                   int64_t part_stride = 0, int out_stride = 0);
+// pg in (0, pixels): two BatchNorm populations, pixels >= pg use scale/shift + gstride
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
-                const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale);
+                const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale,
+                int64_t pg = 0, int gstride = 0);
 // column sum / sumsq of a dense (pixels,c) tensor -> partials [blocks][2][c]; returns rows in *rows_out
 int op_col_stats(hipStream_t st, int dtype, const void* x, int64_t pixels, int c, float* partials, int* rows_out);
 
@@ -161,9 +163,12 @@ struct ActBnBwdArgs {
   float* dgamma; float* dbeta;        // accumulated (+=) with 1/loss_scale when non-null
   float inv_loss_scale;
   float* partials;                    // scratch [blocks][2][c]
-  float* sums;                        // scratch [2][c]
+  float* sums;                        // scratch [groups][2][c]
+  int groups;                         // 2: the tensor is two consecutive BatchNorm populations (save_mean / save_invstd of
+  int stat_stride;                    //    the second at +stat_stride floats), reduced separately in the same launches
 };
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a);
+int op_bwd_rows_per_block(int64_t pixels);   // rows one reduce workgroup covers (groups = 2 needs pixels/2 to be a multiple)
 
 // discriminator head: conv(512->1,k4,s1,p0) + Flatten + Linear(P,1) [+ sigmoid]
 struct HeadArgs {
@@ -174,6 +179,7 @@ struct HeadArgs {
   float* h;            // (n,P) conv output (saved)
   float* out;          // (n,1)
   int n, Hh, Wh, c, sigmoid;
+  float* out2 = nullptr;   // optional second copy of out (the caller's y)
 };
 int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a);
 struct HeadBwdArgs {

@@ -40,67 +40,83 @@ __device__ __forceinline__ void store_vec(char* base, int64_t elem_off, const fl
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials, int rows, int c, float count,
                                                           const float* gamma, const float* beta, float* rmean,
                                                           float* rvar, float* scale, float* shift, float* smean,
-                                                          float* sinv, int train, float momentum, float eps) {
+                                                          float* sinv, int train, float momentum, float eps, int groups,
+                                                          int64_t part_stride, int out_stride) {
+  // groups > 1: consecutive BatchNorm populations (stacked critic batch); group j's partial rows start at
+  // partials + j*part_stride, its outputs at +j*out_stride; running statistics are updated in group order
   __shared__ double rs[256], rq[256];
   const int ch = blockIdx.x;
-  float mean, var;
-  if (train) {
-    double s = 0.0, q = 0.0;
-    for (int r = threadIdx.x; r < rows; r += 256) {
-      s += (double)partials[((int64_t)r * 2) * c + ch];
-      q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
-    }
-    rs[threadIdx.x] = s;
-    rq[threadIdx.x] = q;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+  for (int j = 0; j < groups; ++j) {
+    float mean = 0.f, var = 1.f;
+    if (train) {
+      const float* pj = partials + (int64_t)j * part_stride;
+      double s = 0.0, q = 0.0;
+      for (int r = threadIdx.x; r < rows; r += 256) {
+        s += (double)pj[((int64_t)r * 2) * c + ch];
+        q += (double)pj[((int64_t)r * 2 + 1) * c + ch];
+      }
+      rs[threadIdx.x] = s;
+      rq[threadIdx.x] = q;
       __syncthreads();
+      for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+        __syncthreads();
+      }
     }
-    if (threadIdx.x != 0) return;
-    const double m = rs[0] / count;
-    double v = rq[0] / count - m * m;
-    if (v < 0.0) v = 0.0;
-    mean = (float)m;
-    var = (float)v;
-    const float unbiased = count > 1.f ? (float)(v * (double)count / ((double)count - 1.0)) : var;
-    rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean;
-    rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * unbiased;
-  } else {
-    if (threadIdx.x != 0) return;
-    mean = rmean[ch];
-    var = rvar[ch];
+    if (threadIdx.x == 0) {
+      if (train) {
+        const double m = rs[0] / count;
+        double v = rq[0] / count - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m;
+        var = (float)v;
+        const float unbiased = count > 1.f ? (float)(v * (double)count / ((double)count - 1.0)) : var;
+        rmean[ch] = (1.f - momentum) * rmean[ch] + momentum * mean;
+        rvar[ch] = (1.f - momentum) * rvar[ch] + momentum * unbiased;
+      } else {
+        mean = rmean[ch];
+        var = rvar[ch];
+      }
+      const float inv = 1.0f / sqrtf(var + eps);
+      const float sc = gamma[ch] * inv;
+      const int o = j * out_stride + ch;
+      scale[o] = sc;
+      shift[o] = beta[ch] - mean * sc;
+      smean[o] = mean;
+      sinv[o] = inv;
+    }
+    __syncthreads();   // rs / rq are reused by the next group
   }
-  const float inv = 1.0f / sqrtf(var + eps);
-  const float sc = gamma[ch] * inv;
-  scale[ch] = sc;
-  shift[ch] = beta[ch] - mean * sc;
-  smean[ch] = mean;
-  sinv[ch] = inv;
 }
 
 // grid-stride is a multiple of the chunks-per-pixel (a power of two <= 256), so a thread's channel
 // chunk never changes: scale/shift live in registers, index math is shifts.
-template <typename T>
+// G2: two BatchNorm populations in one pass, pixels >= pg use the second scale/shift set (at +gstride floats).
+template <typename T, bool G2>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, int64_t pixels, int c, int ldy, int coffy,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int act, const uint8_t* drop, float drop_scale) {
+                                                       int act, const uint8_t* drop, float drop_scale, int64_t pg, int gstride) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpp = c / EPC;
   const int lg = 31 - __builtin_clz(cpp);
   const int64_t total = pixels * cpp;
   const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int cc = (int)(gid0 & (cpp - 1));
-  float sc[EPC], sh[EPC];
+  float sc[EPC], sh[EPC], sc1[G2 ? EPC : 1], sh1[G2 ? EPC : 1];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { sc[e] = scale ? scale[cc * EPC + e] : 1.f; sh[e] = scale ? shift[cc * EPC + e] : 0.f; }
+  if constexpr (G2) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc1[e] = scale[gstride + cc * EPC + e]; sh1[e] = shift[gstride + cc * EPC + e]; }
+  }
   for (int64_t gid = gid0; gid < total; gid += (int64_t)gridDim.x * 256) {
     const int64_t pix = gid >> lg;
     float v[EPC];
     load_vec<T, EPC>(x, pix * c + cc * EPC, v);
+    const bool second = G2 && pix >= pg;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float t = fmaf(v[e], sc[e], sh[e]);
+      float t = G2 ? fmaf(v[e], second ? sc1[e] : sc[e], second ? sh1[e] : sh[e]) : fmaf(v[e], sc[e], sh[e]);
       if (act == GI_ACT_RELU) t = t > 0.f ? t : 0.f;
       else if (act == GI_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
       v[e] = t;
@@ -155,6 +171,8 @@ struct BwdP {
   const float* gamma; const float* mean; const float* inv;
   float* partials; const float* sums;
   int rows_per_block;
+  int64_t pg;        // pixels per BatchNorm population (= pixels for one group); blocks never straddle populations
+  int stat_stride;   // floats between the populations' mean / inv vectors; sums are [group][2][c]
 };
 
 template <typename T, int EPC>
@@ -189,8 +207,9 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
   const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
   const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block, r1 = min(p.pixels, r0 + p.rows_per_block);
   float s[EPC], sx[EPC], mu[EPC], iv[EPC];
+  const int so = r0 >= p.pg ? p.stat_stride : 0;
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { s[e] = sx[e] = 0.f; mu[e] = p.mean[q * EPC + e]; iv[e] = p.inv[q * EPC + e]; }
+  for (int e = 0; e < EPC; ++e) { s[e] = sx[e] = 0.f; mu[e] = p.mean[so + q * EPC + e]; iv[e] = p.inv[so + q * EPC + e]; }
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     float dz[EPC], xv[EPC];
     compute_dz<T, EPC>(p, r, q * EPC, dz);
@@ -212,27 +231,33 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
 }
 
 // partials [rows][2][c] -> sums [2][c]; also accumulates dgamma/dbeta
+// groups > 1: `rows` partial rows per population, one after the other; sums [group][2][c]; the parameter gradients
+// accumulate population by population (the order of separate calls)
 __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, int rows, int c, float* sums, float* dgamma,
-                                                       float* dbeta, float inv_loss_scale) {
+                                                       float* dbeta, float inv_loss_scale, int groups) {
   __shared__ double rs[256], rq[256];
   const int ch = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int r = threadIdx.x; r < rows; r += 256) {
-    s += (double)partials[((int64_t)r * 2) * c + ch];
-    q += (double)partials[((int64_t)r * 2 + 1) * c + ch];
-  }
-  rs[threadIdx.x] = s;
-  rq[threadIdx.x] = q;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+  for (int j = 0; j < groups; ++j) {
+    const float* pj = partials + (int64_t)j * rows * 2 * c;
+    double s = 0.0, q = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      s += (double)pj[((int64_t)r * 2) * c + ch];
+      q += (double)pj[((int64_t)r * 2 + 1) * c + ch];
+    }
+    rs[threadIdx.x] = s;
+    rq[threadIdx.x] = q;
     __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    sums[ch] = (float)rs[0];
-    sums[c + ch] = (float)rq[0];
-    if (dbeta) dbeta[ch] += (float)rs[0] * inv_loss_scale;
-    if (dgamma) dgamma[ch] += (float)rq[0] * inv_loss_scale;
+    for (int off = 128; off > 0; off >>= 1) {
+      if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      sums[j * 2 * c + ch] = (float)rs[0];
+      sums[j * 2 * c + c + ch] = (float)rq[0];
+      if (dbeta) dbeta[ch] += (float)rs[0] * inv_loss_scale;
+      if (dgamma) dgamma[ch] += (float)rq[0] * inv_loss_scale;
+    }
+    __syncthreads();
   }
 }
 
@@ -242,7 +267,7 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpp = p.c / EPC;
   const int64_t total = p.pixels * cpp;
-  const float invM = 1.f / (float)p.pixels;
+  const float invM = 1.f / (float)p.pg;
   for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
     const int cc = (int)(gid % cpp);
     const int64_t pix = gid / cpp;
@@ -251,11 +276,15 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
     if (HAS_BN) {
       float xv[EPC];
       load_vec<T, EPC>(p.x, pix * p.c + cc * EPC, xv);
+      const bool second = pix >= p.pg;
+      const float* mean = p.mean + (second ? p.stat_stride : 0);
+      const float* inv = p.inv + (second ? p.stat_stride : 0);
+      const float* sums = p.sums + (second ? 2 * p.c : 0);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         const int ch = cc * EPC + e;
-        const float xh = (xv[e] - p.mean[ch]) * p.inv[ch];
-        dz[e] = p.gamma[ch] * p.inv[ch] * (dz[e] - p.sums[ch] * invM - xh * p.sums[p.c + ch] * invM);
+        const float xh = (xv[e] - mean[ch]) * inv[ch];
+        dz[e] = p.gamma[ch] * inv[ch] * (dz[e] - sums[ch] * invM - xh * sums[p.c + ch] * invM);
       }
     }
     store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, dz);
@@ -701,22 +730,27 @@ inline int nblocks(int64_t count, int per_thread = 4) {
 // =================================================================================================
 int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64_t count, const float* gamma,
                    const float* beta, float* running_mean, float* running_var, float* scale, float* shift,
-                   float* save_mean, float* save_invstd, int train, float momentum, float eps) {
+                   float* save_mean, float* save_invstd, int train, float momentum, float eps, int groups,
+                   int64_t part_stride, int out_stride) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(c), dim3(256), 0, st, partials, rows, c, (float)count, gamma, beta,
-                     running_mean, running_var, scale, shift, save_mean, save_invstd, train, momentum, eps);
+                     running_mean, running_var, scale, shift, save_mean, save_invstd, train, momentum, eps, groups, part_stride,
+                     out_stride);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
 
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
-                const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale) {
+                const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale, int64_t pg,
+                int gstride) {
   const int epc = dtype == GI_F16 ? 8 : 4;
   GI_REQUIRE(c % epc == 0 && gi_is_pow2(c / epc) && c / epc <= 256, "bn_apply: c=%d", c);
   const int grid = nblocks(pixels * (c / epc), 4);
-  if (dtype == GI_F16)
-    hipLaunchKernelGGL(bn_apply_kernel<half_t>, dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale);
-  else
-    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale);
+  const bool g2 = pg > 0 && pg < pixels;
+  GI_REQUIRE(!g2 || scale, "bn_apply: two groups need scale/shift");
+#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale, pg, gstride)
+  if (dtype == GI_F16) { if (g2) GI_BN_APPLY(half_t, true); else GI_BN_APPLY(half_t, false); }
+  else { if (g2) GI_BN_APPLY(float, true); else GI_BN_APPLY(float, false); }
+#undef GI_BN_APPLY
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
@@ -743,6 +777,11 @@ int op_col_stats(hipStream_t st, int dtype, const void* x, int64_t pixels, int c
   return GI_OK;
 }
 
+int op_bwd_rows_per_block(int64_t pixels) {
+  int blocks;
+  return rows_per_block_for(pixels, &blocks);
+}
+
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   const int epc = dtype == GI_F16 ? 8 : 4;
   const int Q = a.c / epc;
@@ -755,8 +794,12 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   p.pixels = a.pixels; p.c = a.c; p.act = a.act; p.drop_scale = a.drop_scale;
   p.gamma = a.gamma; p.mean = a.save_mean; p.inv = a.save_invstd;
   p.partials = a.partials; p.sums = a.sums;
-  int blocks = 0;
-  p.rows_per_block = rows_per_block_for(a.pixels, &blocks);
+  const int groups = (a.groups == 2 && a.has_bn && !a.eval_bn) ? 2 : 1;
+  GI_REQUIRE(a.groups <= 1 || groups == 2, "act_bn_bwd: groups=%d needs a train-mode BatchNorm", a.groups);
+  GI_REQUIRE(a.pixels % groups == 0, "act_bn_bwd: %lld pixels in %d groups", (long long)a.pixels, groups);
+  p.pg = a.pixels / groups; p.stat_stride = a.stat_stride;
+  int blocks = 0;   // per population
+  p.rows_per_block = rows_per_block_for(p.pg, &blocks);
   const int grid2 = nblocks(a.pixels * Q, 2);
   if (a.has_bn && a.eval_bn) {
     // running-statistics BatchNorm is a per-channel affine map: the batch-mean terms vanish (sums = 0)
@@ -764,10 +807,13 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
     if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1>), dim3(grid2), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1>), dim3(grid2), dim3(256), 0, st, p);
   } else if (a.has_bn) {
-    if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(256), 0, st, p);
+    GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
+               (long long)p.pg, p.rows_per_block);
+    if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks * groups), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
     GI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, blocks, a.c, a.sums, a.dgamma, a.dbeta, a.inv_loss_scale);
+    hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, blocks, a.c, a.sums, a.dgamma, a.dbeta, a.inv_loss_scale,
+                       groups);
     GI_LAUNCH_CHECK();
     if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1>), dim3(grid2), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1>), dim3(grid2), dim3(256), 0, st, p);

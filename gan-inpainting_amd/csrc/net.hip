@@ -321,7 +321,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oD = A.take(maxD);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
-  net->oSums = A.take(2 * 512 * 4);
+  net->oSums = A.take(2 * 2 * 512 * 4);   // [groups][2][c]
   if (maxSplit > 0) maxSplit = max64(maxSplit, (int64_t)400 * 128 * 128 * 4);
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
@@ -518,6 +518,15 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
   // the GEMM epilogue's partial rows can be split between the groups when a group is a whole number of tiles
   // (tile heights are 256, 128 or a power of two <= 64); otherwise each group's statistics come from a column pass
   const bool aligned = g == 1 || (pg % 256 == 0 && ntiles % g == 0);
+  if (g == 2 && aligned) {   // both populations in one finalize and one apply launch
+    BNPtrs p = bn_ptrs(net, slot, b, 0);
+    const int rows = ntiles / 2;
+    GI_TRY(op_bn_finalize(st, (const float*)net->shared(net->oPart), rows, b.c, pg, net->params + b.gamma_off, net->params + b.beta_off,
+                          net->buffers + b.rmean_off, net->buffers + b.rvar_off, p.scale, p.shift, p.mean, p.inv, train, 0.1f, 1e-5f, 2,
+                          (int64_t)rows * 2 * b.c, 4 * b.c));
+    GI_TRY(op_bn_apply(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, p.scale, p.shift, act, drop, drop_scale, pg, 4 * b.c));
+    return GI_OK;
+  }
   for (int j = 0; j < g; ++j) {
     BNPtrs p = bn_ptrs(net, slot, b, j);
     const char* rj = (const char*)raw + (int64_t)j * pg * b.c * T;
@@ -572,12 +581,17 @@ int wgrad(gi_net* net, const void* S, int ca, int ldS, int coffS, int relu_S, co
 int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, const void* g2, int ldg2, int coffg2,
                const void* y, int ldy, int coffy, const void* x, void* dx, int64_t pixels, int c, int act, float drop_scale,
                const BN* bn, int need_wgrad) {
-  const int g = (net->kind == 1 && bn) ? net->bn_groups : 1;   // BatchNorm groups: reductions per group
-  const int64_t pg = pixels / g;
+  int g = (net->kind == 1 && bn) ? net->bn_groups : 1;   // BatchNorm groups: reductions per group
+  int64_t pg = pixels / g;
   const int64_t T = (int64_t)net->tsz();
+  // both populations in the same three launches when a reduce workgroup never straddles them
+  const bool merged = g == 2 && !net->bwd_eval && pg % op_bwd_rows_per_block(pg) == 0 &&
+                      (2 * (pg / op_bwd_rows_per_block(pg))) * 2 * c <= net->part_floats;
+  if (merged) { g = 1; pg = pixels; }
   for (int j = 0; j < g; ++j) {
     ActBnBwdArgs a;
     memset(&a, 0, sizeof(a));
+    a.groups = merged ? 2 : 1; a.stat_stride = 4 * c;
     const int64_t o = (int64_t)j * pg;
     a.g1 = g1 ? (const char*)g1 + o * ldg1 * T : nullptr; a.ldg1 = ldg1; a.coffg1 = coffg1;
     a.g2 = g2 ? (const char*)g2 + o * ldg2 * T : nullptr; a.ldg2 = ldg2; a.coffg2 = coffg2;
@@ -697,7 +711,8 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   float* osave = (float*)net->slot(s, net->oOut);
   if (net->out_c == 1) {
     GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
-                         net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol)));
+                         net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y));
+    return GI_OK;   // y written beside the saved output
   } else {
     // u1 with out_c channels: the same sub-pixel GEMM as the other up-convolutions on weights zero-padded to 64
     // output channels, then bias + tanh of the first out_c channels into the (n,out_c,H,W) fp32 result
@@ -840,8 +855,8 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   h.a4 = net->slot(s, net->oA[4]); h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;
   h.h = (float*)net->slot(s, net->oHh); h.out = (float*)net->slot(s, net->oOut);
   h.n = n; h.Hh = net->Hh; h.Wh = net->Wh; h.c = 512; h.sigmoid = net->sigmoid;
+  h.out2 = y;
   GI_TRY(op_head_forward(st, dt, h));
-  GI_HIP(hipMemcpyAsync(y, h.out, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
   return GI_OK;
 }
 
