@@ -163,7 +163,9 @@ struct ActBnBwdArgs {
   float* dgamma; float* dbeta;        // accumulated (+=) with 1/loss_scale when non-null
   float inv_loss_scale;
   float* partials;                    // scratch [blocks][2][c]
-  float* sums;                        // scratch [groups][2][c]
+  float* sums;                        // scratch [groups][8][c]
+  const float* fwd_scale; const float* fwd_shift;   // non-null (BatchNorm layers without dropout): the forward's affine map;
+                                      // sign(act input) = sign(fma(x, scale, shift)) replaces the read of y
   int groups;                         // 2: the tensor is two consecutive BatchNorm populations (save_mean / save_invstd of
   int stat_stride;                    //    the second at +stat_stride floats), reduced separately in the same launches
 };

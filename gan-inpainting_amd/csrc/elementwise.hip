@@ -21,6 +21,15 @@ __device__ __forceinline__ void load_vec(const char* base, int64_t elem_off, flo
     for (int e = 0; e < EPC; ++e) v[e] = f[e];
   }
 }
+template <int EPC>
+__device__ __forceinline__ void load_f32(const float* src, float (&v)[EPC]) {   // EPC consecutive floats, 16-byte aligned
+#pragma unroll
+  for (int q = 0; q < EPC / 4; ++q) {
+    const f4_t f = *(const f4_t*)(src + 4 * q);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * q + e] = f[e];
+  }
+}
 template <typename T, int EPC>
 __device__ __forceinline__ void store_vec(char* base, int64_t elem_off, const float (&v)[EPC]) {
   if constexpr (std::is_same<T, half_t>::value) {
@@ -173,29 +182,44 @@ struct BwdP {
   int rows_per_block;
   int64_t pg;        // pixels per BatchNorm population (= pixels for one group); blocks never straddle populations
   int stat_stride;   // floats between the populations' mean / inv vectors; sums are [group][2][c]
+  const float* scale; const float* shift;   // non-null: the activation's sign comes from fma(x, scale, shift), the
+                                            // forward's own pre-activation value, instead of a read of y
 };
 
+// The upstream gradients of one 16-byte chunk: g1 (unmasked) and g2 (passes the parent's ReLU, masked by [y > 0]).
+// All loads are issued before any arithmetic (with_y: also the saved activation y).
 template <typename T, int EPC>
-__device__ __forceinline__ void compute_dz(const BwdP& p, int64_t pix, int ch0, float (&dz)[EPC]) {
-  float yv[EPC];
-  load_vec<T, EPC>(p.y, pix * p.ldy + p.coffy + ch0, yv);
-  float g[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) g[e] = 0.f;
-  if (p.g1) load_vec<T, EPC>(p.g1, pix * p.ldg1 + p.coffg1 + ch0, g);
-  if (p.g2) {
-    float g2[EPC];
-    load_vec<T, EPC>(p.g2, pix * p.ldg2 + p.coffg2 + ch0, g2);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) g[e] += yv[e] > 0.f ? g2[e] : 0.f;
-  }
+struct DzIn { float g1[EPC], g2[EPC], y[EPC]; };
+template <typename T, int EPC>
+__device__ __forceinline__ void load_dz(const BwdP& p, int64_t pix, int ch0, bool with_y, DzIn<T, EPC>& in) {
+  if (p.g1) load_vec<T, EPC>(p.g1, pix * p.ldg1 + p.coffg1 + ch0, in.g1);
+  if (p.g2) load_vec<T, EPC>(p.g2, pix * p.ldg2 + p.coffg2 + ch0, in.g2);
+  if (with_y) load_vec<T, EPC>(p.y, pix * p.ldy + p.coffy + ch0, in.y);
+}
+// sgn: values with the sign of the activation's input (the saved y, or fma(x, scale, shift) of the forward)
+template <typename T, int EPC>
+__device__ __forceinline__ void finish_dz(const BwdP& p, const DzIn<T, EPC>& in, const float (&sgn)[EPC], float (&dz)[EPC]) {
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
+    const bool pos = sgn[e] > 0.f;
+    float g = p.g1 ? in.g1[e] : 0.f;
+    if (p.g2) g += pos ? in.g2[e] : 0.f;
     float sl = 1.f;
-    if (p.act == GI_ACT_LRELU) sl = yv[e] > 0.f ? 1.f : 0.2f;
-    else if (p.act == GI_ACT_RELU) sl = yv[e] > 0.f ? 1.f : 0.f;
-    dz[e] = g[e] * sl * p.drop_scale;
+    if (p.act == GI_ACT_LRELU) sl = pos ? 1.f : 0.2f;
+    else if (p.act == GI_ACT_RELU) sl = pos ? 1.f : 0.f;
+    dz[e] = g * sl * p.drop_scale;
   }
+}
+template <typename T, int EPC>
+__device__ __forceinline__ void compute_dz(const BwdP& p, int64_t pix, int ch0, float (&dz)[EPC]) {
+  DzIn<T, EPC> in;
+  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
+  load_dz<T, EPC>(p, pix, ch0, need_y, in);
+  if (!need_y) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) in.y[e] = 1.f;
+  }
+  finish_dz<T, EPC>(p, in, in.y, dz);
 }
 
 // pass 1: partial sums of dz and dz*xhat
@@ -210,10 +234,22 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
   const int so = r0 >= p.pg ? p.stat_stride : 0;
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { s[e] = sx[e] = 0.f; mu[e] = p.mean[so + q * EPC + e]; iv[e] = p.inv[so + q * EPC + e]; }
+  float sc[EPC], sh[EPC];
+  if (p.scale) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = p.scale[so + q * EPC + e]; sh[e] = p.shift[so + q * EPC + e]; }
+  }
+  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     float dz[EPC], xv[EPC];
-    compute_dz<T, EPC>(p, r, q * EPC, dz);
+    DzIn<T, EPC> in;
     load_vec<T, EPC>(p.x, r * p.c + q * EPC, xv);
+    load_dz<T, EPC>(p, r, q * EPC, need_y && !p.scale, in);
+    if (p.scale || !need_y) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) in.y[e] = p.scale ? fmaf(xv[e], sc[e], sh[e]) : 1.f;
+    }
+    finish_dz<T, EPC>(p, in, in.y, dz);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { s[e] += dz[e]; sx[e] = fmaf(dz[e], (xv[e] - mu[e]) * iv[e], sx[e]); }
   }
@@ -231,10 +267,14 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
 }
 
 // partials [rows][2][c] -> sums [2][c]; also accumulates dgamma/dbeta
-// groups > 1: `rows` partial rows per population, one after the other; sums [group][2][c]; the parameter gradients
-// accumulate population by population (the order of separate calls)
+// groups > 1: `rows` partial rows per population, one after the other; the parameter gradients accumulate population by
+// population (the order of separate calls). Output per population [8][c]: s1, s2, then the coefficients of the apply pass
+//   dx = k1*dz + k2*x + k3  (k1 = gamma*inv, k2 = -k1*inv*s2/M, k3 = -k1*s1/M - k2*mean)  and the forward's scale / shift.
+// rows = 0 (running-statistics BatchNorm): s1 = s2 = 0, dx = gamma*inv*dz.
 __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, int rows, int c, float* sums, float* dgamma,
-                                                       float* dbeta, float inv_loss_scale, int groups) {
+                                                       float* dbeta, float inv_loss_scale, int groups, const float* gamma,
+                                                       const float* mean, const float* inv, const float* scale,
+                                                       const float* shift, int stat_stride, float invM) {
   __shared__ double rs[256], rq[256];
   const int ch = blockIdx.x;
   for (int j = 0; j < groups; ++j) {
@@ -252,39 +292,76 @@ __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, in
       __syncthreads();
     }
     if (threadIdx.x == 0) {
-      sums[j * 2 * c + ch] = (float)rs[0];
-      sums[j * 2 * c + c + ch] = (float)rq[0];
-      if (dbeta) dbeta[ch] += (float)rs[0] * inv_loss_scale;
-      if (dgamma) dgamma[ch] += (float)rq[0] * inv_loss_scale;
+      float* o = sums + (int64_t)j * 8 * c;
+      const float s1 = (float)rs[0], s2 = (float)rq[0];
+      o[ch] = s1;
+      o[c + ch] = s2;
+      if (dbeta) dbeta[ch] += s1 * inv_loss_scale;
+      if (dgamma) dgamma[ch] += s2 * inv_loss_scale;
+      const int so = j * stat_stride + ch;
+      const float iv = inv[so];
+      const float k1 = gamma[ch] * iv;
+      const float k2 = -k1 * iv * s2 * invM;
+      o[2 * c + ch] = k1;
+      o[3 * c + ch] = k2;
+      o[4 * c + ch] = -k1 * s1 * invM - k2 * mean[so];
+      o[5 * c + ch] = scale ? scale[so] : 0.f;
+      o[6 * c + ch] = scale ? shift[so] : 0.f;
     }
     __syncthreads();
   }
 }
 
-// pass 2 (or the only pass when there is no BN): writes dx
-template <typename T, int HAS_BN>
+// pass 2 (or the only pass when there is no BN): writes dx. With BatchNorm
+//   dx = gamma*inv*(dz - s1/M - xhat*s2/M) = k1*dz + k2*x + k3,   k1 = gamma*inv, k2 = -k1*inv*s2/M, k3 = -k1*s1/M - k2*mean:
+// the grid stride is a multiple of the chunks per pixel, so a thread's channels never change and the coefficients
+// (both populations' with G2) stay in registers.
+template <typename T, int HAS_BN, bool G2>
 __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpp = p.c / EPC;
+  const int lg = 31 - __builtin_clz(cpp);
   const int64_t total = p.pixels * cpp;
-  const float invM = 1.f / (float)p.pg;
-  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int cc = (int)(gid % cpp);
-    const int64_t pix = gid / cpp;
+  const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cc = (int)(gid0 & (cpp - 1));
+  constexpr int NG = G2 ? 2 : 1;
+  float k1[NG][EPC], k2[NG][EPC], k3[NG][EPC], sc[NG][EPC], sh[NG][EPC];
+  if (HAS_BN) {   // coefficient rows written by bwd_sums_kernel: [group][8][c]
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float* o = p.sums + (int64_t)g * 8 * p.c + cc * EPC;
+      load_f32<EPC>(o + 2 * p.c, k1[g]);
+      load_f32<EPC>(o + 3 * p.c, k2[g]);
+      load_f32<EPC>(o + 4 * p.c, k3[g]);
+      if (p.scale) {
+        load_f32<EPC>(o + 5 * p.c, sc[g]);
+        load_f32<EPC>(o + 6 * p.c, sh[g]);
+      }
+    }
+  }
+  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
+  for (int64_t gid = gid0; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int64_t pix = gid >> lg;
     float dz[EPC];
-    compute_dz<T, EPC>(p, pix, cc * EPC, dz);
-    if (HAS_BN) {
+    if (!HAS_BN) {
+      compute_dz<T, EPC>(p, pix, cc * EPC, dz);
+    } else {
       float xv[EPC];
+      DzIn<T, EPC> in;
       load_vec<T, EPC>(p.x, pix * p.c + cc * EPC, xv);
-      const bool second = pix >= p.pg;
-      const float* mean = p.mean + (second ? p.stat_stride : 0);
-      const float* inv = p.inv + (second ? p.stat_stride : 0);
-      const float* sums = p.sums + (second ? 2 * p.c : 0);
+      load_dz<T, EPC>(p, pix, cc * EPC, need_y && !p.scale, in);
+      const int g = (G2 && pix >= p.pg) ? 1 : 0;
+      if (p.scale || !need_y) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) in.y[e] = p.scale ? fmaf(xv[e], G2 ? (g ? sc[NG - 1][e] : sc[0][e]) : sc[0][e], G2 ? (g ? sh[NG - 1][e] : sh[0][e]) : sh[0][e]) : 1.f;
+      }
+      finish_dz<T, EPC>(p, in, in.y, dz);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        const int ch = cc * EPC + e;
-        const float xh = (xv[e] - mean[ch]) * inv[ch];
-        dz[e] = p.gamma[ch] * inv[ch] * (dz[e] - sums[ch] * invM - xh * sums[p.c + ch] * invM);
+        const float a1 = G2 ? (g ? k1[NG - 1][e] : k1[0][e]) : k1[0][e];
+        const float a2 = G2 ? (g ? k2[NG - 1][e] : k2[0][e]) : k2[0][e];
+        const float a3 = G2 ? (g ? k3[NG - 1][e] : k3[0][e]) : k3[0][e];
+        dz[e] = fmaf(a1, dz[e], fmaf(a2, xv[e], a3));
       }
     }
     store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, dz);
@@ -794,18 +871,21 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   p.pixels = a.pixels; p.c = a.c; p.act = a.act; p.drop_scale = a.drop_scale;
   p.gamma = a.gamma; p.mean = a.save_mean; p.inv = a.save_invstd;
   p.partials = a.partials; p.sums = a.sums;
+  p.scale = a.has_bn ? a.fwd_scale : nullptr; p.shift = a.has_bn ? a.fwd_shift : nullptr;
   const int groups = (a.groups == 2 && a.has_bn && !a.eval_bn) ? 2 : 1;
   GI_REQUIRE(a.groups <= 1 || groups == 2, "act_bn_bwd: groups=%d needs a train-mode BatchNorm", a.groups);
   GI_REQUIRE(a.pixels % groups == 0, "act_bn_bwd: %lld pixels in %d groups", (long long)a.pixels, groups);
   p.pg = a.pixels / groups; p.stat_stride = a.stat_stride;
   int blocks = 0;   // per population
   p.rows_per_block = rows_per_block_for(p.pg, &blocks);
-  const int grid2 = nblocks(a.pixels * Q, 2);
+  const int grid2 = nblocks(a.pixels * Q, 4);
   if (a.has_bn && a.eval_bn) {
     // running-statistics BatchNorm is a per-channel affine map: the batch-mean terms vanish (sums = 0)
-    GI_HIP(hipMemsetAsync(a.sums, 0, sizeof(float) * 2 * a.c, st));
-    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1>), dim3(grid2), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1>), dim3(grid2), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, 0, a.c, a.sums, (float*)nullptr, (float*)nullptr, 0.f, 1,
+                       a.gamma, a.save_mean, a.save_invstd, p.scale, p.shift, 0, 0.f);
+    GI_LAUNCH_CHECK();
+    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1, false>), dim3(grid2), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1, false>), dim3(grid2), dim3(256), 0, st, p);
   } else if (a.has_bn) {
     GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
                (long long)p.pg, p.rows_per_block);
@@ -813,13 +893,18 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
     else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
     GI_LAUNCH_CHECK();
     hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, blocks, a.c, a.sums, a.dgamma, a.dbeta, a.inv_loss_scale,
-                       groups);
+                       groups, a.gamma, a.save_mean, a.save_invstd, p.scale, p.shift, a.stat_stride, 1.f / (float)p.pg);
     GI_LAUNCH_CHECK();
-    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1>), dim3(grid2), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1>), dim3(grid2), dim3(256), 0, st, p);
+    if (groups == 2) {
+      if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1, true>), dim3(grid2), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1, true>), dim3(grid2), dim3(256), 0, st, p);
+    } else {
+      if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 1, false>), dim3(grid2), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 1, false>), dim3(grid2), dim3(256), 0, st, p);
+    }
   } else {
-    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 0>), dim3(grid2), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 0>), dim3(grid2), dim3(256), 0, st, p);
+    if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 0, false>), dim3(grid2), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 0, false>), dim3(grid2), dim3(256), 0, st, p);
   }
   GI_LAUNCH_CHECK();
   return GI_OK;

@@ -233,7 +233,7 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
-  net->oSums = A.take(2 * maxc * 4);
+  net->oSums = A.take(8 * maxc * 4);   // [8][c]: sums + apply coefficients
   // split-K scratch: one fp32 buffer per split (split x output ~ 384 tiles of 128 x 128) for the deterministic path
   if (maxSplit > 0) maxSplit = max64(maxSplit, (int64_t)400 * 128 * 128 * 4);
   net->split_bytes = maxSplit;
@@ -321,7 +321,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oD = A.take(maxD);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
-  net->oSums = A.take(2 * 2 * 512 * 4);   // [groups][2][c]
+  net->oSums = A.take(2 * 8 * 512 * 4);   // [groups][8][c]: sums + apply coefficients
   if (maxSplit > 0) maxSplit = max64(maxSplit, (int64_t)400 * 128 * 128 * 4);
   net->split_bytes = maxSplit;
   net->oSplit = A.take(maxSplit > 0 ? maxSplit : 16);
@@ -603,6 +603,7 @@ int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, cons
     if (bn) {
       BNPtrs p = bn_ptrs(net, slot, *bn, j);
       a.gamma = net->params + bn->gamma_off; a.save_mean = p.mean; a.save_invstd = p.inv;
+      if (drop_scale == 1.f && x) { a.fwd_scale = p.scale; a.fwd_shift = p.shift; }   // dropout zeros live only in y
       a.dgamma = need_wgrad ? net->grads + bn->gamma_off : nullptr;
       a.dbeta = need_wgrad ? net->grads + bn->beta_off : nullptr;
     }
