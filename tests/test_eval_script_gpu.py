@@ -83,3 +83,41 @@ def test_eval_script_train_mode_default(tmp_path):
     assert torch.isfinite(a[1]).all() and float(a[1].abs().max()) <= 1.0
     # batch statistics + dropout (seeded per network handle, so repeatable) against running statistics: far apart
     assert float((a[1] - b[1]).abs().mean()) > 1e-2
+
+
+def test_local_mse_script_matches_oracle(tmp_path):
+    """local_mse.py mirror: masked-region MSE of the raw generator output per checkpoint, train and test sets."""
+    pytest.importorskip("PIL")
+    from gan_inpainting_amd import local_mse as lm
+    root = tmp_path / "data"
+    df, G, M = _dataset(root, 6, 128)
+    (root / "csv").mkdir()
+    df.to_csv(root / "csv" / "train_all_masks.csv", index=False)
+    df.iloc[:3].to_csv(root / "csv" / "test_all_masks.csv", index=False)
+    exp_root = tmp_path / "model" / "wgan_rmse"
+    (exp_root / "run1").mkdir(parents=True)
+    P = {20: op.make_unet_params(41), 5: op.make_unet_params(42)}
+    for ep, p in P.items():
+        torch.save({k: torch.from_numpy(np.array(v)) for k, v in p.items()}, exp_root / "run1" / f"epoch{ep}_G.pt")
+    metric, path = lm.main(["--exp-root", str(exp_root), "--data", str(root), "--imagedim", "128", "--batchsize", "3", "--dtype", "fp32",
+                            "--eval-mode", "--seed", "1"])
+    assert list(metric["test"]) == [5, 20] and list(metric["train"]) == [5, 20]      # sorted by epoch
+    with open(path, "rb") as f:
+        assert pickle.load(f) == metric
+
+    def oracle(p, idx_batches):
+        PT = {k: torch.from_numpy(np.array(v)) for k, v in p.items()}
+        tot = 0.0
+        for idx in idx_batches:
+            g = torch.from_numpy(G[idx].astype(np.float32) / 255.0)[:, None]
+            m = torch.ceil(torch.from_numpy(M[idx].astype(np.float32) / 255.0)[:, None])
+            y = orc.unet_forward(PT, g * (1 - m), 7, False, None)
+            tot += float((((g * m) - (y * m)) ** 2).sum() / (m != 0).float().sum())
+        return tot / len(idx_batches)
+    for ep, p in P.items():
+        want = oracle(p, [np.arange(0, 3)])
+        assert abs(metric["test"][ep] - want) <= 1e-4 * max(1.0, abs(want)), (ep, metric["test"][ep], want)
+    # the train loader is shuffled: whatever the grouping, a batch's sum/count is a weighted mean of its images'
+    # ratios, so the reported mean over batches lies between the smallest and the largest per-image value
+    per_image = [oracle(P[5], [np.array([i])]) for i in range(6)]
+    assert min(per_image) * (1 - 1e-4) <= metric["train"][5] <= max(per_image) * (1 + 1e-4)
