@@ -405,7 +405,10 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   kp.nk = kp.Ktot / 64;
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
+  kp.dbg = 0;
+#ifdef GI_ABLATION   // timing-only ablation kernels compute wrong results: compiled only with `build.sh -DGI_ABLATION`
   { const char* e = getenv("GI_IGEMM3_DBG"); kp.dbg = e ? atoi(e) : 0; }
+#endif
   if (mode == 1) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
   else if (mode == 2) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
   else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
@@ -424,6 +427,7 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   const int vi = (BN == 64 ? 3 : 0) + mode;
   if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX)); attr_set[vi] = true; }
   const dim3 g(grid), b(512);
+#ifdef GI_ABLATION
   if (kp.dbg && vi == 1) {   // timing-only ablation builds of the PHASE / 128 kernel (GI_IGEMM3_DBG, tools only)
     static bool dbg_attr = false;
     if (!dbg_attr) {
@@ -449,6 +453,7 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
     a.ntiles_out = kp.mtiles * nph;
     return GI_OK;
   }
+#endif
   switch (vi) {
     case 0: hipLaunchKernelGGL((igemm3_kernel<0, 128, 8>), g, b, LDS, st, kp); break;
     case 1: hipLaunchKernelGGL((igemm3_kernel<1, 128, 8>), g, b, LDS, st, kp); break;
