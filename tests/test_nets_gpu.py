@@ -169,6 +169,29 @@ def test_patchgan_vs_oracle(dtype, cfg):
         assert fx["out_sig"].shape[1] == 1
 
 
+@pytest.mark.parametrize("cfg", [(64, 5), (256, 4), (512, 1)])
+def test_patchgan_head_gradients_are_reproducible(cfg):
+    """fp16 head kernels (csrc/c1.hip: head_fwd512 / head_bwd512 / head_wsum512): the weight-gradient partials are
+    summed in a fixed order, so the head's parameter gradients and the network output repeat bit for bit
+    (the 4x4, 16x16 and 32x32 feature maps: one tile, LDS-resident map, dynamic-LDS path above 64 KiB)."""
+    HW, N = cfg
+    P = op.make_patchgan_params(300 + HW, HW, HW)
+    ground, _ = op.synth_batch(301 + HW, N, HW, HW)
+    runs = []
+    for _ in range(2):
+        net = make_d(P, HW, False, "fp16")
+        x = torch.from_numpy(ground).cuda().requires_grad_(True)
+        y = net(x)
+        y.sum().backward()
+        g = {k: v.grad.detach().cpu().clone() for k, v in net.named_parameters() if k.startswith(("model.11.", "model.13."))}
+        runs.append((y.detach().cpu().clone(), g))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert set(runs[0][1]) == {"model.11.weight", "model.13.weight", "model.13.bias"}
+    for k in runs[0][1]:
+        assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+        assert torch.isfinite(runs[0][1][k]).all() and float(runs[0][1][k].abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_patchgan_vs_golden(dtype):
     fx = load("patchgan128")
