@@ -42,6 +42,17 @@ __device__ __forceinline__ void store_vec(char* base, int64_t elem_off, const fl
   }
 }
 
+// two block-wide sums at once (256 threads): wave shuffles, then one LDS exchange of the four wave totals.
+// Fixed order, so results repeat. sh: 8 doubles.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh) {
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+  __syncthreads();   // sh may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = a; sh[4 + (threadIdx.x >> 6)] = b; }
+  __syncthreads();
+  a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+}
+
 // ---- BatchNorm statistics --------------------------------------------------------------------
 // partials [rows][2][c] -> per-channel scale/shift (+ running-stat update in train mode).
 // nn.BatchNorm2d semantics (lib/models/networks.py:38): biased variance for normalisation,
@@ -53,29 +64,23 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials,
                                                           int64_t part_stride, int out_stride) {
   // groups > 1: consecutive BatchNorm populations (stacked critic batch); group j's partial rows start at
   // partials + j*part_stride, its outputs at +j*out_stride; running statistics are updated in group order
-  __shared__ double rs[256], rq[256];
+  __shared__ double sh[8];
   const int ch = blockIdx.x;
   for (int j = 0; j < groups; ++j) {
     float mean = 0.f, var = 1.f;
+    double s = 0.0, q = 0.0;
     if (train) {
       const float* pj = partials + (int64_t)j * part_stride;
-      double s = 0.0, q = 0.0;
       for (int r = threadIdx.x; r < rows; r += 256) {
         s += (double)pj[((int64_t)r * 2) * c + ch];
         q += (double)pj[((int64_t)r * 2 + 1) * c + ch];
       }
-      rs[threadIdx.x] = s;
-      rq[threadIdx.x] = q;
-      __syncthreads();
-      for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
-        __syncthreads();
-      }
+      block_sum2(s, q, sh);
     }
     if (threadIdx.x == 0) {
       if (train) {
-        const double m = rs[0] / count;
-        double v = rq[0] / count - m * m;
+        const double m = s / count;
+        double v = q / count - m * m;
         if (v < 0.0) v = 0.0;
         mean = (float)m;
         var = (float)v;
@@ -94,7 +99,6 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials,
       smean[o] = mean;
       sinv[o] = inv;
     }
-    __syncthreads();   // rs / rq are reused by the next group
   }
 }
 
@@ -275,7 +279,7 @@ __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, in
                                                        float* dbeta, float inv_loss_scale, int groups, const float* gamma,
                                                        const float* mean, const float* inv, const float* scale,
                                                        const float* shift, int stat_stride, float invM) {
-  __shared__ double rs[256], rq[256];
+  __shared__ double sh[8];
   const int ch = blockIdx.x;
   for (int j = 0; j < groups; ++j) {
     const float* pj = partials + (int64_t)j * rows * 2 * c;
@@ -284,16 +288,10 @@ __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, in
       s += (double)pj[((int64_t)r * 2) * c + ch];
       q += (double)pj[((int64_t)r * 2 + 1) * c + ch];
     }
-    rs[threadIdx.x] = s;
-    rq[threadIdx.x] = q;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-      if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
-      __syncthreads();
-    }
+    block_sum2(s, q, sh);
     if (threadIdx.x == 0) {
       float* o = sums + (int64_t)j * 8 * c;
-      const float s1 = (float)rs[0], s2 = (float)rq[0];
+      const float s1 = (float)s, s2 = (float)q;
       o[ch] = s1;
       o[c + ch] = s2;
       if (dbeta) dbeta[ch] += s1 * inv_loss_scale;
@@ -308,7 +306,6 @@ __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, in
       o[5 * c + ch] = scale ? scale[so] : 0.f;
       o[6 * c + ch] = scale ? shift[so] : 0.f;
     }
-    __syncthreads();
   }
 }
 
