@@ -169,7 +169,7 @@ class _StepBase:
         self.sync.launch(flat, 0, split2)
         self.sync.wait(flat.device)
 
-    def _d_pair(self, net, real, fake, kind, t_real, t_fake, name_real, name_fake, gs_real=1.0, gs_fake=1.0, synced=False):
+    def _d_pair(self, net, real, fake, kind, t_real, t_fake, name_real, name_fake, gs_real=1.0, gs_fake=1.0, synced=False, x2=None):
         """A discriminator's two calls of a batch, D(real) and D(fake), as ONE [real | fake] batch whose BatchNorm
         layers are evaluated per half (gi_net_set_bn_groups): per image the reference's arithmetic, half the
         launches, one weight-gradient GEMM over both halves. Losses go to L[name_*], gradients accumulate."""
@@ -179,9 +179,12 @@ class _StepBase:
         if key not in bufs:
             bufs[key] = (torch.empty((2 * n,) + tuple(real.shape[1:]), dtype=torch.float32, device=real.device),
                          torch.empty((2 * n, 1), dtype=torch.float32, device=real.device))
-        x2, dp2 = bufs[key]
+        own, dp2 = bufs[key]
+        if x2 is None:
+            x2 = own
         x2[:n].copy_(real)
-        x2[n:].copy_(fake)
+        if fake.data_ptr() != x2[n:].data_ptr():      # the caller may have produced `fake` in the pair buffer already
+            x2[n:].copy_(fake)
         p, t = self._fwd(net, x2, bn_groups=2)
         o.adv(p[:n], kind, t_real, self._loss(name_real), dp2[:n], gs_real)
         o.adv(p[n:], kind, t_fake, self._loss(name_fake), dp2[n:], gs_fake)
@@ -302,9 +305,10 @@ class WGANStep(_StepBase):
         sD = self._sD
         k = self._k
         self._k ^= 1
-        if self._inp2[k] is None:
-            self._inp2[k] = torch.empty_like(ground)
-        inp = self._inp2[k]
+        if self._inp2[k] is None or self._inp2[k].shape[0] != 2 * ground.shape[0] or self._inp2[k].shape[1:] != ground.shape[1:]:
+            # [ground | inpainted] of the stacked critic pass: the composite writes its half in place
+            self._inp2[k] = torch.empty((2 * ground.shape[0],) + tuple(ground.shape[1:]), dtype=ground.dtype, device=ground.device)
+        inp = self._inp2[k][ground.shape[0]:]
         if self._evD[k] is not None:
             main.wait_event(self._evD[k])        # the critic pass that read this buffer two batches ago is done
         e0 = main.record_event()
@@ -320,7 +324,7 @@ class WGANStep(_StepBase):
             self.optD.zero_grad()
             if self.stacked:
                 sD.wait_event(e_inp)
-                self._critic_stacked(ground, inp)
+                self._critic_stacked(ground, inp, x2=self._inp2[k])
             else:
                 pr, tr = self._fwd(self.D, ground)
                 o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)
@@ -389,11 +393,11 @@ class WGANStep(_StepBase):
             self.optG.step()
         return self.L
 
-    def _critic_stacked(self, ground, inp):
+    def _critic_stacked(self, ground, inp, x2=None):
         """D(ground) and D(inpainted) of wgan_l1.py:134-141 as one [ground | inpainted] batch, BatchNorm per half;
         backward(one) / backward(mone) are the gradient scales +1 / -1."""
         synced = self.sync is not None and self.sync.world > 1 and self.gp_lambda <= 0
-        self._d_pair(self.D, ground, inp, MEAN, 0.0, 0.0, "d_loss_real", "d_loss_fake", +1.0, -1.0, synced=synced)
+        self._d_pair(self.D, ground, inp, MEAN, 0.0, 0.0, "d_loss_real", "d_loss_fake", +1.0, -1.0, synced=synced, x2=x2)
         self._d_synced = synced   # the all-reduce already overlapped the tail of the backward
 
     def _g_losses(self, inp, ground):
