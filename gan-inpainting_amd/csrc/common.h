@@ -99,6 +99,11 @@ struct IgemmArgs {
   int act_out;         // gi_act on the result
   int force_splitk;    // 0 = heuristic, >0 forces that split
   int ntiles_out;      // (returned) number of partial rows written
+  // optional fused activation backward on the result (input-gradient GEMMs): out *= (mask > 0 ? 1 : mask_slope), with
+  // mask the forward activation of the producing layer, laid out like out (pixels x channels, ld = ldmask). Kernels
+  // that implement it set mask_applied = 1; otherwise the caller runs the separate pass.
+  const void* mask; int ldmask, coffmask; float mask_slope;
+  int mask_applied;
 };
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
 

@@ -43,6 +43,7 @@ struct KP5 {
   int nchunk;         // cin / 64
   int relu_in, relu_cend, act_out;
   int ntiles;
+  const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
 };
 
 __device__ __forceinline__ float act5(float v, int act) {
@@ -337,8 +338,18 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   const int oc = tid % CPRO;
 #pragma unroll 1
   for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
-    const int64_t o = (int64_t)(out_pixel(r) + (DUAL ? (oc >> 3) : 0)) * p.ldout + p.coffout + n0 + (DUAL ? (oc & 7) : oc) * 8;
-    *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+    const int64_t opx = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
+    const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
+    const int64_t o = opx * p.ldout + p.coffout + och;
+    u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+    if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
+      const h8_t m = *(const h8_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
+      h8_t hv = __builtin_bit_cast(h8_t, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) hv[e] = (float)m[e] > 0.f ? hv[e] : (half_t)((float)hv[e] * p.mask_slope);
+      v = __builtin_bit_cast(u4_t, hv);
+    }
+    *(u4_t*)(p.out + o * 2) = v;
   }
 }
 
@@ -381,6 +392,11 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.nchunk = a.cin / 64;
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
+  kp.mask = (const char*)a.mask; kp.ldmask = a.ldmask; kp.coffmask = a.coffmask; kp.mask_slope = a.mask_slope;
+  if (a.mask) {
+    GI_REQUIRE(a.ldmask % 8 == 0 && a.coffmask % 8 == 0 && out_px * a.ldmask < (1ll << 31), "igemm5: mask layout");
+    a.mask_applied = 1;
+  }
   kp.ntiles = a.cout / BN;
   const int nyz = kp.ntiles * (dual ? 2 : nph);
   const int grid = ((mtiles + 7) / 8) * 8 * nyz;

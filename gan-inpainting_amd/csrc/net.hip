@@ -548,11 +548,14 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
   return GI_OK;
 }
 
+// mask / ldmask / mask_slope / mask_applied: IgemmArgs::mask (activation backward fused into an input-gradient GEMM)
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
-          int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0) {
+          int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
+          const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.relu_cend = relu_cend;
+  a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
   a.in = in; a.w = w; a.out = out; a.bias = nullptr;
   a.partials = stats ? (float*)net->shared(net->oPart) : nullptr;
   a.ws = net->split_bytes > 0 ? (float*)net->shared(net->oSplit) : nullptr;
@@ -562,6 +565,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   a.cout = cout; a.ldout = ldout; a.coffout = coffout;
   a.relu_in = relu_in; a.act_out = act_out;
   GI_TRY(op_igemm(net->ctx->stream, net->dtype, phase, a));
+  if (mask_applied) *mask_applied = a.mask_applied;
   if (ntiles) *ntiles = a.ntiles_out;
   if (stats) GI_REQUIRE((int64_t)a.ntiles_out * 2 * cout <= net->part_floats, "internal: partials buffer too small");
   return GI_OK;
@@ -883,6 +887,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   hb.scratch = (float*)net->shared(net->oHw); hb.scratch_bytes = net->hw_bytes;
   hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = net->sigmoid; hb.loss_scale = LS;
   if (phase != 2) GI_TRY(op_head_backward(st, dt, hb));
+  int lrelu1_done = 0;
   for (int i = 4; i >= 2; --i) {
     if (i == 4 ? phase == 2 : phase == 1) continue;
     const Conv& c = net->dconv[i];
@@ -892,16 +897,24 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
                       D, pix, c.ca, GI_ACT_LRELU, 1.f, &net->dbn[i], need_wgrad));
     if (need_wgrad)
       GI_TRY(wgrad(net, D, c.ca, c.ca, 0, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, net->grads + c.w_off));
+    // conv1 has no BatchNorm: its LeakyReLU backward rides in the epilogue of conv2's input-gradient GEMM when the
+    // kernel supports it (same arithmetic, one 3-tensor HBM pass less)
+    const bool fuse1 = (i == 2);
     GI_TRY(igemm(net, 1, D, c.ca, c.ca, 0, phase_ptr(net, c), net->shared(net->ogA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, 0, GI_ACT_NONE, false,
-                 nullptr));
+                 nullptr, 0, fuse1 ? net->slot(s, net->oA[1]) : nullptr, 64, 0.2f, fuse1 ? &lrelu1_done : nullptr));
   }
   if (phase == 1) return GI_OK;
   const int64_t pix = (int64_t)n * (H / 2) * (W / 2);
-  GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[1]), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D, pix, 64, GI_ACT_LRELU,
-                    1.f, nullptr, need_wgrad));
+  void* D1 = D;
+  if (lrelu1_done) {
+    D1 = net->shared(net->ogA[1]);
+  } else {
+    GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[1]), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D, pix, 64, GI_ACT_LRELU,
+                      1.f, nullptr, need_wgrad));
+  }
   if (need_wgrad)
-    GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f));
-  if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS,
+    GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f));
+  if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS,
                                net->shared(net->oCol)));
   return GI_OK;
 }
