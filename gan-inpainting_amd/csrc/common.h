@@ -103,6 +103,8 @@ struct IgemmArgs {
   // mask the forward activation of the producing layer, laid out like out (pixels x channels, ld = ldmask). Kernels
   // that implement it set mask_applied = 1; otherwise the caller runs the separate pass.
   const void* mask; int ldmask, coffmask; float mask_slope;
+  const void* add; int ldadd, coffadd;   // with mask: a second gradient added where mask > 0 before the slope (the skip
+                                         // half of a U-Net concat gradient, which passed the parent's in-place ReLU)
   int mask_applied;
 };
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);

@@ -44,6 +44,7 @@ struct KP5 {
   int relu_in, relu_cend, act_out;
   int ntiles;
   const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
+  const char* add; int ldadd, coffadd;
 };
 
 __device__ __forceinline__ float act5(float v, int act) {
@@ -345,8 +346,18 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
       const h8_t m = *(const h8_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
       h8_t hv = __builtin_bit_cast(h8_t, v);
+      if (p.add) {
+        const h8_t a8 = *(const h8_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) hv[e] = (float)m[e] > 0.f ? hv[e] : (half_t)((float)hv[e] * p.mask_slope);
+        for (int e = 0; e < 8; ++e) {
+          const bool pos = (float)m[e] > 0.f;
+          const float g = (float)hv[e] + (pos ? (float)a8[e] : 0.f);
+          hv[e] = (half_t)(pos ? g : g * p.mask_slope);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (float)m[e] > 0.f ? hv[e] : (half_t)((float)hv[e] * p.mask_slope);
+      }
       v = __builtin_bit_cast(u4_t, hv);
     }
     *(u4_t*)(p.out + o * 2) = v;
@@ -393,8 +404,10 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.relu_in = a.relu_in; kp.act_out = a.act_out;
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
   kp.mask = (const char*)a.mask; kp.ldmask = a.ldmask; kp.coffmask = a.coffmask; kp.mask_slope = a.mask_slope;
+  kp.add = a.mask ? (const char*)a.add : nullptr; kp.ldadd = a.ldadd; kp.coffadd = a.coffadd;
   if (a.mask) {
     GI_REQUIRE(a.ldmask % 8 == 0 && a.coffmask % 8 == 0 && out_px * a.ldmask < (1ll << 31), "igemm5: mask layout");
+    GI_REQUIRE(!a.add || (a.ldadd % 8 == 0 && a.coffadd % 8 == 0 && out_px * a.ldadd < (1ll << 31)), "igemm5: add layout");
     a.mask_applied = 1;
   }
   kp.ntiles = a.cout / BN;

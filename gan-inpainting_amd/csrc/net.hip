@@ -551,11 +551,13 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
 // mask / ldmask / mask_slope / mask_applied: IgemmArgs::mask (activation backward fused into an input-gradient GEMM)
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
-          const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr) {
+          const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
+          const void* add = nullptr, int ldadd = 0) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.relu_cend = relu_cend;
   a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
+  a.add = add; a.ldadd = ldadd; a.coffadd = 0;
   a.in = in; a.w = w; a.out = out; a.bias = nullptr;
   a.partials = stats ? (float*)net->shared(net->oPart) : nullptr;
   a.ws = net->split_bytes > 0 ? (float*)net->shared(net->oSplit) : nullptr;
@@ -799,6 +801,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   // the encoder half may be split once more: phase 3 = innermost .. level 5 (their parameter gradients, the bulk
   // of the encoder's, are complete first), phase 4 = levels 4 .. 1; phase 2 (or 0) runs both
   const bool run_inner = phase != 4, run_outer = phase != 3;
+  int lrelu1_done = 0;
   // innermost conv (no norm): dz = gE * [E > 0]
   if (run_inner) {
     const int c = net->ch[nd];
@@ -821,17 +824,22 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     const int cb = net->ch[k - 1];
     if (need_wgrad)
       GI_TRY(wgrad(net, D, c, c, 0, 0, C(k - 1), cb, 2 * cb, 0, n, net->Hk[k], net->Wk[k], net->grads + net->conv[k].w_off));
+    // d1 has no norm: its backward, (g + [y>0] * skip gradient) * LeakyReLU'(y), rides in the epilogue of d2's
+    // input-gradient GEMM when the kernel supports it (same arithmetic, one 4-tensor HBM pass less)
+    const bool fuse1 = (k == 2);
     GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[k]), gA(k - 1), cb, cb, 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE,
-                 false, nullptr));
+                 false, nullptr, 0, fuse1 ? C(1) : nullptr, 2 * cb, 0.2f, fuse1 ? &lrelu1_done : nullptr, fuse1 ? gC(1) : nullptr, 2 * cb));
   }
   if (run_outer) {
     const int c = net->ch[1];
     const int64_t pix = (int64_t)n * net->Hk[1] * net->Wk[1];
-    GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
+    void* D1 = D;
+    if (lrelu1_done) D1 = gA(1);
+    else GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
     if (need_wgrad)
-      GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c,
+      GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c,
                          0, 0, iLS, 1.f));
-    if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS,
+    if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS,
                                  net->shared(net->oCol)));
   }
   return GI_OK;
