@@ -73,3 +73,23 @@ def test_product_never_imports_the_oracle():
                     if pat.search(line):
                         bad.append(f"{os.path.join(d, f)}:{i}: {line.strip()}")
     assert not bad, bad
+
+
+def test_offline_scripts_host_logic(tmp_path):
+    """eval.py / local_mse.py mirrors: the reference's CLI names (eval.py:24-29), checkpoint discovery sorted by the
+    number after 'epoch' across sub-directories (local_mse.py:43-54); no device needed for either."""
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import eval as ev
+    from gan_inpainting_amd import local_mse as lm
+    a = ev.build_parser().parse_args(["-m", "M", "-d", "D", "-f", "F"])
+    assert (a.modelpath, a.datasetpath, a.csvfile, a.generator, a.batchsize, a.eval_mode) == ("M", "D", "F", "unet", 50, False)
+    assert ev.build_parser().parse_args(["--modelpath", "M", "--datasetpath", "D", "--csvfile", "F", "-g", "vgg19"]).generator == "vgg19"
+    for sub, name in (("a", "epoch100_G.pt"), ("a", "epoch20_G.pt"), ("b/c", "epoch3_G.pt"), ("b", "notes.txt")):
+        d = tmp_path / sub
+        d.mkdir(parents=True, exist_ok=True)
+        (d / name).write_bytes(b"")
+    found = lm.checkpoint_paths(str(tmp_path))
+    assert [ep for ep, _ in found] == [3, 20, 100]
+    assert all(p.endswith(f"epoch{ep}_G.pt") for ep, p in found)
+    b = lm.build_parser().parse_args(["--exp-root", "R", "--data", "D"])
+    assert (b.exp, b.imagedim, b.batchsize) == ("wgan_rmse", 128, 64)      # local_mse.py:40,56,69
