@@ -223,9 +223,13 @@ __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __rest
 // v_mfma_f32_16x16x32_f16; B fragments are 16-byte row loads of X straight from global memory (each
 // lane: 8 consecutive channels of its pixel), A fragments (the 16 x c weights) live in registers.
 // Each lane ends with 4 consecutive taps of one pixel -> one 8-byte store; a wave writes 512 B.
+// X2 != null: channels [c/2, c) are not read from X but produced on the fly as relu(fma(X2[p][ch - c/2], sc2, sh2)),
+// the BatchNorm + ReLU of the raw decoder output X2 (dense, ld2): the same fp32 expression and fp16 rounding as the
+// separate apply pass, which then never has to materialise that half of the concat buffer.
 template <int KS>   // KS = c / 32
 __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float* __restrict__ w, half_t* col,
-                                                     int64_t P, int ldx, int coffx, int relu_in) {
+                                                     int64_t P, int ldx, int coffx, int relu_in, const char* X2, int ld2,
+                                                     const float* __restrict__ sc2, const float* __restrict__ sh2) {
   const int lane = threadIdx.x & 63;
   const int tapr = lane & 15, kq = lane >> 4;
   h8_t af[KS];
@@ -233,6 +237,14 @@ __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float*
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int j = 0; j < 8; ++j) af[ks][j] = (half_t)w[(ks * 32 + kq * 8 + j) * 16 + tapr];
+  constexpr int KH = KS / 2;
+  float s2[KH][8], h2[KH][8];
+  if (X2) {
+#pragma unroll
+    for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s2[ks][j] = sc2[ks * 32 + kq * 8 + j]; h2[ks][j] = sh2[ks * 32 + kq * 8 + j]; }
+  }
   const int64_t ngroups = (P + 15) / 16;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
@@ -243,8 +255,17 @@ __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float*
     h8_t bf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
-      if (relu_in) bf[ks] = __builtin_elementwise_max(bf[ks], zero);
+      if (X2 && ks >= KH) {
+        const h8_t raw = live ? *(const h8_t*)(X2 + ((pix * ld2 + (ks - KH) * 32 + kq * 8) << 1)) : zero;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = fmaf((float)raw[j], s2[ks >= KH ? ks - KH : 0][j], h2[ks >= KH ? ks - KH : 0][j]);
+          bf[ks][j] = live ? (half_t)(t > 0.f ? t : 0.f) : (half_t)0.f;
+        }
+      } else {
+        bf[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
+        if (relu_in) bf[ks] = __builtin_elementwise_max(bf[ks], zero);
+      }
     }
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -454,7 +475,8 @@ __global__ void __launch_bounds__(256) c1_wgrad_kernel(const char* X, const floa
 template <int NT>   // NT = c / 16
 __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const float* __restrict__ img, float* dW,
                                                             int n, int Hs, int Ws, int ldx, int coffx, int relu_in,
-                                                            float scale, float img_scale) {
+                                                            float scale, float img_scale, const char* X2, int ld2,
+                                                            const float* __restrict__ sc2, const float* __restrict__ sh2) {
   constexpr int C = NT * 16;
   constexpr int LROW = C * 2 + 32;                  // padded LDS row: conflict-free transposing reads
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -475,9 +497,19 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
   const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
   const int g16 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
 
+  // X2 != null: the channel chunks of the upper half come from the raw decoder output through relu(fma(x, sc2, sh2))
+  const bool upper = X2 != nullptr && xc * 8 >= C / 2;
+  float s2[8], h2[8];
+  if (upper) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s2[j] = sc2[xc * 8 - C / 2 + j]; h2[j] = sh2[xc * 8 - C / 2 + j]; }
+  }
   auto load_x = [&](int64_t t, u4_t (&xv)[NP]) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) xv[i] = *(const u4_t*)(X + (((t * 32 + xr + RPP * i) * ldx + coffx) << 1) + xc * 16);
+    for (int i = 0; i < NP; ++i) {
+      const int64_t row = t * 32 + xr + RPP * i;
+      xv[i] = upper ? *(const u4_t*)(X2 + ((row * ld2 + xc * 8 - C / 2) << 1)) : *(const u4_t*)(X + ((row * ldx + coffx) << 1) + xc * 16);
+    }
   };
   auto load_a = [&](int64_t t, float (&av)[8]) {   // 8 pixels x0 + 8*kq + j of the tile's image row, tap (ky,kx)
     const int64_t p0 = t * 32;
@@ -507,7 +539,16 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       u4_t v = xv[i];
-      if (relu_in) {
+      if (upper) {
+        const h8_t raw = __builtin_bit_cast(h8_t, v);
+        h8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float tt = fmaf((float)raw[j], s2[j], h2[j]);
+          o[j] = (half_t)(tt > 0.f ? tt : 0.f);
+        }
+        v = __builtin_bit_cast(u4_t, o);
+      } else if (relu_in) {
         typedef short s8_t __attribute__((ext_vector_type(8)));
         s8_t hh = __builtin_bit_cast(s8_t, v);
         const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -980,15 +1021,25 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
   return GI_OK;
 }
 
+bool op_c1_affine_ok(int dtype, int c, int Ws, int ldx, int coffx) {
+  return dtype == GI_F16 && (c == 64 || c == 128) && Ws % 32 == 0 && ldx % 8 == 0 && coffx % 8 == 0;
+}
+
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img, int n, int Hs,
-                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale, void* col_scratch, float* img2) {
+                  int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale, void* col_scratch, float* img2,
+                  const C1Affine* aff) {
+  GI_REQUIRE(!aff || (col_scratch && op_c1_affine_ok(dtype, c, Ws, ldx, coffx) && aff->ld2 % 8 == 0), "c1_scatter: fused upper half unsupported here");
   if (dtype == GI_F16 && col_scratch && (c == 64 || c == 128) && ldx % 8 == 0 && coffx % 8 == 0) {
     const int64_t P = (int64_t)n * Hs * Ws;
     const int grid = grid_for((P + 15) / 16, 4, 256 * 8);
+    const char* x2 = aff ? (const char*)aff->x2 : nullptr;
+    const int ld2 = aff ? aff->ld2 : 0;
+    const float* sc2 = aff ? aff->scale : nullptr;
+    const float* sh2 = aff ? aff->shift : nullptr;
     if (c == 128)
-      hipLaunchKernelGGL(c1_col_kernel<4>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in);
+      hipLaunchKernelGGL(c1_col_kernel<4>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in, x2, ld2, sc2, sh2);
     else
-      hipLaunchKernelGGL(c1_col_kernel<2>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in);
+      hipLaunchKernelGGL(c1_col_kernel<2>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in, x2, ld2, sc2, sh2);
     GI_LAUNCH_CHECK();
     hipLaunchKernelGGL(c1_col2im_kernel, dim3(grid_for(P, 256, 256 * 8)), dim3(256), 0, st, (const half_t*)col_scratch, bias, img, img2, n, Hs,
                        Ws, post, out_scale);
@@ -1012,7 +1063,12 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
 }
 
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws, int c,
-                int ldx, int coffx, int relu_in, float scale, float img_scale) {
+                int ldx, int coffx, int relu_in, float scale, float img_scale, const C1Affine* aff) {
+  GI_REQUIRE(!aff || (op_c1_affine_ok(dtype, c, Ws, ldx, coffx) && aff->ld2 % 8 == 0), "c1_wgrad: fused upper half unsupported here");
+  const char* x2 = aff ? (const char*)aff->x2 : nullptr;
+  const int ld2 = aff ? aff->ld2 : 0;
+  const float* sc2 = aff ? aff->scale : nullptr;
+  const float* sh2 = aff ? aff->shift : nullptr;
   if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 32 == 0 && ldx % 8 == 0 && coffx % 8 == 0) {
     const int64_t ntiles = (int64_t)n * Hs * Ws / 32;
     int grid = (int)((ntiles + 3) / 4);
@@ -1021,10 +1077,10 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
     if (lds < (size_t)4 * c * 16 * 4) lds = (size_t)4 * c * 16 * 4;
     if (c == 64)
       hipLaunchKernelGGL(c1_wgrad_mfma_kernel<4>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
-                         scale, img_scale);
+                         scale, img_scale, x2, ld2, sc2, sh2);
     else
       hipLaunchKernelGGL(c1_wgrad_mfma_kernel<8>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
-                         scale, img_scale);
+                         scale, img_scale, x2, ld2, sc2, sh2);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }

@@ -132,12 +132,16 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
 // img[n,Y,X] = post( bias + sum_{c,tap} relu?(X[p][c]) * w[c][tap] ) (overlap-add of the 4x4 taps)
 // post: 0 none, 1 tanh. img fp32 (n,2Hs,2Ws); out_scale multiplies the result (loss-scale removal)
 // col_scratch (fp16 path): >= n*Hs*Ws*16 halves; null selects the register-reduction kernel
+// Fused producer for the upper half of a c1 kernel's input channels: relu(fma(x2, scale, shift)) of a dense raw tensor
+// (the BatchNorm + ReLU of the last decoder level), instead of reading that half from X.
+struct C1Affine { const void* x2; int ld2; const float* scale; const float* shift; };
+bool op_c1_affine_ok(int dtype, int c, int Ws, int ldx, int coffx);
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img,
                   int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale,
-                  void* col_scratch, float* img2 = nullptr);
+                  void* col_scratch, float* img2 = nullptr, const C1Affine* aff = nullptr);
 // dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx]
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws,
-                int c, int ldx, int coffx, int relu_in, float scale, float img_scale);
+                int c, int ldx, int coffx, int relu_in, float scale, float img_scale, const C1Affine* aff = nullptr);
 
 // BatchNorm helpers -------------------------------------------------------------------------
 // partials [rows][2][c] -> scale/shift (y = x*scale + shift), saved mean / invstd; train mode also

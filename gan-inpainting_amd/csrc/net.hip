@@ -80,6 +80,8 @@ struct gi_net {
   int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1, oCol = -1;
   int64_t part_floats = 0, split_bytes = 0;
   int64_t oHw = -1, hw_bytes = 0;    // head weight-gradient partials
+  int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
+  std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
   // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
@@ -262,6 +264,8 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->slot_base = A.take(S.size * n_slots);
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
+  net->slot_fused_u2.assign(n_slots, 0);
+  { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }   // 0: materialise the last decoder level (tools: A/B)
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
   return GI_OK;
@@ -509,8 +513,9 @@ BNPtrs bn_ptrs(const gi_net* net, int slot, const BN& b, int group = 0) {
 // With bn_groups = g the batch is g consecutive groups of pixels/g pixels, each normalised with its OWN batch
 // statistics (the reference calls the critic separately on the real and on the fake batch: two BatchNorm
 // populations, running statistics updated group by group in that order).
+// apply = false: statistics / scale / shift only (a consumer applies the affine map itself, C1Affine)
 int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixels, int ntiles, void* dst, int ldy,
-               int coffy, int act, const uint8_t* drop, float drop_scale, int train) {
+               int coffy, int act, const uint8_t* drop, float drop_scale, int train, bool apply = true) {
   hipStream_t st = net->ctx->stream;
   const int g = net->kind == 1 ? net->bn_groups : 1;
   const int64_t pg = pixels / g;
@@ -542,8 +547,9 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
     }
     GI_TRY(op_bn_finalize(st, part, rows, b.c, pg, net->params + b.gamma_off, net->params + b.beta_off, net->buffers + b.rmean_off,
                           net->buffers + b.rvar_off, p.scale, p.shift, p.mean, p.inv, train, 0.1f, 1e-5f));
-    GI_TRY(op_bn_apply(st, net->dtype, rj, (char*)dst + (int64_t)j * pg * ldy * T, pg, b.c, ldy, coffy, p.scale, p.shift, act,
-                       drop ? drop + (int64_t)j * pg * b.c : nullptr, drop_scale));
+    if (apply)
+      GI_TRY(op_bn_apply(st, net->dtype, rj, (char*)dst + (int64_t)j * pg * ldy * T, pg, b.c, ldy, coffy, p.scale, p.shift, act,
+                         drop ? drop + (int64_t)j * pg * b.c : nullptr, drop_scale));
   }
   return GI_OK;
 }
@@ -673,6 +679,8 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   const int H = net->H, W = net->W;
   net->slot_n[s] = n;
   net->slot_train[s] = train;
+  const bool fuse_u2 = nd >= 3 && net->out_c == 1 && net->fuse_head && op_c1_affine_ok(dt, 2 * net->ch[1], net->Wk[1], 2 * net->ch[1], 0);
+  net->slot_fused_u2[s] = fuse_u2 ? 1 : 0;
   auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
   GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   // d1: Conv2d(1->ngf) then the next block's in-place LeakyReLU (networks.py:287): the skip IS lrelu(x)
@@ -712,13 +720,21 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     }
     // the decoder half is only ever consumed through the parent's in-place ReLU (networks.py:289): store
     // relu(u) so that consumers need the ReLU on the skip half only; [u > 0] masks are unchanged
+    // the last decoder level feeds only the single-channel head: its BatchNorm + ReLU is applied by the head's
+    // kernels while they read the raw tensor (C1Affine), so the upper half of C(1) is never written
+    const bool fused = (k == 2) && fuse_u2;
     GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_RELU, drop,
-                      drop ? 1.f / (1.f - net->dropout_p) : 1.f, train));
+                      drop ? 1.f / (1.f - net->dropout_p) : 1.f, train, !fused));
   }
   float* osave = (float*)net->slot(s, net->oOut);
   if (net->out_c == 1) {
+    C1Affine aff;
+    if (fuse_u2) {
+      BNPtrs p = bn_ptrs(net, s, net->unorm[2]);
+      aff.x2 = net->slot(s, net->oU[2]); aff.ld2 = net->ch[1]; aff.scale = p.scale; aff.shift = p.shift;
+    }
     GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
-                         net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y));
+                         net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y, fuse_u2 ? &aff : nullptr));
     return GI_OK;   // y written beside the saved output
   } else {
     // u1 with out_c channels: the same sub-pixel GEMM as the other up-convolutions on weights zero-padded to 64
@@ -768,7 +784,13 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   if (need_wgrad) {
     hipLaunchKernelGGL(sum_acc_kernel, dim3(256), dim3(256), 0, st, G0, npx, net->grads + net->up[1].bias_off, iLS);
     GI_LAUNCH_CHECK();
-    GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f));
+    C1Affine aff;
+    const bool fused = net->slot_fused_u2[s] != 0;
+    if (fused) {   // the upper half of C(1) was never written (unet_forward): recompute it from the raw decoder output
+      BNPtrs p = bn_ptrs(net, s, net->unorm[2]);
+      aff.x2 = net->slot(s, net->oU[2]); aff.ld2 = net->ch[1]; aff.scale = p.scale; aff.shift = p.shift;
+    }
+    GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, fused ? &aff : nullptr));
   }
   if (net->out_c == 1) {
     GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
