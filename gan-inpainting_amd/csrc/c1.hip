@@ -730,12 +730,22 @@ constexpr int HT_PITCH = 17;   // floats per pixel row of t in LDS (16 taps + 1:
 __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restrict__ a4, const float* __restrict__ w5,
                                                            const float* __restrict__ wl, const float* __restrict__ bl,
                                                            float* __restrict__ h, float* __restrict__ out,
-                                                           float* __restrict__ out2, int Hh, int Wh, int sigmoid) {
-  extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] | 16 partial sums | w5 as fp16 [16 taps][512]
+                                                           float* __restrict__ out2, int Hh, int Wh, int sigmoid,
+                                                           const float* __restrict__ sc4, const float* __restrict__ sh4,
+                                                           int n_per_group, int gstride) {
+  // sc4 != null: a4 is the RAW conv4 output; LeakyReLU(fma(x, sc4, sh4)) (the layer's BatchNorm + activation, the
+  // population of image nn at +gstride floats) is applied to the fragments as they are loaded, the same fp32
+  // expression and fp16 rounding as the separate apply pass
+  extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] | 16 partial sums | w5 as fp16 [16 taps][512] | scale, shift [2][512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nn = blockIdx.x, npx = Hh * Wh;
   float* red = t_lds + ((npx * HT_PITCH + 3) & ~3);   // 16-byte aligned
   half_t* wh = (half_t*)(red + 16);
+  float* aff = (float*)(wh + 16 * 512);
+  if (sc4) {
+    const int go = (nn / n_per_group) * gstride;
+    for (int i = threadIdx.x; i < 512; i += 1024) { aff[i] = sc4[go + i]; aff[512 + i] = sh4[go + i]; }
+  }
   for (int i = threadIdx.x; i < 16 * 512 / 4; i += 1024) {
     const f4_t v = *(const f4_t*)(w5 + i * 4);
     *(h4_t*)(wh + i * 4) = h4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -751,6 +761,18 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
     h8_t av[16];
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) av[ks] = *(const h8_t*)(row + ks * 64);
+    if (sc4) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float* a0 = aff + ks * 32 + (lane >> 4) * 8;
+        const f4_t s0 = *(const f4_t*)a0, s1 = *(const f4_t*)(a0 + 4), h0 = *(const f4_t*)(a0 + 512), h1 = *(const f4_t*)(a0 + 516);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = fmaf((float)av[ks][j], j < 4 ? s0[j & 3] : s1[j & 3], j < 4 ? h0[j & 3] : h1[j & 3]);
+          av[ks][j] = (half_t)(t > 0.f ? t : 0.2f * t);
+        }
+      }
+    }
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[ks], bf[ks], acc, 0, 0, 0);
@@ -798,7 +820,9 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
                                                           const float* __restrict__ w5, const char* __restrict__ a4,
                                                           char* __restrict__ da4, float* __restrict__ part,
                                                           float* __restrict__ dwl, float* __restrict__ dbl, int n, int Hh,
-                                                          int Wh, int bands, int sigmoid, float loss_scale) {
+                                                          int Wh, int bands, int sigmoid, float loss_scale,
+                                                          const float* __restrict__ sc4, const float* __restrict__ sh4,
+                                                          int n_per_group, int gstride) {
   __shared__ float red[2 * 16 * 512];   // 64 KiB: two waves' accumulators at a time
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -851,6 +875,12 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
   for (int tap = 0; tap < 16; ++tap)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[tap][e] = 0.f;
+  float s4[8], h4[8];   // sc4 != null: a4 is the raw conv4 output (see head_fwd512_kernel); a lane owns 8 channels
+  if (sc4) {
+    const int go = (nn / n_per_group) * gstride + lane * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s4[e] = sc4[go + e]; h4[e] = sh4[go + e]; }
+  }
   const char* arow = a4 + (int64_t)nn * npx * 1024 + lane * 16;
   for (int qb = q0 + wave; qb < q1; qb += 32) {   // 8 pixel rows in flight per wave
     h8_t v[8];
@@ -868,6 +898,13 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
       float vf[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) vf[e] = (float)v[jx][e];
+      if (sc4) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float t = fmaf(vf[e], s4[e], h4[e]);
+          vf[e] = (float)(half_t)(t > 0.f ? t : 0.2f * t);
+        }
+      }
 #pragma unroll
       for (int tap = 0; tap < 16; ++tap)
 #pragma unroll
@@ -975,6 +1012,8 @@ int grid_for(int64_t work_items, int per_block, int cap) {
 }
 
 }  // namespace
+
+bool op_head_affine_ok(int dtype, int c) { return dtype == GI_F16 && c == 512 && head_fast(); }
 
 int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh) {
   (void)Hh; (void)Wh;   // n * head_bands(n, .) < 512 while bands > 1, = n otherwise
@@ -1108,14 +1147,16 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
   const int Ph = a.Hh - 3, Pw = a.Wh - 3;
   GI_REQUIRE(Ph >= 1 && Pw >= 1, "head: feature map %dx%d too small", a.Hh, a.Wh);
   const int blocks = a.n * Ph * Pw;
+  GI_REQUIRE(!a.scale4 || op_head_affine_ok(dtype, a.c), "head: fused BatchNorm input needs the fp16 c=512 kernels");
   if (dtype == GI_F16 && a.c == 512 && head_fast()) {
-    const int lds = (((a.Hh * a.Wh * HT_PITCH + 3) & ~3) + 16) * 4 + 16 * 512 * 2;
+    const int lds = (((a.Hh * a.Wh * HT_PITCH + 3) & ~3) + 16) * 4 + 16 * 512 * 2 + 2 * 512 * 4;
     GI_REQUIRE(lds <= 160 * 1024, "head: feature map %dx%d too large", a.Hh, a.Wh);
     if (lds > 64 * 1024) {
       static bool attr = false;
       if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     }
-    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid);
+    hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid,
+                       a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
@@ -1132,13 +1173,16 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
 
 int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
   const int Ph = a.Hh - 3, Pw = a.Wh - 3, P = Ph * Pw;
+  GI_REQUIRE(!a.scale4 || (op_head_affine_ok(dtype, a.c) && (!a.dw5 || (a.scratch && a.scratch_bytes >= (int64_t)a.n * head_bands(a.n, a.Hh * a.Wh) * 8192 * 4))),
+             "head: fused BatchNorm input needs the fp16 c=512 kernels");
   if (dtype == GI_F16 && a.c == 512 && head_fast()) {
     const int bands = head_bands(a.n, a.Hh * a.Wh), nb = a.n * bands;
     const bool wg = a.dw5 != nullptr;
     if (!wg || (a.scratch && a.scratch_bytes >= (int64_t)nb * 8192 * 4)) {
       GI_REQUIRE(!wg || a.dwl, "head: dw5 without dwl");
       hipLaunchKernelGGL(head_bwd512_kernel, dim3(wg ? 2 * nb : nb), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.w5, (const char*)a.a4,
-                         (char*)a.da4, a.scratch, a.dwl, a.dbl, a.n, a.Hh, a.Wh, bands, a.sigmoid, a.loss_scale);
+                         (char*)a.da4, a.scratch, a.dwl, a.dbl, a.n, a.Hh, a.Wh, bands, a.sigmoid, a.loss_scale,
+                         a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride);
       GI_LAUNCH_CHECK();
       if (wg) {
         hipLaunchKernelGGL(head_wsum512_kernel, dim3(256 + P + 1), dim3(256), 0, st, a.scratch, nb, a.dw5, a.dy, a.out, a.h, a.dwl, a.dbl, a.n, P, a.sigmoid);

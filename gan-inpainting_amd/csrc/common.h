@@ -193,7 +193,11 @@ struct HeadArgs {
   float* out;          // (n,1)
   int n, Hh, Wh, c, sigmoid;
   float* out2 = nullptr;   // optional second copy of out (the caller's y)
+  // non-null: a4 is the RAW conv4 output and the head applies LeakyReLU(fma(x, scale4, shift4)) itself (BatchNorm
+  // population of image i: i / n_per_group, its vectors at + population * gstride floats); op_head_affine_ok()
+  const float* scale4 = nullptr; const float* shift4 = nullptr; int n_per_group = 0, gstride = 0;
 };
+bool op_head_affine_ok(int dtype, int c);
 int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a);
 struct HeadBwdArgs {
   const void* a4; const float* w5; const float* wl; const float* h; const float* out;
@@ -204,6 +208,7 @@ struct HeadBwdArgs {
   int n, Hh, Wh, c, sigmoid;
   float loss_scale;
   float* scratch = nullptr; int64_t scratch_bytes = 0;   // weight-gradient partials (op_head_scratch_bytes)
+  const float* scale4 = nullptr; const float* shift4 = nullptr; int n_per_group = 0, gstride = 0;   // as in HeadArgs
 };
 int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh);
 int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a);

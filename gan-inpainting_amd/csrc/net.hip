@@ -368,6 +368,8 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->slot_base = A.take(S.size * (n_slots + 1));
   net->slot_n.assign(n_slots + 1, 0);
   net->slot_train.assign(n_slots + 1, 0);
+  net->slot_fused_u2.assign(n_slots + 1, 0);
+  { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }
   net->slot_groups.assign(n_slots + 1, 1);
   *out = net;
   return GI_OK;
@@ -529,7 +531,7 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
     GI_TRY(op_bn_finalize(st, (const float*)net->shared(net->oPart), rows, b.c, pg, net->params + b.gamma_off, net->params + b.beta_off,
                           net->buffers + b.rmean_off, net->buffers + b.rvar_off, p.scale, p.shift, p.mean, p.inv, train, 0.1f, 1e-5f, 2,
                           (int64_t)rows * 2 * b.c, 4 * b.c));
-    GI_TRY(op_bn_apply(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, p.scale, p.shift, act, drop, drop_scale, pg, 4 * b.c));
+    if (apply) GI_TRY(op_bn_apply(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, p.scale, p.shift, act, drop, drop_scale, pg, 4 * b.c));
     return GI_OK;
   }
   for (int j = 0; j < g; ++j) {
@@ -875,6 +877,8 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   net->slot_groups[s] = net->bn_groups;
   net->slot_n[s] = n;
   net->slot_train[s] = train;
+  const bool fuse_a4 = net->fuse_head && op_head_affine_ok(dt, 512);
+  net->slot_fused_u2[s] = fuse_a4 ? 1 : 0;   // (critic: "conv4's activation was not materialised")
   GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   GI_TRY(op_c1_gather(st, dt, x, net->params + net->dconv[1].w_off, net->slot(s, net->oA[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_LRELU, 1.f));
   for (int i = 2; i <= 4; ++i) {
@@ -884,10 +888,17 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
     void* R = net->slot(s, net->oRd[i]);
     GI_TRY(igemm(net, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, packed_ptr(net, c), R, c.ca, c.ca, 0, n, Hs, Ws, 0, GI_ACT_NONE,
                  true, &nt));
-    GI_TRY(bn_forward(net, s, net->dbn[i], R, (int64_t)n * Hs * Ws, nt, net->slot(s, net->oA[i]), c.ca, 0, GI_ACT_LRELU, nullptr, 1.f, train));
+    // conv4 feeds only the head: its BatchNorm + LeakyReLU is applied by the head kernels from the raw tensor
+    GI_TRY(bn_forward(net, s, net->dbn[i], R, (int64_t)n * Hs * Ws, nt, net->slot(s, net->oA[i]), c.ca, 0, GI_ACT_LRELU, nullptr, 1.f, train,
+                      !(i == 4 && fuse_a4)));
   }
   HeadArgs h;
-  h.a4 = net->slot(s, net->oA[4]); h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;
+  h.a4 = net->slot(s, fuse_a4 ? net->oRd[4] : net->oA[4]);
+  if (fuse_a4) {
+    BNPtrs p = bn_ptrs(net, s, net->dbn[4]);
+    h.scale4 = p.scale; h.shift4 = p.shift; h.n_per_group = n / net->bn_groups; h.gstride = 4 * 512;
+  }
+  h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;
   h.h = (float*)net->slot(s, net->oHh); h.out = (float*)net->slot(s, net->oOut);
   h.n = n; h.Hh = net->Hh; h.Wh = net->Wh; h.c = 512; h.sigmoid = net->sigmoid;
   h.out2 = y;
@@ -915,6 +926,11 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   hb.dbl = need_wgrad ? net->grads + net->bl_off : nullptr;
   hb.dh = (float*)net->shared(net->oDh);
   hb.scratch = (float*)net->shared(net->oHw); hb.scratch_bytes = net->hw_bytes;
+  if (net->slot_fused_u2[s]) {   // the forward left conv4's activation to the head kernels: so does the backward
+    BNPtrs p = bn_ptrs(net, s, net->dbn[4]);
+    hb.a4 = net->slot(s, net->oRd[4]);
+    hb.scale4 = p.scale; hb.shift4 = p.shift; hb.n_per_group = n / net->bn_groups; hb.gstride = 4 * 512;
+  }
   hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = net->sigmoid; hb.loss_scale = LS;
   if (phase != 2) GI_TRY(op_head_backward(st, dt, hb));
   int lrelu1_done = 0;
