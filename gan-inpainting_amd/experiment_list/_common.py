@@ -139,6 +139,16 @@ def make_optimizers(kind, net_G, d_params):
             optim.RMSprop(d_params, lr=0.00005))
 
 
+def wgan_cadence(state, batch_index, g_iter_count):
+    """Whether this batch updates the generator: the reference rule (wgan_l1.py:157-163: every 140th batch while
+    fewer than 25 generator updates were made or their count is a multiple of 500, else every 5th; never batch 0),
+    or, with --g-every N (an extension for short runs: the reference rule never fires in epochs shorter than 141
+    batches), every Nth batch."""
+    if state.get("g_every"):
+        return batch_index % int(state["g_every"]) == 0 and batch_index > 0
+    return trainer.wgan_update_g(batch_index, g_iter_count, update_g_every=5)
+
+
 def make_sync():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -147,4 +157,4 @@ def make_sync():
     return None
 
 
-__all__ = ["setup", "build_networks", "run_epochs", "make_optimizers", "make_sync", "trainer"]
+__all__ = ["setup", "build_networks", "run_epochs", "make_optimizers", "make_sync", "wgan_cadence", "trainer"]

@@ -33,10 +33,7 @@ def begin(state, loaders):
     counters = {"G_iter_count": 0}
 
     def batch(bi, ground, mask, segment):
-        if state.get("g_every"):      # fixed period (smoke runs); default: the reference cadence :185-191
-            upd = bi % int(state["g_every"]) == 0 and bi > 0
-        else:
-            upd = C.trainer.wgan_update_g(bi, counters["G_iter_count"], update_g_every=5)
+        upd = C.wgan_cadence(state, bi, counters["G_iter_count"])     # the reference cadence :185-191 (or --g-every)
         L = step(ground, mask, upd, segment=segment if seg is not None else None)
         if upd:
             counters["G_iter_count"] += 1

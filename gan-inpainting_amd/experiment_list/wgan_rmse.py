@@ -15,7 +15,7 @@ def begin(state, loaders):
     counters = {"G_iter_count": 0}
 
     def batch(bi, ground, mask):
-        upd = C.trainer.wgan_update_g(bi, counters["G_iter_count"], update_g_every=5)
+        upd = C.wgan_cadence(state, bi, counters["G_iter_count"])
         L = step(ground, mask, upd)
         if upd:
             counters["G_iter_count"] += 1

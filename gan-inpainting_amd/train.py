@@ -67,7 +67,7 @@ def main(argv=None):
                         help="random: a randomly initialised frozen UnetGenerator(1,4,7,ngf=32) stands in for the reference's "
                              "_states/face_segmentation checkpoint (train.py:169-175), which is not available")
     parser.add_argument("--g-every", dest="g_every", type=int, default=0,
-                        help="config-5 plugin only: update G every N batches from the start (0 = the reference's 140-then-5 cadence)")
+                        help="WGAN plugins: update G every N batches from the start (0 = the reference's 140-then-5 cadence, which never fires in epochs shorter than 141 batches)")
     parser.add_argument("--data", default="synthetic")
     parser.add_argument("--samples", type=int, default=1024)
     parser.add_argument("--outdir", default=os.path.join(os.getcwd(), "runs"))
