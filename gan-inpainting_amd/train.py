@@ -68,6 +68,9 @@ def main(argv=None):
                              "_states/face_segmentation checkpoint (train.py:169-175), which is not available")
     parser.add_argument("--g-every", dest="g_every", type=int, default=0,
                         help="WGAN plugins: update G every N batches from the start (0 = the reference's 140-then-5 cadence, which never fires in epochs shorter than 141 batches)")
+    parser.add_argument("--workers", type=int, default=0,
+                        help="DataLoader worker processes (0 = decode in the training process like the reference, train.py:148-152; "
+                             "the PNG decode, not the GPU, bounds real-data throughput at 0)")
     parser.add_argument("--data", default="synthetic")
     parser.add_argument("--samples", type=int, default=1024)
     parser.add_argument("--outdir", default=os.path.join(os.getcwd(), "runs"))
@@ -79,6 +82,9 @@ def main(argv=None):
     rank, world = parallel.init_from_env()
     if torch.cuda.is_available():
         torch.cuda.set_device(parallel.local_device())
+    lkw = {"num_workers": args.workers}
+    if args.workers > 0:
+        lkw.update(persistent_workers=True, pin_memory=True, prefetch_factor=4)
     if args.data != "synthetic":
         # the reference's dataset layout (train.py:64-90): <dir>/csv/{train,test}_all_masks.csv with columns
         # groundtruth_source, mask_source[, segment]; decode on the host, Resize + ToTensor on the device
@@ -90,12 +96,11 @@ def main(argv=None):
             if world > 1:
                 df = df.iloc[rank::world].reset_index(drop=True)          # one shard per rank
             return torch.utils.data.DataLoader(dataset.InpaintingDataset(args.data, dataframe=df, transform=None),
-                                               batch_size=args.batchsize, shuffle=shuffle, num_workers=0, drop_last=True)
+                                               batch_size=args.batchsize, shuffle=shuffle, drop_last=True, **lkw)
         loaders = {"train": mk_real("train_all_masks.csv", True), "test": mk_real("test_all_masks.csv", True)}     # :75-90
     else:
         mk = lambda n, seed: torch.utils.data.DataLoader(   # noqa: E731
-            SyntheticInpainting(n, args.imagedim, seed + 100000 * rank), batch_size=args.batchsize, shuffle=True, num_workers=0,
-            drop_last=True)
+            SyntheticInpainting(n, args.imagedim, seed + 100000 * rank), batch_size=args.batchsize, shuffle=True, drop_last=True, **lkw)
         loaders = {"train": mk(args.samples, 1), "test": mk(max(args.batchsize, 64), 2), "extra": mk(max(args.batchsize, 64), 3)}
     segmentation_model = None
     if args.face_parsing == "random":
