@@ -732,14 +732,16 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
                                                            float* __restrict__ h, float* __restrict__ out,
                                                            float* __restrict__ out2, int Hh, int Wh, int sigmoid,
                                                            const float* __restrict__ sc4, const float* __restrict__ sh4,
-                                                           int n_per_group, int gstride) {
+                                                           int n_per_group, int gstride, float* __restrict__ tbuf, int slices) {
+  // tbuf != null (large feature maps, few images): `slices` workgroups per image each compute t for their share of
+  // the pixel tiles into tbuf[image][pixel][16] and stop; head_h512_kernel finishes (h, Linear, sigmoid).
   // sc4 != null: a4 is the RAW conv4 output; LeakyReLU(fma(x, sc4, sh4)) (the layer's BatchNorm + activation, the
   // population of image nn at +gstride floats) is applied to the fragments as they are loaded, the same fp32
   // expression and fp16 rounding as the separate apply pass
   extern __shared__ float t_lds[];   // [Hh*Wh][HT_PITCH] | 16 partial sums | w5 as fp16 [16 taps][512] | scale, shift [2][512]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nn = blockIdx.x, npx = Hh * Wh;
-  float* red = t_lds + ((npx * HT_PITCH + 3) & ~3);   // 16-byte aligned
+  const int nn = tbuf ? blockIdx.x / slices : blockIdx.x, npx = Hh * Wh;
+  float* red = t_lds + (tbuf ? 0 : ((npx * HT_PITCH + 3) & ~3));   // 16-byte aligned
   half_t* wh = (half_t*)(red + 16);
   float* aff = (float*)(wh + 16 * 512);
   if (sc4) {
@@ -755,7 +757,10 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bf[ks] = *(const h8_t*)(wh + (lane & 15) * 512 + ks * 32 + (lane >> 4) * 8);
   const char* img = a4 + (int64_t)nn * npx * 1024;
-  for (int tile = wave; tile * 16 < npx; tile += 16) {
+  const int ntile = (npx + 15) / 16;
+  const int tile0 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices) / slices) : 0;
+  const int tile1 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices + 1) / slices) : ntile;
+  for (int tile = tile0 + wave; tile < tile1; tile += 16) {
     const int px = min(tile * 16 + (lane & 15), npx - 1);
     const char* row = img + (int64_t)px * 1024 + (lane >> 4) * 16;
     h8_t av[16];
@@ -780,9 +785,13 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int q = tile * 16 + 4 * (lane >> 4) + r;
-      if (q < npx) t_lds[q * HT_PITCH + (lane & 15)] = acc[r];
+      if (q < npx) {
+        if (tbuf) tbuf[((int64_t)nn * npx + q) * 16 + (lane & 15)] = acc[r];
+        else t_lds[q * HT_PITCH + (lane & 15)] = acc[r];
+      }
     }
   }
+  if (tbuf) return;
   __syncthreads();
   const int Ph = Hh - 3, Pw = Wh - 3, P = Ph * Pw;
   float part = 0.f;
@@ -802,6 +811,34 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
 #pragma unroll
     for (int w = 0; w < 16; ++w) z += red[w];
     z += bl[0];
+    z = sigmoid ? 1.f / (1.f + expf(-z)) : z;
+    out[nn] = z;
+    if (out2) out2[nn] = z;
+  }
+}
+
+// second stage of the sliced forward: h[p] = sum_tap t[p + (ky,kx)][tap], Linear(P,1), sigmoid; one workgroup per image
+__global__ void __launch_bounds__(256) head_h512_kernel(const float* __restrict__ tbuf, const float* __restrict__ wl,
+                                                        const float* __restrict__ bl, float* __restrict__ h,
+                                                        float* __restrict__ out, float* __restrict__ out2, int Hh, int Wh,
+                                                        int sigmoid) {
+  __shared__ float red[4];
+  const int nn = blockIdx.x, npx = Hh * Wh, Ph = Hh - 3, Pw = Wh - 3, P = Ph * Pw;
+  const float* t = tbuf + (int64_t)nn * npx * 16;
+  float part = 0.f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const int py = p / Pw, px = p - py * Pw;
+    float sacc = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) sacc += t[((py + (tap >> 2)) * Wh + px + (tap & 3)) * 16 + tap];
+    h[(int64_t)nn * P + p] = sacc;
+    part = fmaf(sacc, wl[p], part);
+  }
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float z = ((red[0] + red[1]) + (red[2] + red[3])) + bl[0];
     z = sigmoid ? 1.f / (1.f + expf(-z)) : z;
     out[nn] = z;
     if (out2) out2[nn] = z;
@@ -1155,8 +1192,22 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
       static bool attr = false;
       if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     }
+    // large maps with few images (512x512 inputs: 32x32 map, 64 tiles per image): slice each image over several
+    // workgroups so that ~256 of them stream the activations, and finish in a second small kernel
+    const int npx = a.Hh * a.Wh;
+    int slices = 1;
+    while (a.n * slices < 256 && npx / (slices * 2) >= 256) slices *= 2;
+    if (slices > 1 && a.tbuf && a.tbuf_bytes >= (int64_t)a.n * npx * 16 * 4) {
+      const int lds2 = (16) * 4 + 16 * 512 * 2 + 2 * 512 * 4;
+      hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n * slices), dim3(1024), lds2, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh,
+                         a.Wh, a.sigmoid, a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, a.tbuf, slices);
+      GI_LAUNCH_CHECK();
+      hipLaunchKernelGGL(head_h512_kernel, dim3(a.n), dim3(256), 0, st, a.tbuf, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid);
+      GI_LAUNCH_CHECK();
+      return GI_OK;
+    }
     hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid,
-                       a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride);
+                       a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, (float*)nullptr, 1);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }

@@ -196,6 +196,7 @@ struct HeadArgs {
   // non-null: a4 is the RAW conv4 output and the head applies LeakyReLU(fma(x, scale4, shift4)) itself (BatchNorm
   // population of image i: i / n_per_group, its vectors at + population * gstride floats); op_head_affine_ok()
   const float* scale4 = nullptr; const float* shift4 = nullptr; int n_per_group = 0, gstride = 0;
+  float* tbuf = nullptr; int64_t tbuf_bytes = 0;   // optional (n, Hh*Wh, 16) fp32 scratch: lets large maps be sliced over workgroups
 };
 bool op_head_affine_ok(int dtype, int c);
 int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a);

@@ -80,6 +80,7 @@ struct gi_net {
   int64_t ogE = -1, oD = -1, oG0 = -1, oPart = -1, oSums = -1, oSplit = -1, oDh = -1, oCol = -1;
   int64_t part_floats = 0, split_bytes = 0;
   int64_t oHw = -1, hw_bytes = 0;    // head weight-gradient partials
+  int64_t oHt = -1, ht_bytes = 0;    // head forward: per-pixel tap products of large feature maps (sliced forward)
   int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
   std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
@@ -335,6 +336,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oDh = A.take(N * net->P * 4);
   net->hw_bytes = op_head_scratch_bytes((int)N, net->Hh, net->Wh);
   net->oHw = A.take(net->hw_bytes);
+  if (net->Hh * net->Wh > 256) { net->ht_bytes = N * net->Hh * net->Wh * 16 * 4; net->oHt = A.take(net->ht_bytes); }
   net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
   {   // gradient penalty (fp32 critics): tangent / stacked-gradient tensors
     int64_t maxl = 0;
@@ -898,6 +900,7 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
     BNPtrs p = bn_ptrs(net, s, net->dbn[4]);
     h.scale4 = p.scale; h.shift4 = p.shift; h.n_per_group = n / net->bn_groups; h.gstride = 4 * 512;
   }
+  if (net->oHt >= 0) { h.tbuf = (float*)net->shared(net->oHt); h.tbuf_bytes = net->ht_bytes; }
   h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;
   h.h = (float*)net->slot(s, net->oHh); h.out = (float*)net->slot(s, net->oOut);
   h.n = n; h.Hh = net->Hh; h.Wh = net->Wh; h.c = 512; h.sigmoid = net->sigmoid;

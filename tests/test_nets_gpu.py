@@ -141,7 +141,7 @@ def test_unet_train_vs_golden_with_imposed_masks(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-@pytest.mark.parametrize("cfg", [(128, 3, True), (128, 3, False), (64, 2, True), (256, 2, False)])
+@pytest.mark.parametrize("cfg", [(128, 3, True), (128, 3, False), (64, 2, True), (256, 2, False), (512, 1, True)])   # 512: sliced head forward
 def test_patchgan_vs_oracle(dtype, cfg):
     HW, N, sig = cfg
     seed = 200 + HW
