@@ -51,10 +51,14 @@ __global__ void __launch_bounds__(256) sum_cin_kernel(const float* __restrict__ 
 __global__ void __launch_bounds__(256) vgg_conv1_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int n, int H, int W,
                                                         const float* __restrict__ w1, const float* __restrict__ bias,
                                                         half_t* __restrict__ out) {
-  __shared__ float sw[64 * 9 + 64];
-  for (int i = threadIdx.x; i < 64 * 9 + 64; i += 256) sw[i] = i < 576 ? w1[i] : bias[i - 576];
-  __syncthreads();
-  const int grp = threadIdx.x & 7;   // 8 channels each
+  const int grp = threadIdx.x & 7;   // 8 channels each: their 72 weights and 8 biases stay in registers
+  float wr[8][9], br[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    br[c] = bias[grp * 8 + c];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[c][k] = w1[(grp * 8 + c) * 9 + k];
+  }
   const int64_t npix = (int64_t)2 * n * H * W;
   for (int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (int64_t)gridDim.x * 32) {
     const int x = (int)(pix % W);
@@ -71,10 +75,9 @@ __global__ void __launch_bounds__(256) vgg_conv1_kernel(const float* __restrict_
     h8_t o;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int ch = grp * 8 + c;
-      float s = sw[576 + ch];
+      float s = br[c];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) s = fmaf(sw[ch * 9 + k], v[k], s);
+      for (int k = 0; k < 9; ++k) s = fmaf(wr[c][k], v[k], s);
       o[c] = (half_t)(s > 0.f ? s : 0.f);
     }
     *(h8_t*)(out + pix * 64 + grp * 8) = o;
