@@ -334,6 +334,17 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     gen_fwd_ms = e0.elapsed_time(e1) / reps
+    # the same in eval mode (running-statistics BatchNorm, no dropout): what eval.py / the evaluation pass run
+    G.eval()
+    for _ in range(3):
+        G._forward_raw(masked)
+    e0.record()
+    for _ in range(reps):
+        G._forward_raw(masked)
+    e1.record()
+    torch.cuda.synchronize()
+    gen_fwd_eval_ms = e0.elapsed_time(e1) / reps
+    G.train()
 
     k = dominant_kernel(args.kernel_iters)
     achieved = k["flop"] / (k["ms"] * 1e-3) / 1e12
@@ -364,6 +375,7 @@ def main():
                    "global_batch": world * BS, "parallelism": f"dp{world}",
                    "compute": "fp16 MFMA, fp32 accumulate, fp32 master weights" if args.dtype == "fp16" else "fp32 MFMA"},
         "generator_fwd_ms": gen_fwd_ms,
+        "generator_fwd_eval_ms": gen_fwd_eval_ms,
         "generator_fwd_mfma_frac": BS * F_G / (gen_fwd_ms * 1e-3) / (PEAK_F16_TFLOPS * 1e12),
         "step_algorithmic_tflops": flop_batch / (dt / args.steps) / 1e12,
         "losses": losses,

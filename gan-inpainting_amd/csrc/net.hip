@@ -29,6 +29,7 @@ struct BN {
   int c = 0;
   int64_t gamma_off = -1, beta_off = -1, rmean_off = -1, rvar_off = -1;
   int64_t stat_off = -1;  // per-slot: [scale|shift|mean|inv] * c floats (offset inside slot)
+  int id = -1;            // index into gi_net::eval_gen
 };
 
 struct Arena {
@@ -81,6 +82,10 @@ struct gi_net {
   int64_t part_floats = 0, split_bytes = 0;
   int64_t oHw = -1, hw_bytes = 0;    // head weight-gradient partials
   int64_t oHt = -1, ht_bytes = 0;    // head forward: per-pixel tap products of large feature maps (sliced forward)
+  // eval-mode BatchNorm is a fixed affine map of (gamma, beta, running statistics): its scale / shift in a slot stay
+  // valid until those change (weights re-synced, a train-mode forward, set_train), tracked by a generation counter
+  uint64_t affine_gen = 1;
+  std::vector<std::vector<uint64_t>> eval_gen;   // [slot][BN id]: generation the slot's scale / shift were computed at
   int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
   std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
@@ -257,15 +262,17 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->oOut = S.take(N * H * W * 4 * out_c);
   net->oX = S.take(N * H * W * 4);
   int64_t stat_floats = 0;
+  int nbn = 0;
   for (int k = 1; k <= nd; ++k)
     for (BN* b : {&net->dnorm[k], &net->unorm[k]})
-      if (b->c) { b->stat_off = stat_floats; stat_floats += 4 * b->c; }
+      if (b->c) { b->stat_off = stat_floats; stat_floats += 4 * b->c; b->id = nbn++; }
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
   net->slot_base = A.take(S.size * n_slots);
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
   net->slot_fused_u2.assign(n_slots, 0);
+  net->eval_gen.assign(n_slots, std::vector<uint64_t>(nbn, 0));
   { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }   // 0: materialise the last decoder level (tools: A/B)
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
@@ -363,7 +370,8 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oOut = S.take(N * 4);
   net->oX = S.take(N * H * W * 4);
   int64_t stat_floats = 0;
-  for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 2 * 4 * net->dbn[i].c; }   // x2: BN groups
+  for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 2 * 4 * net->dbn[i].c; net->dbn[i].id = i - 2; }   // x2: BN groups
+  net->eval_gen.assign(n_slots + 1, std::vector<uint64_t>(3, 0));
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
   net->gp_slot = n_slots;                      // one private activation set for the gradient penalty
@@ -436,6 +444,7 @@ __global__ void __launch_bounds__(256) pad_b_kernel(const float* __restrict__ sr
 
 extern "C" int gi_net_sync_weights(gi_net* net) {
   GI_REQUIRE(net && net->bound, "sync_weights: net not bound");
+  ++net->affine_gen;   // parameters (and possibly running statistics) were written from outside
   PackJobs P;
   P.n = 0;
   auto add = [&](const Conv& c) {
@@ -469,6 +478,7 @@ extern "C" int gi_net_sync_weights(gi_net* net) {
 extern "C" int gi_net_set_train(gi_net* net, int train) {
   GI_REQUIRE(net, "set_train: null");
   net->train = train ? 1 : 0;
+  ++net->affine_gen;
   return GI_OK;
 }
 extern "C" int gi_net_set_bn_groups(gi_net* net, int groups) {
@@ -549,8 +559,12 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
       GI_TRY(op_col_stats(st, net->dtype, rj, pg, b.c, scratch, &rows));
       part = scratch;
     }
-    GI_TRY(op_bn_finalize(st, part, rows, b.c, pg, net->params + b.gamma_off, net->params + b.beta_off, net->buffers + b.rmean_off,
-                          net->buffers + b.rvar_off, p.scale, p.shift, p.mean, p.inv, train, 0.1f, 1e-5f));
+    const bool cached = !train && g == 1 && b.id >= 0 && net->eval_gen[slot][b.id] == net->affine_gen;
+    if (!cached) {
+      GI_TRY(op_bn_finalize(st, part, rows, b.c, pg, net->params + b.gamma_off, net->params + b.beta_off, net->buffers + b.rmean_off,
+                            net->buffers + b.rvar_off, p.scale, p.shift, p.mean, p.inv, train, 0.1f, 1e-5f));
+      if (b.id >= 0) net->eval_gen[slot][b.id] = (!train && g == 1) ? net->affine_gen : 0;
+    }
     if (apply)
       GI_TRY(op_bn_apply(st, net->dtype, rj, (char*)dst + (int64_t)j * pg * ldy * T, pg, b.c, ldy, coffy, p.scale, p.shift, act,
                          drop ? drop + (int64_t)j * pg * b.c : nullptr, drop_scale));
@@ -680,6 +694,7 @@ __global__ void __launch_bounds__(256) pad_dy_kernel(const float* __restrict__ g
 int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   hipStream_t st = net->ctx->stream;
   const int nd = net->nd, dt = net->dtype, train = net->train;
+  if (train) ++net->affine_gen;   // running statistics change below
   const int H = net->H, W = net->W;
   net->slot_n[s] = n;
   net->slot_train[s] = train;
@@ -875,6 +890,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
 int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   hipStream_t st = net->ctx->stream;
   const int dt = net->dtype, train = net->train, H = net->H, W = net->W;
+  if (train) ++net->affine_gen;   // running statistics change below
   GI_REQUIRE(n % net->bn_groups == 0, "patchgan_forward: %d images do not split into %d BatchNorm groups", n, net->bn_groups);
   net->slot_groups[s] = net->bn_groups;
   net->slot_n[s] = n;

@@ -107,6 +107,40 @@ def test_unet_eval_forward(dtype):
     assert ok, msg
 
 
+def test_eval_affine_cache_follows_statistics_and_parameter_changes():
+    """Eval-mode BatchNorm scale / shift are cached per activation slot (net.hip: affine_gen). The cache must drop when the
+    running statistics move (a train-mode forward) and when parameters are written (load_state_dict)."""
+    nd, N, HW = 7, 2, 128
+    net = make_unet(op.make_unet_params(12, num_downs=nd), nd, "fp16").eval()
+    ground, mask = op.synth_batch(19, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask)).cuda()
+    x2 = torch.from_numpy(op.synth_batch(23, N, HW, HW)[0]).cuda()
+
+    def fresh_eval(state):
+        ref = networks.UnetGenerator(1, 1, nd, ngf=64, use_dropout="False", dtype="fp16")
+        ref.load_state_dict({k: v.detach().cpu().clone() for k, v in state.items()})
+        with torch.no_grad():
+            return ref.to("cuda").eval()(x).cpu()
+
+    with torch.no_grad():
+        y1, y2 = net(x).cpu(), net(x).cpu()
+        assert torch.equal(y1, y2)                                   # second call: cached affine maps
+        net.train()
+        net(x2)                                                       # moves every running mean / variance
+        net.eval()
+        y3 = net(x).cpu()
+    assert not torch.equal(y1, y3)
+    assert torch.equal(y3, fresh_eval(net.state_dict()))             # a handle without any cache agrees bit for bit
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    for k in sd:
+        if k.endswith(".running_var"):
+            sd[k] = sd[k] * 1.7
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        y4 = net.eval()(x).cpu()
+    assert not torch.equal(y3, y4) and torch.equal(y4, fresh_eval(sd))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
 def test_unet_train_vs_golden_with_imposed_masks(dtype):
     """Directly against the numbers recorded from the reference (tests/golden/unet128_train.npz):
