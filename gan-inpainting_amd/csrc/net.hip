@@ -477,8 +477,8 @@ extern "C" int gi_net_sync_weights(gi_net* net) {
 }
 extern "C" int gi_net_set_train(gi_net* net, int train) {
   GI_REQUIRE(net, "set_train: null");
+  if (net->train != (train ? 1 : 0)) ++net->affine_gen;
   net->train = train ? 1 : 0;
-  ++net->affine_gen;
   return GI_OK;
 }
 extern "C" int gi_net_set_bn_groups(gi_net* net, int groups) {
