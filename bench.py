@@ -344,6 +344,15 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     gen_fwd_eval_ms = e0.elapsed_time(e1) / reps
+    # inference: eval mode, never differentiated -> BatchNorm folded into the convolutions (gi_net_set_inference)
+    for _ in range(3):
+        G._forward_raw(masked, inference=True)
+    e0.record()
+    for _ in range(reps):
+        G._forward_raw(masked, inference=True)
+    e1.record()
+    torch.cuda.synchronize()
+    gen_fwd_inf_ms = e0.elapsed_time(e1) / reps
     G.train()
 
     k = dominant_kernel(args.kernel_iters)
@@ -376,6 +385,7 @@ def main():
                    "compute": "fp16 MFMA, fp32 accumulate, fp32 master weights" if args.dtype == "fp16" else "fp32 MFMA"},
         "generator_fwd_ms": gen_fwd_ms,
         "generator_fwd_eval_ms": gen_fwd_eval_ms,
+        "generator_fwd_inference_ms": gen_fwd_inf_ms,
         "generator_fwd_mfma_frac": BS * F_G / (gen_fwd_ms * 1e-3) / (PEAK_F16_TFLOPS * 1e12),
         "step_algorithmic_tflops": flop_batch / (dt / args.steps) / 1e12,
         "losses": losses,

@@ -34,6 +34,7 @@ PROTOTYPES = {
     "gi_net_bind": (_i, [_vp, _vp, _vp, _vp, _vp, _i64]),
     "gi_net_sync_weights": (_i, [_vp]),
     "gi_net_set_train": (_i, [_vp, _i]),
+    "gi_net_set_inference": (_i, [_vp, _i]),
     "gi_net_set_loss_scale": (_i, [_vp, _f]),
     "gi_net_set_bn_groups": (_i, [_vp, _i]),
     "gi_net_set_dropout_seed": (_i, [_vp, _u64]),

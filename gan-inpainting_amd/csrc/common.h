@@ -217,7 +217,7 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a);
 // weight packing / conversions
 int op_pack_weights(hipStream_t st, int dtype, const float* w, int ca, int cb, void* w_packed, void* w_phase);
 // the same for up to 16 layers in ONE launch (packed / phase may be null per layer)
-struct PackJob { const float* w; void* packed; void* phase; int ca, cb, tile0, pad_; };
+struct PackJob { const float* w; void* packed; void* phase; int ca, cb, tile0, scale_on_b; const float* scale; };   // scale: per a (or b) factor, or null
 struct PackJobs { PackJob j[16]; int n; };
 int op_pack_weights_batch(hipStream_t st, int dtype, PackJobs& P);
 int op_convert(hipStream_t st, int dtype, const float* src, void* dst, int64_t count);

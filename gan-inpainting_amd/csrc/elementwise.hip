@@ -757,6 +757,7 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs P) {
     if (a < ca && b < cb) {
       const int64_t idx = ((int64_t)a * 16 + ky * 4 + kx) * cb + b;
       v = w[idx];
+      if (P.j[jb].scale) v *= P.j[jb].scale[P.j[jb].scale_on_b ? b : a];   // inference: the following BatchNorm's scale folded in
       if (packed) packed[idx] = (T)v;
     }
     tile[r][tx] = v;

@@ -24,12 +24,14 @@ struct Conv {            // 4x4 weight [a][16][b] fp32 master at params+w_off
   int ca = 0, cb = 0;
   int64_t w_off = -1, bias_off = -1;
   int64_t packed_off = -1, phase_off = -1;  // workspace offsets of the T copies (-1: b == 1 layer)
+  int64_t inf_off = -1;                     // inference: the forward's copy with the following BatchNorm's scale folded in
 };
 struct BN {
   int c = 0;
   int64_t gamma_off = -1, beta_off = -1, rmean_off = -1, rvar_off = -1;
   int64_t stat_off = -1;  // per-slot: [scale|shift|mean|inv] * c floats (offset inside slot)
   int id = -1;            // index into gi_net::eval_gen
+  int64_t inf_off = -1;   // shared workspace: [scale|shift|mean|inv] * c floats of the inference affine map
 };
 
 struct Arena {
@@ -85,6 +87,9 @@ struct gi_net {
   // eval-mode BatchNorm is a fixed affine map of (gamma, beta, running statistics): its scale / shift in a slot stay
   // valid until those change (weights re-synced, a train-mode forward, set_train), tracked by a generation counter
   uint64_t affine_gen = 1;
+  uint64_t inf_gen = 0;              // generation the folded inference copies were built at
+  int inference = 0;                 // gi_net_set_inference: eval-mode forwards will never be differentiated
+  std::vector<int> slot_inference;
   std::vector<std::vector<uint64_t>> eval_gen;   // [slot][BN id]: generation the slot's scale / shift were computed at
   int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
   std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
@@ -211,6 +216,11 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
       c->phase_off = A.take(cnt * T);
     }
   }
+  for (int k = 2; k <= nd; ++k) {   // inference copies: conv in its packed form, transposed conv in its phase form
+    if (k < nd) { net->conv[k].inf_off = A.take((int64_t)net->conv[k].ca * 16 * net->conv[k].cb * T); net->dnorm[k].inf_off = A.take(4 * net->dnorm[k].c * 4); }
+    net->up[k].inf_off = A.take((int64_t)net->up[k].ca * 16 * net->up[k].cb * T);
+    net->unorm[k].inf_off = A.take(4 * net->unorm[k].c * 4);
+  }
   const int64_t N = max_n;
   net->ogC.assign(nd + 1, -1); net->ogA.assign(nd + 1, -1);
   int64_t maxD = 0, maxPart = 0, maxSplit = 0, maxc = 0;
@@ -272,6 +282,7 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
   net->slot_fused_u2.assign(n_slots, 0);
+  net->slot_inference.assign(n_slots, 0);
   net->eval_gen.assign(n_slots, std::vector<uint64_t>(nbn, 0));
   { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }   // 0: materialise the last decoder level (tools: A/B)
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
@@ -449,7 +460,7 @@ extern "C" int gi_net_sync_weights(gi_net* net) {
   P.n = 0;
   auto add = [&](const Conv& c) {
     PackJob& J = P.j[P.n++];
-    J.w = net->params + c.w_off; J.ca = c.ca; J.cb = c.cb; J.tile0 = 0; J.pad_ = 0;
+    J.w = net->params + c.w_off; J.ca = c.ca; J.cb = c.cb; J.tile0 = 0; J.scale_on_b = 0; J.scale = nullptr;
     J.packed = c.packed_off >= 0 ? (void*)net->shared(c.packed_off) : nullptr;
     J.phase = net->shared(c.phase_off);
   };
@@ -479,6 +490,11 @@ extern "C" int gi_net_set_train(gi_net* net, int train) {
   GI_REQUIRE(net, "set_train: null");
   if (net->train != (train ? 1 : 0)) ++net->affine_gen;
   net->train = train ? 1 : 0;
+  return GI_OK;
+}
+extern "C" int gi_net_set_inference(gi_net* net, int inference) {
+  GI_REQUIRE(net, "set_inference: null");
+  net->inference = inference ? 1 : 0;
   return GI_OK;
 }
 extern "C" int gi_net_set_bn_groups(gi_net* net, int groups) {
@@ -576,13 +592,13 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
-          const void* add = nullptr, int ldadd = 0) {
+          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.relu_cend = relu_cend;
   a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
   a.add = add; a.ldadd = ldadd; a.coffadd = 0;
-  a.in = in; a.w = w; a.out = out; a.bias = nullptr;
+  a.in = in; a.w = w; a.out = out; a.bias = bias;
   a.partials = stats ? (float*)net->shared(net->oPart) : nullptr;
   a.ws = net->split_bytes > 0 ? (float*)net->shared(net->oSplit) : nullptr;
   a.ws_bytes = net->split_bytes;
@@ -691,9 +707,90 @@ __global__ void __launch_bounds__(256) pad_dy_kernel(const float* __restrict__ g
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inference (gi_net_set_inference + eval mode): every BatchNorm is a fixed affine map, so its scale goes into the
+// preceding convolution's weights (a second copy in the forward's layout), its shift becomes the GEMM's bias and
+// the activation runs in the GEMM epilogue, which writes straight into the skip buffers: no normalisation pass at all.
+// The folded copies are rebuilt when the generation counter says weights or running statistics changed.
+int unet_sync_inference(gi_net* net) {
+  hipStream_t st = net->ctx->stream;
+  const int nd = net->nd;
+  auto aff = [&](const BN& b) { return (float*)net->shared(b.inf_off); };
+  PackJobs P;
+  P.n = 0;
+  for (int k = 2; k <= nd; ++k) {
+    for (int up = 0; up < 2; ++up) {
+      if (!up && k == nd) continue;   // the innermost convolution has no norm
+      const BN& b = up ? net->unorm[k] : net->dnorm[k];
+      const Conv& c = up ? net->up[k] : net->conv[k];
+      float* a = aff(b);
+      GI_TRY(op_bn_finalize(st, nullptr, 0, b.c, 1, net->params + b.gamma_off, net->params + b.beta_off, net->buffers + b.rmean_off,
+                            net->buffers + b.rvar_off, a, a + b.c, a + 2 * b.c, a + 3 * b.c, 0, 0.1f, 1e-5f));
+      if (P.n == 16) { GI_TRY(op_pack_weights_batch(st, net->dtype, P)); P.n = 0; }
+      PackJob& J = P.j[P.n++];
+      J.w = net->params + c.w_off; J.ca = c.ca; J.cb = c.cb; J.tile0 = 0;
+      J.packed = up ? nullptr : (void*)net->shared(c.inf_off);
+      J.phase = up ? (void*)net->shared(c.inf_off) : nullptr;
+      J.scale = a; J.scale_on_b = up;
+    }
+  }
+  GI_TRY(op_pack_weights_batch(st, net->dtype, P));
+  net->inf_gen = net->affine_gen;
+  return GI_OK;
+}
+
+int unet_forward_inference(gi_net* net, int s, const float* x, float* y, int n) {
+  hipStream_t st = net->ctx->stream;
+  const int nd = net->nd, dt = net->dtype;
+  if (net->inf_gen != net->affine_gen) GI_TRY(unet_sync_inference(net));
+  net->slot_n[s] = n;
+  net->slot_train[s] = 0;
+  net->slot_inference[s] = 1;
+  net->slot_fused_u2[s] = 0;
+  auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
+  auto shift = [&](const BN& b) { return (const float*)net->shared(b.inf_off) + b.c; };
+  GI_TRY(op_c1_gather(st, dt, x, net->params + net->conv[1].w_off, C(1), n, net->Hk[1], net->Wk[1], net->ch[1], 2 * net->ch[1], 0,
+                      GI_ACT_LRELU, 1.f));
+  for (int k = 2; k <= nd; ++k) {
+    if (k < nd)
+      GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, net->shared(net->conv[k].inf_off), C(k), net->ch[k],
+                   2 * net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_LRELU, false, nullptr, 0, nullptr, 0, 0.f, nullptr, nullptr, 0,
+                   shift(net->dnorm[k])));
+    else
+      GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), net->slot(s, net->oE),
+                   net->ch[k], net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_RELU, false, nullptr));
+  }
+  for (int k = nd; k >= 2; --k) {
+    const void* in = (k == nd) ? (const void*)net->slot(s, net->oE) : C(k);
+    const int cin = net->up[k].ca, co = net->ch[k - 1];
+    GI_TRY(igemm(net, 1, in, cin, cin, 0, net->shared(net->up[k].inf_off), C(k - 1), co, 2 * co, co, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
+                 GI_ACT_RELU, false, nullptr, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, shift(net->unorm[k])));
+  }
+  float* osave = (float*)net->slot(s, net->oOut);
+  if (net->out_c == 1) {
+    GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
+                         net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y));
+    return GI_OK;
+  }
+  void* U1 = net->shared(net->oU1);
+  const int c1 = 2 * net->ch[1], H = net->H, W = net->W;
+  GI_TRY(igemm(net, 1, C(1), c1, c1, 0, net->shared(net->oUp1Phase), U1, 64, 64, 0, n, net->Hk[1], net->Wk[1], 1, GI_ACT_NONE, false, nullptr,
+               net->ch[1]));
+  const int64_t total = (int64_t)n * net->out_c * H * W;
+  if (dt == GI_F16)
+    hipLaunchKernelGGL(head_tanh_kernel<half_t>, dim3(grid1d(total)), dim3(256), 0, st, (const half_t*)U1, net->params + net->up[1].bias_off, y, n,
+                       net->out_c, H * W);
+  else
+    hipLaunchKernelGGL(head_tanh_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, (const float*)U1, net->params + net->up[1].bias_off, y, n,
+                       net->out_c, H * W);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
 int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   hipStream_t st = net->ctx->stream;
   const int nd = net->nd, dt = net->dtype, train = net->train;
+  if (!train && net->inference && nd >= 3) return unet_forward_inference(net, s, x, y, n);
+  net->slot_inference[s] = 0;
   if (train) ++net->affine_gen;   // running statistics change below
   const int H = net->H, W = net->W;
   net->slot_n[s] = n;
@@ -785,6 +882,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   // a forward in eval mode (running-statistics BatchNorm, no dropout) can be differentiated w.r.t. its input only:
   // the frozen segmentation network of the face-parsing loss (wgan_perceptual_style_faceparsing.py:212-213)
   GI_REQUIRE(n > 0 && (net->slot_train[s] || !need_wgrad), "unet_backward: slot %d holds no train-mode forward", s);
+  GI_REQUIRE(!net->slot_inference[s], "unet_backward: slot %d holds an inference forward (gi_net_set_inference): nothing was saved for a backward", s);
   GI_REQUIRE(net->out_c == 1 || !need_wgrad, "unet_backward: parameter gradients of a %d-channel generator are not built", net->out_c);
   const int evalbn = net->slot_train[s] ? 0 : 1;
   net->bwd_eval = evalbn;

@@ -296,9 +296,11 @@ class HipNet(nn.Module):
         self._groups_set = 1
         self._dirty = True
 
-    def _forward_raw(self, x, bn_groups=1):
+    def _forward_raw(self, x, bn_groups=1, inference=False):
         """bn_groups = 2 (discriminators only): x stacks two equally sized batches that are normalised with
-        independent BatchNorm statistics, i.e. two reference forward calls in one launch sequence."""
+        independent BatchNorm statistics, i.e. two reference forward calls in one launch sequence.
+        inference (eval mode only): this forward will never be differentiated; generators then run with their
+        BatchNorm layers folded into the convolutions (gi_net_set_inference)."""
         if x.dim() != 4 or x.shape[1] != 1:
             raise ValueError(f"expected (N,1,H,W) input, got {tuple(x.shape)}")
         if x.dtype != torch.float32 or not x.is_cuda:
@@ -311,6 +313,10 @@ class HipNet(nn.Module):
             B.check(lib.gi_net_sync_weights(self._handle))
             self._dirty = False
         B.check(lib.gi_net_set_train(self._handle, 1 if self.training else 0))
+        inference = bool(inference) and not self.training
+        if getattr(self, "_inference_set", (None, False)) != (self._handle, inference):
+            B.check(lib.gi_net_set_inference(self._handle, 1 if inference else 0))
+            self._inference_set = (self._handle, inference)
         if bn_groups != 1 or self._groups_set != 1:
             B.check(lib.gi_net_set_bn_groups(self._handle, bn_groups))
             self._groups_set = bn_groups
@@ -342,7 +348,7 @@ class HipNet(nn.Module):
     def forward(self, x):
         if torch.is_grad_enabled() and (self.training or x.requires_grad):
             return _NetFunction.apply(x, self._anchor, self)
-        return self._forward_raw(x)[0]
+        return self._forward_raw(x, inference=not self.training)[0]   # no autograd node: nothing can be differentiated
 
 
 def _init_conv(cout, cin, transposed=False, bias=False):
@@ -443,7 +449,7 @@ class UnetGenerator(HipNet):
             out[lvl] = m
         return out
 
-    def _forward_raw(self, x):
+    def _forward_raw(self, x, bn_groups=1, inference=False):
         self._last_n = x.shape[0]
         if getattr(self, "_pending_masks", None):
             self._ensure_handle(x.shape[0], x.shape[2], x.shape[3])
@@ -451,12 +457,12 @@ class UnetGenerator(HipNet):
             self._mask_keep = {k: v.to(self.device).contiguous() for k, v in self._pending_masks.items()}
             for lvl, m in self._mask_keep.items():
                 B.check(B.lib().gi_net_set_dropout_mask(self._handle, slot, lvl, B.ptr(m)))
-            out = super()._forward_raw(x)
+            out = super()._forward_raw(x, inference=inference)
             for lvl in self._mask_keep:
                 B.check(B.lib().gi_net_set_dropout_mask(self._handle, slot, lvl, None))
             self._pending_masks = None
             return out
-        return super()._forward_raw(x)
+        return super()._forward_raw(x, inference=inference)
 
     def impose_dropout_masks(self, masks):
         """Use these keep-masks ({level: uint8 (N,C,H,W)}) in the NEXT forward (parity tests)."""

@@ -86,6 +86,10 @@ int gi_net_bind(gi_net* net, float* params, float* grads, float* buffers, void* 
 /* re-derive the packed (fp16 / transposed) weight copies after params were written by the caller */
 int gi_net_sync_weights(gi_net* net);
 int gi_net_set_train(gi_net* net, int train);
+/* Inference hint (generators): with train = 0, forwards will never be differentiated. BatchNorm layers are then folded
+ * into the neighbouring convolutions (scale into a second weight copy, shift as the GEMM bias, activation in the
+ * epilogue); gi_net_backward on such a forward fails. What eval.py:94 / evaluate.py:127-158 run under no_grad. */
+int gi_net_set_inference(gi_net* net, int inference);
 int gi_net_set_loss_scale(gi_net* net, float scale);
 /* discriminator only: the next forward/backward batches hold `groups` (1 or 2) consecutive, equally sized image
  * groups with INDEPENDENT BatchNorm batch statistics (running statistics updated group by group). groups = 2 runs

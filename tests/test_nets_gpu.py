@@ -107,6 +107,32 @@ def test_unet_eval_forward(dtype):
     assert ok, msg
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_unet_inference_forward_folds_batchnorm(dtype):
+    """Module call in eval mode without autograd = inference: BatchNorm folded into the convolutions
+    (gi_net_set_inference). Same numbers as the golden eval forward recorded from the reference (within the dtype's
+    tolerance: the folded fp16 weights are rounded after the scaling), and no backward is possible."""
+    from gan_inpainting_amd import backend as B
+    nd, N, HW = 7, 2, 128
+    net = make_unet(op.make_unet_params(12, num_downs=nd), nd, dtype).eval()
+    fx = load("unet128_eval")
+    ground, mask = op.synth_batch(12 + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask)).cuda()
+    with torch.no_grad():
+        y_inf = net(x)                                               # inference path
+    y_eval, slot, gen = net._forward_raw(x)                          # plain eval path (differentiable w.r.t. x)
+    ok, msg = report(f"unet inference {dtype} vs golden(reference)", y_inf.cpu(), torch.from_numpy(fx["out"]), TOL_OUT[dtype])
+    assert ok, msg
+    ok, msg = report(f"unet inference {dtype} vs eval path", y_inf.cpu(), y_eval.cpu(), TOL_OUT[dtype])
+    assert ok, msg
+    dx = net._backward_raw(slot, gen, torch.ones_like(y_eval), True, False)      # the eval forward can be differentiated
+    assert torch.isfinite(dx).all()
+    y2, slot2, gen2 = net._forward_raw(x, inference=True)
+    assert torch.equal(y2, y_inf)
+    with pytest.raises(B.BackendError, match="inference forward"):
+        net._backward_raw(slot2, gen2, torch.ones_like(y2), True, False)
+
+
 def test_eval_affine_cache_follows_statistics_and_parameter_changes():
     """Eval-mode BatchNorm scale / shift are cached per activation slot (net.hip: affine_gen). The cache must drop when the
     running statistics move (a train-mode forward) and when parameters are written (load_state_dict)."""
