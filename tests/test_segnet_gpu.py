@@ -90,6 +90,22 @@ def test_wide_multichannel_eval_and_train_forward_vs_oracle():
     assert rel_l2(yt.cpu(), yto) <= 1e-4
 
 
+def test_multichannel_and_narrow_inference_forward_vs_oracle():
+    """Inference path (BatchNorm folded into the convolutions) of the multi-channel head, wide (ngf=64, 3 channels) and
+    embedded narrow (ngf=32, 4 classes: the face-parsing network called under no_grad by the evaluation pass)."""
+    _, networks = _mods()
+    for ngf, out_c, nd, hw, dtype, tol in ((64, 3, 6, 64, "fp32", 1e-5), (32, 4, 7, 128, "fp16", 2e-2)):
+        P = op.make_unet_params(321 + ngf, num_downs=nd, ngf=ngf, in_c=1, out_c=out_c)
+        net = networks.UnetGenerator(1, out_c, nd, ngf=ngf, use_dropout=False, dtype=dtype)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in P.items()}, strict=True)
+        net = net.cuda().eval()
+        g, _ = op.synth_batch(322 + ngf, 2, hw, hw)
+        with torch.no_grad():
+            y = net(torch.from_numpy(g).cuda())                       # eval mode, no autograd node: inference
+        yo = orc.unet_forward(orc.to_torch(P, requires_grad=False), torch.from_numpy(g), nd, False, None)
+        assert rel_l2(y.cpu(), yo) <= tol, (ngf, rel_l2(y.cpu(), yo))
+
+
 def test_parameter_gradients_of_multichannel_net_are_refused():
     _, networks = _mods()
     from gan_inpainting_amd import backend as B
