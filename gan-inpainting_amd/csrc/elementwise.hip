@@ -1099,13 +1099,21 @@ int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, in
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
-int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
-  GI_REQUIRE(ctx && g && flag3 && count > 0, "check_finite: bad argument");
+int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
+  GI_REQUIRE(ctx && g && flag3 && count > 0, "check_finite_scan: bad argument");
   hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks(count, 8)), dim3(256), 0, ctx->stream, g, count, flag3);
   GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_check_finite_finish(gi_ctx* ctx, int* flag3) {
+  GI_REQUIRE(ctx && flag3, "check_finite_finish: bad argument");
   hipLaunchKernelGGL(check_finite_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, flag3);
   GI_LAUNCH_CHECK();
   return GI_OK;
+}
+int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
+  GI_TRY(gi_check_finite_scan(ctx, g, count, flag3));
+  return gi_check_finite_finish(ctx, flag3);
 }
 int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi) {
   hipLaunchKernelGGL(clamp_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, count, lo, hi);

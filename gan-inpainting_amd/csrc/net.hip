@@ -1099,6 +1099,7 @@ int patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, 
   const int dt = net->dtype, H = net->H, W = net->W, s = net->gp_slot;
   GI_REQUIRE(dt == GI_F32, "gradient_penalty: built for fp32 critics (BASELINE config 2); fp16 needs tangent scaling");
   GI_REQUIRE(!net->sigmoid && net->train, "gradient_penalty: needs a train-mode critic without sigmoid");
+  GI_REQUIRE(net->bn_groups == 1, "internal: gradient_penalty runs with one BatchNorm group");
   const int64_t T = 4;
   const int chans[5] = {1, 64, 128, 256, 512};
   auto A2 = [&](int i, int half) { return (void*)(net->shared(net->oA2[i]) + (int64_t)half * n * (H >> i) * (W >> i) * chans[i] * T); };
@@ -1185,7 +1186,13 @@ int patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, 
 extern "C" int gi_patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, float* penalty_out) {
   GI_REQUIRE(net && net->bound && net->kind == 1, "gradient_penalty: bound discriminator handle required");
   GI_REQUIRE(xhat && n >= 1 && n <= net->max_n, "gradient_penalty: n=%d (max %d)", n, net->max_n);
-  return patchgan_gradient_penalty(net, xhat, n, lam, penalty_out);
+  // the interpolates are ONE BatchNorm population whatever the stacked real|fake passes around this call use
+  // (gi_net_set_bn_groups): the penalty's primal forward, its backward and the tangent passes all run with one group
+  const int groups = net->bn_groups;
+  net->bn_groups = 1;
+  const int rc = patchgan_gradient_penalty(net, xhat, n, lam, penalty_out);
+  net->bn_groups = groups;
+  return rc;
 }
 
 extern "C" int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n) {

@@ -12,6 +12,7 @@ Differences to the reference, all host-side and listed in DESIGN.md:
     train and test loaders (reconstruction metrics on fused HIP reductions; FID reported as -1, needs
     Inception weights); `state['eval_fn']`, if given, replaces it and is called with (net_G, loader, epoch).
 """
+import contextlib
 import logging
 import os
 import pickle
@@ -23,6 +24,11 @@ from .. import optim, trainer
 from ..lib.models import evaluate, networks, util
 
 
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def setup(state, title):
     state = state.copy()
     state.update({"title": title})
@@ -32,9 +38,11 @@ def setup(state, title):
     os.makedirs(os.path.join(outdir, "log"), exist_ok=True)
     logger = logging.getLogger(title)
     if not logger.handlers:
-        h = logging.FileHandler(os.path.join(outdir, "log", f"{title}.log"))
+        # data-parallel runs: rank 0 owns the log file (and the checkpoints / histories, run_epochs)
+        h = logging.FileHandler(os.path.join(outdir, "log", f"{title}.log")) if _rank() == 0 else logging.NullHandler()
         h.setFormatter(logging.Formatter("%(asctime)s %(message)s"))
         logger.addHandler(h)
+        logger.propagate = _rank() == 0
     logger.setLevel(logging.INFO)
     if not torch.cuda.is_available():
         raise RuntimeError("the HIP backend needs a gfx950 device (there is no CPU fallback)")
@@ -78,11 +86,19 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
     flow_G = util.GradFlow(net_G)
     flows_D = [util.GradFlow(d) for d in nets_D]
     history, eval_hist = [], []
+    side = step.side_stream() if step is not None else None
+    side_keys = set(step.side_keys()) if step is not None else set()
+    rank0 = _rank() == 0
+
+    def _on(stream):
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
     for epoch in range(num_epochs + 1):
         start = time.time()
         sums, g_updates, batches = {}, 0, 0
         acc_g = torch.zeros(len(flow_G.names), device=device)
-        acc_d = [torch.zeros(len(f.names), device=device) for f in flows_D]
+        with _on(side):
+            acc_d = [torch.zeros(len(f.names), device=device) for f in flows_D]
         for bi, (ground, mask, extra) in enumerate(loaders["train"]):
             ground = to_device_images(ground, device, state)
             mask = to_device_images(mask, device, state)
@@ -90,19 +106,29 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
                 L, g_updated = batch_fn(bi, ground, mask, extra.to(device, non_blocking=True).contiguous())
             else:
                 L, g_updated = batch_fn(bi, ground, mask)
+            # values the step produced on its side stream (overlapped critic: its losses, its gradient buffer) are
+            # accumulated ON that stream, in stream order behind the kernels that wrote them and ahead of the next
+            # batch's zero_grad; everything else on the caller's stream. No cross-stream wait per batch.
             for k, v in L.items():
-                sums[k] = sums.get(k, 0) + v.detach().clone()
+                with _on(side if k in side_keys else None):
+                    if k not in sums:
+                        sums[k] = torch.zeros(1, dtype=torch.float32, device=device)
+                    sums[k] += v.detach().view(1)
             batches += 1
-            for f, a in zip(flows_D, acc_d):
-                a += f.measure()
+            with _on(side):
+                for f, a in zip(flows_D, acc_d):
+                    a += f.measure()
             if g_updated:
                 g_updates += 1
                 acc_g += flow_G.measure()
             if bi % log_every == 0:
                 if step is not None:
                     step.poll_overflow(logger)                 # fp16 guard: back the loss scale off after skipped updates
+                    step.sync_for_logging()                    # the values below may come from the side stream
                 logger.info("[epoch %d/%d][batch %d/%d] %s", epoch, num_epochs, bi, len(loaders["train"]),
                             " ".join(f"{k}: {float(v):.4f}" for k, v in L.items()))
+        if step is not None:
+            step.sync_for_logging()
         rec = {k: float(v) / max(batches, 1) for k, v in sums.items()}
         grads = {"avg_g": dict(zip(flow_G.names, (acc_g / g_updates).tolist())) if g_updates
                  else {n: -7777 for n in flow_G.names}}     # -7777 sentinel: minimaxgan_l1.py:209-218
@@ -118,11 +144,12 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
                             for k in ("train", "test") if loaders.get(k) is not None}
                 eval_hist.append(rec_eval)
                 logger.info("VALIDATION: %s", ", ".join(f"{k} - {v}" for k, v in rec_eval.items()))
-            with open(os.path.join(exp_dir, "training_epoch_history.obj"), "wb") as h:
-                pickle.dump(history, h, protocol=pickle.HIGHEST_PROTOCOL)
-            with open(os.path.join(exp_dir, "eval_history.obj"), "wb") as h:
-                pickle.dump(eval_hist, h, protocol=pickle.HIGHEST_PROTOCOL)
-        if epoch % save_every == 0 and epoch > 0:
+            if rank0:        # every rank holds the same replica: one writer
+                with open(os.path.join(exp_dir, "training_epoch_history.obj"), "wb") as h:
+                    pickle.dump(history, h, protocol=pickle.HIGHEST_PROTOCOL)
+                with open(os.path.join(exp_dir, "eval_history.obj"), "wb") as h:
+                    pickle.dump(eval_hist, h, protocol=pickle.HIGHEST_PROTOCOL)
+        if epoch % save_every == 0 and epoch > 0 and rank0:
             # same contract as the reference: G only, plain state_dict (minimaxgan_l1.py:253-255)
             torch.save({k: v.detach().cpu().contiguous() for k, v in net_G.state_dict().items()},
                        os.path.join(exp_dir, "epoch{}_G.pt".format(epoch)))

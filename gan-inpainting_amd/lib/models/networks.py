@@ -423,6 +423,8 @@ class UnetGenerator(HipNet):
         h = C.c_void_p()
         B.check(B.lib().gi_unet_create_ex(ctx, self.num_downs, self.ngf, self.output_nc, self.dropout_p, H, W, max_n, self._dtype,
                                           self.n_slots, C.byref(h)))
+        if getattr(self, "_drop_seed", None) is not None:      # a seed chosen before the handle existed
+            B.check(B.lib().gi_net_set_dropout_seed(h, self._drop_seed))
         return h
 
     def _output_shape(self, n, H, W):

@@ -35,21 +35,26 @@ class _FlatOptimizer:
         self._flags = None
         self._seen = 0
 
-    def _guard_ptr(self, i, net):
-        """Run the finite check on network i's gradients; returns the device flag pointer (None when the guard is off)."""
+    def _guard_ptr(self):
+        """Run the finite check over the gradients of EVERY network of this optimizer into one shared verdict (all of
+        them skip the update or none does, and a skipped update counts once whatever the number of networks); returns
+        the device flag pointer (None when the guard is off)."""
         if not self.guard:
             return None
+        lib = B.lib()
         if self._flags is None:
-            self._flags = [torch.zeros(3, dtype=torch.int32, device=n.flat_params().device) for n in self.nets]
-        g = net.flat_grads()
-        B.check(B.lib().gi_check_finite(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags[i])))
-        return B.ptr(self._flags[i])
+            self._flags = torch.zeros(3, dtype=torch.int32, device=self.nets[0].flat_params().device)
+        for net in self.nets:
+            g = net.flat_grads()
+            B.check(lib.gi_check_finite_scan(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags)))
+        B.check(lib.gi_check_finite_finish(B.get_ctx(self._flags.device), B.ptr(self._flags)))
+        return B.ptr(self._flags)
 
     def poll_skipped(self):
         """Number of updates skipped since the last poll (one device read-back: call it at logging cadence)."""
         if not self.guard or self._flags is None:
             return 0
-        total = int(sum(int(f[0].item()) for f in self._flags))
+        total = int(self._flags[0].item())
         new, self._seen = total - self._seen, total
         return new
 
@@ -73,16 +78,17 @@ class Adam(_FlatOptimizer):
     def step(self):
         self.t += 1
         lib = B.lib()
-        for i, (n, st) in enumerate(zip(self.nets, self.state)):
+        guard = self._guard_ptr()
+        for n, st in zip(self.nets, self.state):
             p, g = n.flat_params(), n.flat_grads()
             B.check(lib.gi_adam_step_guarded(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
-                                             self.lr, self.betas[0], self.betas[1], self.eps, self.t, self.grad_scale,
-                                             self._guard_ptr(i, n)))
+                                             self.lr, self.betas[0], self.betas[1], self.eps, self.t, self.grad_scale, guard))
         self._done()
 
     def poll_skipped(self):
         new = super().poll_skipped()
-        self.t -= new     # skipped updates do not advance the bias correction (applied when the host learns of them)
+        self.t -= new     # one per skipped UPDATE (shared verdict): skipped updates do not advance the bias correction
+        #                   (applied when the host learns of them, i.e. at the plugins' logging cadence)
         return new
 
 
@@ -98,10 +104,11 @@ class RMSprop(_FlatOptimizer):
     @torch.no_grad()
     def step(self):
         lib = B.lib()
-        for i, (n, st) in enumerate(zip(self.nets, self.state)):
+        guard = self._guard_ptr()
+        for n, st in zip(self.nets, self.state):
             p, g = n.flat_params(), n.flat_grads()
             B.check(lib.gi_rmsprop_step_guarded(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["sq"]), p.numel(), self.lr,
-                                                self.alpha, self.eps, self.clamp, self.grad_scale, self._guard_ptr(i, n)))
+                                                self.alpha, self.eps, self.clamp, self.grad_scale, guard))
         self._done()
 
 

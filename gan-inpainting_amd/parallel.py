@@ -20,6 +20,7 @@ class GradSync:
             raise RuntimeError("GradSync needs an initialised torch.distributed process group")
         self.group = group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.bucket_floats = int(bucket_floats)
         self.use_side_stream = use_side_stream
         self._stream = None

@@ -47,6 +47,13 @@ class SyntheticInpainting(torch.utils.data.Dataset):
         return ground, mask, segment
 
 
+def shard_rows(df, rank, world, batchsize):
+    """Rows of `df` for this rank: the first floor(len / (world*batchsize)) * world*batchsize rows, interleaved, so that
+    all ranks get the same number of full batches (drop_last loaders)."""
+    keep = (len(df) // (world * batchsize)) * world * batchsize
+    return df.iloc[:keep].iloc[rank::world].reset_index(drop=True)
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("-exp", "--experiments", nargs="+", required=True)
@@ -94,7 +101,9 @@ def main(argv=None):
         def mk_real(csv, shuffle):
             df = pd.read_csv(os.path.join(args.data, "csv", csv))
             if world > 1:
-                df = df.iloc[rank::world].reset_index(drop=True)          # one shard per rank
+                # every rank must see the same number of batches (each optimizer update holds an all-reduce): cut the
+                # index to a multiple of world * batchsize, then one interleaved shard per rank
+                df = shard_rows(df, rank, world, args.batchsize)
             return torch.utils.data.DataLoader(dataset.InpaintingDataset(args.data, dataframe=df, transform=None),
                                                batch_size=args.batchsize, shuffle=shuffle, drop_last=True, **lkw)
         loaders = {"train": mk_real("train_all_masks.csv", True), "test": mk_real("test_all_masks.csv", True)}     # :75-90

@@ -93,6 +93,8 @@ class _StepBase:
             n.always_sync = False
         if sync is not None:
             sync.broadcast_parameters([net_G] + self.Ds)    # replicas start identical whatever the ranks' RNG state
+            if hasattr(net_G, "set_dropout_seed"):          # ... but draw their own dropout masks
+                net_G.set_dropout_seed(0x5EED0000 + 1000 * sync.rank)
 
     def _bind_optimizers(self, *opts):
         self._opts = opts
@@ -126,9 +128,23 @@ class _StepBase:
             if d._dtype == B.GI_F16:
                 d.set_loss_scale(min(65536.0, 64.0 * n))
 
+    # ---- stream contract for readers of the step's results (plugins: loss accumulation, gradient-flow statistics) ----
+    def side_stream(self):
+        """The HIP stream the discriminator side of the step runs on, or None when everything is on the caller's."""
+        return None
+
+    def side_keys(self):
+        """Keys of the loss dict whose values (and the discriminators' gradient buffers) are produced on side_stream()."""
+        return ()
+
+    def sync_for_logging(self):
+        """Make the caller's stream wait for everything the step has issued on its side stream, so that losses,
+        discriminator gradients and overflow flags can be read from the caller's stream."""
+
     def poll_overflow(self, logger=None):
         """fp16 only, call at logging cadence: when an optimizer skipped updates because its gradients held
         inf/NaN, halve the loss scale of its networks (they re-derive it from the batch geometry otherwise)."""
+        self.sync_for_logging()
         out = 0
         for opt in getattr(self, "_opts", ()):
             new = opt.poll_skipped()
@@ -309,6 +325,10 @@ class WGANStep(_StepBase):
             # [ground | inpainted] of the stacked critic pass: the composite writes its half in place
             self._inp2[k] = torch.empty((2 * ground.shape[0],) + tuple(ground.shape[1:]), dtype=ground.dtype, device=ground.device)
         inp = self._inp2[k][ground.shape[0]:]
+        # the side stream reads the caller's `ground` (critic real half, gradient penalty): tell the caching allocator,
+        # or a per-batch `ground` freed by the caller could be handed to the next batch's H2D copy while the critic
+        # still reads it (critic-only batches never make the main stream wait for the side stream)
+        ground.record_stream(sD)
         if self._evD[k] is not None:
             main.wait_event(self._evD[k])        # the critic pass that read this buffer two batches ago is done
         e0 = main.record_event()
@@ -354,6 +374,16 @@ class WGANStep(_StepBase):
             self._bwd_G(gtok, self.g_gen)
             self.optG.step()
         return self.L
+
+    def side_stream(self):
+        return self._sD if self.overlap else None
+
+    def side_keys(self):
+        return ("d_loss_real", "d_loss_fake", "gp", "g_adv") if self.overlap else ()
+
+    def sync_for_logging(self):
+        if self.overlap:
+            torch.cuda.current_stream(self.G.device).wait_stream(self._sD)
 
     @torch.no_grad()
     def __call__(self, ground, mask, update_g):

@@ -169,6 +169,11 @@ int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi);
  * buffer; flag3 is 3 device ints {running count of bad updates, verdict of this scan (0/1), scratch}. The
  * *_guarded optimizer steps do nothing when guard[1] != 0 (pass the same flag3, or NULL for the plain step). */
 int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
+/* the same in two steps, for ONE optimizer over several flat buffers (Adam over itertools.chain(D_local, D_global),
+ * experiment1_global_local_D.py:123): scan every buffer into the same flag3, then finish once - all networks of the
+ * update share one verdict (all skip or none) and the running count advances by one per skipped update. */
+int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
+int gi_check_finite_finish(gi_ctx* ctx, int* flag3);
 int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
                          float beta1, float beta2, float eps, int step, float grad_scale, const int* guard);
 int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr,

@@ -259,11 +259,27 @@ def weighted_cross_entropy(logits, labels, weight):
     return F.cross_entropy(logits, labels, weight=weight)
 
 
+class _BCE(torch.autograd.Function):
+    """nn.BCELoss as ATen computes it: forward with both log terms clamped at -100, backward
+    (p - t) / max(p (1 - p), 1e-12) / n (so p = 0 or 1 gives finite gradients where differentiating the clamped
+    logs would give 0 * inf)."""
+
+    @staticmethod
+    def forward(ctx, p, target):
+        ctx.save_for_backward(p, target)
+        lp = torch.clamp(torch.log(p), min=-100.0)
+        l1p = torch.clamp(torch.log(1 - p), min=-100.0)
+        return -(target * lp + (1 - target) * l1p).mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        p, target = ctx.saved_tensors
+        return g * (p - target) / torch.clamp(p * (1 - p), min=1e-12) / p.numel(), None
+
+
 def bce_loss(p, target):
     """nn.BCELoss (minimaxgan_l1.py:61,135,141,162): log terms clamped at -100."""
-    lp = torch.clamp(torch.log(p), min=-100.0)
-    l1p = torch.clamp(torch.log(1 - p), min=-100.0)
-    return -(target * lp + (1 - target) * l1p).mean()
+    return _BCE.apply(p, target)
 
 
 def mse_loss(p, target):

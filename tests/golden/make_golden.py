@@ -668,6 +668,84 @@ def case_config5(networks, util, ref_root, name, seed, N, pattern):
     return fx
 
 
+LOSS_CASES = [  # (seed, N, H, W, fractional_edge): masks are binary rectangles, or carry values in (0,1) on their border
+    (801, 2, 48, 40, False), (802, 3, 32, 64, True), (803, 1, 128, 128, False),
+]
+
+
+def case_losses(ref_root, name):
+    """The loss objects the reference's loops build, recorded from the reference classes themselves: the texts of
+    lib/models/loss.py:11-47 (RMSELoss, LocalLoss) are executed at generation time (the module as a whole does not
+    import: loss.py:4), and instantiated as the reference does - `loss.RMSELoss()` (minimaxgan_rmse.py:62),
+    `loss.LocalLoss(nn.L1Loss)` (evaluate.py:115) and `LocalLoss(nn.MSELoss)` (what `LocalLoss(RMSELoss)` turns itself into,
+    loss.py:30-31) - beside the torch built-ins nn.L1Loss / nn.MSELoss / nn.BCELoss / torch.mean in the forms of
+    minimaxgan_l1.py:61-62,134-168, experiment1_global_local_D.py:119,162-196 and wgan_l1.py:137-177. Values and full
+    gradients w.r.t. the prediction; the oracle's functions are asserted equal."""
+    src = open(os.path.join(ref_root, "lib/models/loss.py")).read()
+    ns = {"torch": torch, "nn": torch.nn}
+    exec(compile(src[src.index("class RMSELoss"):src.index("def perceptual_loss")], "reference:loss.py", "exec"), ns)
+    RMSELoss, LocalLoss = ns["RMSELoss"], ns["LocalLoss"]
+    fx = {"cases": np.array([[c[0], c[1], c[2], c[3], int(c[4])] for c in LOSS_CASES], dtype=np.int64)}
+    for i, (seed, N, H, W, frac) in enumerate(LOSS_CASES):
+        y_np, m_np = op.synth_batch(seed, N, H, W, fractional_edge=frac)
+        yh_np, _ = op.synth_batch(seed + 50, N, H, W)
+        y, mask = torch.from_numpy(y_np), torch.from_numpy(m_np)
+        recs = {}
+
+        def run(tag, fn, ofn):
+            yh = torch.from_numpy(yh_np.copy()).requires_grad_(True)
+            v = fn(yh)
+            v.backward()
+            yo = torch.from_numpy(yh_np.copy()).requires_grad_(True)
+            vo = ofn(yo)
+            vo.backward()
+            close(float(vo), float(v), 1e-6, f"{name}.{i}.{tag}")
+            close(yo.grad.numpy(), yh.grad.numpy(), 1e-6, f"{name}.{i}.{tag}.grad")
+            recs[tag] = float(v)
+            fx[f"c{i}_{tag}"] = np.array(float(v), dtype=np.float64)
+            fx[f"c{i}_{tag}_grad"] = yh.grad.numpy().copy()
+
+        run("l1", lambda t: torch.nn.L1Loss()(y, t), lambda t: orc.l1_loss(y, t))
+        run("mse", lambda t: torch.nn.MSELoss()(y, t), lambda t: torch.mean((t - y) ** 2))
+        run("rmse", lambda t: RMSELoss()(t, y), lambda t: orc.rmse_loss(t, y))
+        run("local_l1", lambda t: LocalLoss(torch.nn.L1Loss)(t, y, mask), lambda t: orc.local_loss(t, y, mask, "l1"))
+        run("local_mse", lambda t: LocalLoss(torch.nn.MSELoss)(t, y, mask), lambda t: orc.local_loss(t, y, mask, "mse"))
+        # LocalLoss(RMSELoss) (class passed as evaluate.py / the config-5 plugin intend): the reference constructor calls
+        # RMSELoss(reduction='none'), which its __init__ does not accept
+        try:
+            LocalLoss(RMSELoss)
+            raised = 0
+        except TypeError:
+            raised = 1
+        fx[f"c{i}_local_rmse_ctor_raises"] = np.array(raised)
+        print(f"  {name} case {i}: " + " ".join(f"{k}={v:.6g}" for k, v in recs.items()))
+    # adversarial scalars on (n,) critic outputs
+    rng = np.random.Generator(np.random.PCG64(880))
+    for j, n in enumerate((2, 16, 32)):
+        logit = rng.standard_normal(n).astype(np.float32) * 2.0
+        prob = (1.0 / (1.0 + np.exp(-logit))).astype(np.float32)
+        if j == 0:
+            prob[0] = 1.0          # log(1 - p) clamps at -100 (nn.BCELoss)
+        fx[f"adv{j}_prob"], fx[f"adv{j}_logit"] = prob, logit
+        for tag, src_np, fn, ofn in (
+                ("bce1", prob, lambda p: torch.nn.BCELoss()(p, torch.ones(n)), lambda p: orc.bce_loss(p, torch.ones(n))),
+                ("bce0", prob, lambda p: torch.nn.BCELoss()(p, torch.zeros(n)), lambda p: orc.bce_loss(p, torch.zeros(n))),
+                ("lsgan1", prob, lambda p: torch.nn.MSELoss()(p, torch.ones(n)), lambda p: orc.mse_loss(p, torch.ones(n))),
+                ("lsgan0", prob, lambda p: torch.nn.MSELoss()(p, torch.zeros(n)), lambda p: orc.mse_loss(p, torch.zeros(n))),
+                ("mean", logit, lambda p: torch.mean(p).view(1), lambda p: p.mean().view(1))):
+            p = torch.from_numpy(src_np.copy()).requires_grad_(True)
+            v = fn(p)
+            v.backward(torch.ones_like(v))
+            q = torch.from_numpy(src_np.copy()).requires_grad_(True)
+            vo = ofn(q)
+            vo.backward(torch.ones_like(vo))
+            close(float(vo), float(v), 1e-6, f"{name}.adv{j}.{tag}")
+            close(q.grad.numpy(), p.grad.numpy(), 1e-6, f"{name}.adv{j}.{tag}.grad")
+            fx[f"adv{j}_{tag}"] = np.array(float(v), dtype=np.float64)
+            fx[f"adv{j}_{tag}_grad"] = p.grad.numpy().copy()
+    return fx
+
+
 RESIZE_CASES = [  # (seed, in_h, in_w, size)
     (201, 218, 178, 128), (202, 1024, 1024, 256), (203, 200, 300, 64), (204, 50, 50, 128), (205, 100, 37, 16),
     (206, 9, 1000, 7), (207, 128, 128, 128),
@@ -714,6 +792,7 @@ def main():
         segnet=lambda: case_segnet(networks, "segnet", 95, 2, 128),
         resize=lambda: case_resize("resize"),
         config5_steps=lambda: case_config5(networks, util, args.ref, "config5_steps", 97, 2, [0, 1]),
+        losses=lambda: case_losses(args.ref, "losses"),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):

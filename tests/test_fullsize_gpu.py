@@ -125,3 +125,101 @@ def test_vgg_512_symmetry_and_zero_distance():
     p2, s2 = vgg.perceptual_and_style(y, x, 1.0, 1.0)
     assert float(p1) > 0 and abs(float(p1) - float(p2)) <= 1e-6 * float(p1)
     assert abs(float(s1) - float(s2)) <= 1e-3 * float(s1)                     # Gram atomics: fp32 summation order
+
+
+def test_dual_discriminator_step_properties_256_bs32_fp16():
+    """configs[2]: experiment1_global_local_D 256x256 bs=32 fp16 (two LSGAN discriminators, G step first, mask not
+    ceil-ed, output not composited), three batches."""
+    torch.manual_seed(9)
+    G = networks.get_network("generator", "unet", dtype="fp16").cuda()
+    Dg = networks.PatchGANDiscriminator(sigmoid=True, image_size=256, dtype="fp16").cuda()
+    Dl = networks.PatchGANDiscriminator(sigmoid=True, image_size=256, dtype="fp16").cuda()
+    oG = optim.Adam(G.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    oD = optim.Adam(optim.chain(Dl.parameters(), Dg.parameters()), lr=0.0002, betas=(0.5, 0.999))
+    step = trainer.DualDStep(G, Dg, Dl, oG, oD)
+    for it in range(3):
+        ground, mask = _batch(32, 256, 200 + it)
+        w = [n.flat_params().clone() for n in (G, Dg, Dl)]
+        L = step(ground, mask)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in L.values()), {k: float(v) for k, v in L.items()}
+        assert set(L) >= {"g_adv_global", "g_adv_local", "rmse_global", "rmse_local", "d_real_global", "d_fake_global", "d_real_local", "d_fake_local"}
+        gen = step.gen
+        assert torch.isfinite(gen).all() and float(gen.abs().max()) <= 1.0            # tanh output, not composited (:154)
+        assert torch.equal(step.masked, ground * (1 - mask))                            # the mask is used as it comes (:144), fractional values too
+        assert torch.equal(step.inpainted, mask * gen)                                  # the local discriminator's input (:157)
+        # LSGAN losses of sigmoid outputs against 0 / 1 lie in [0, 1]; RMSE of [0,1] data against a tanh output in [0, 2]
+        for k in ("g_adv_global", "g_adv_local", "d_real_global", "d_fake_global", "d_real_local", "d_fake_local"):
+            assert 0.0 <= float(L[k]) <= 1.0, (k, float(L[k]))
+        assert 0.0 < float(L["rmse_local"]) <= float(L["rmse_global"]) * 1.0001 <= 2.0  # masked difference <= full difference
+        for n, w0 in zip((G, Dg, Dl), w):                                                # every network moved by at most lr per element (Adam, t = 1..3)
+            d = (n.flat_params() - w0).abs().max().item()
+            assert 0 < d <= 0.0002 * 1.8, d
+    assert step.poll_overflow() == 0
+
+
+def test_wgan_gp_step_properties_128_bs16_fp32():
+    """configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient penalty (lambda 10) in place of the clipping, overlapped
+    and stacked like the plugin runs it; 6 batches, generator update on the fifth."""
+    torch.manual_seed(10)
+    G = networks.get_network("generator", "unet", dtype="fp32").cuda()
+    D = networks.PatchGANDiscriminator(sigmoid=False, image_size=128, dtype="fp32").cuda()
+    oG, oD = optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5)
+    step = trainer.WGANStep(G, D, oG, oD, recon="l1", gp_lambda=10.0, overlap=True, stacked=True)
+    g0 = G.flat_params().clone()
+    pens = []
+    for it in range(6):
+        ground, mask = _batch(16, 128, 300 + it)
+        d0 = D.flat_params().clone()
+        L = step(ground, mask, it == 4)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in L.values())
+        pens.append(float(L["gp"]))
+        assert pens[-1] >= 0.0
+        mc = torch.ceil(mask)
+        assert torch.equal(step.inpainted[mc == 0], ground[mc == 0])
+        assert not torch.equal(D.flat_params(), d0)
+        if it < 4:
+            assert torch.equal(G.flat_params(), g0)
+    assert not torch.equal(G.flat_params(), g0)
+    assert float(D.flat_params().abs().max()) > 0.011          # not clipped: the penalty replaces wgan_l1.py:151-153
+    # the penalty of a critic with |grad_x D| far from 1 is positive; with lambda = 0 the same call returns exactly 0
+    assert max(pens) > 0
+    ground, mask = _batch(16, 128, 399)
+    D.zero_grad()
+    z = D.gradient_penalty(ground, (ground * 0.5).contiguous(), torch.full((16,), 0.25), lam=0.0)
+    assert float(z) == 0.0 and float(D.flat_grads().abs().max()) == 0.0
+
+
+def test_config5_step_properties_512_bs8_fp16():
+    """configs[4]: wgan_perceptual_style_faceparsing 512x512 bs=8 fp16: critic batch, then a batch with the generator
+    update carrying every extra (VGG-19 perceptual / style constants, TV, frozen ngf=32 face-parsing network + weighted CE)."""
+    import functools
+    torch.manual_seed(11)
+    G = networks.get_network("generator", "unet", dtype="fp16").cuda()
+    D = networks.PatchGANDiscriminator(sigmoid=False, image_size=512, dtype="fp16").cuda()
+    seg = networks.UnetGenerator(1, 4, 7, ngf=32, norm_layer=functools.partial(torch.nn.BatchNorm2d, affine=True, track_running_stats=True),
+                                 use_dropout='False', dtype="fp16").cuda()
+    vgg = networks.VGG19Wrapper(max_pairs=8).cuda()
+    oG, oD = optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5)
+    step = trainer.WGANPerceptualStep(G, D, oG, oD, vgg=vgg, segment_model=seg, clip=0.01, overlap=True)
+    seg_w = step.seg.flat_params().clone()
+    g0 = G.flat_params().clone()
+    for it, upd in enumerate((False, True)):
+        ground, mask = _batch(8, 512, 400 + it)
+        labels = torch.randint(0, 4, (8, 512, 512), generator=torch.Generator().manual_seed(it)).cuda()
+        L = step(ground, mask, upd, segment=labels)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in L.values()), {k: float(v) for k, v in L.items()}
+        mc = torch.ceil(mask)
+        assert torch.equal(step.inpainted[mc == 0], ground[mc == 0])
+        assert float(D.flat_params().abs().max()) <= 0.01 + 1e-9
+        if not upd:
+            assert torch.equal(G.flat_params(), g0)
+    assert set(L) >= {"d_loss_real", "d_loss_fake", "g_adv", "recon_global", "recon_local", "tv", "perceptual", "style", "face_parsing"}
+    assert not torch.equal(G.flat_params(), g0)
+    assert torch.equal(step.seg.flat_params(), seg_w)                     # the face-parsing network is frozen (:67-68)
+    assert float(L["recon_local"]) > 0 and float(L["tv"]) > 0 and float(L["perceptual"]) > 0 and float(L["style"]) > 0
+    # CE of a random-init 4-class net with weights [0,1.2,0.7,0.7], times 0.01: around 0.01 * ln 4
+    assert 0.002 < float(L["face_parsing"]) < 0.1, float(L["face_parsing"])
+    assert step.poll_overflow() == 0

@@ -93,3 +93,19 @@ def test_offline_scripts_host_logic(tmp_path):
     assert all(p.endswith(f"epoch{ep}_G.pt") for ep, p in found)
     b = lm.build_parser().parse_args(["--exp-root", "R", "--data", "D"])
     assert (b.exp, b.imagedim, b.batchsize) == ("wgan_rmse", 128, 64)      # local_mse.py:40,56,69
+
+
+def test_real_data_shards_have_equal_batch_counts():
+    """train.py --data <dir> under torch.distributed.run: every rank must see the same number of full batches, or the rank
+    with one batch more blocks forever in its gradient all-reduce (127 rows, 2 ranks, bs=32 used to give 2 vs 1)."""
+    import pandas as pd
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import train
+    for rows, world, bs in ((127, 2, 32), (1000, 8, 32), (64, 2, 32), (63, 2, 32), (5000, 3, 7)):
+        df = pd.DataFrame({"groundtruth_source": [f"g{i}" for i in range(rows)]})
+        shards = [train.shard_rows(df, r, world, bs) for r in range(world)]
+        counts = {len(s) // bs for s in shards}
+        assert len(counts) == 1 and all(len(s) % bs == 0 for s in shards), (rows, world, bs, [len(s) for s in shards])
+        assert counts.pop() == rows // (world * bs)
+        seen = sorted(v for s in shards for v in s["groundtruth_source"])
+        assert len(seen) == len(set(seen))               # disjoint

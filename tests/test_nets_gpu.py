@@ -55,7 +55,7 @@ def compare_grads(net, OP, OP64, dtype, what):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-@pytest.mark.parametrize("cfg", [(6, 2, 64), (7, 2, 128), (7, 1, 256)])
+@pytest.mark.parametrize("cfg", [(6, 2, 64), (7, 2, 128), (7, 1, 256), (7, 1, 512)])   # 512: config 5's size (TW = 32 patch tiles, 256-wide maps)
 def test_unet_forward_backward_vs_oracle(dtype, cfg):
     nd, N, HW = cfg
     seed = 100 + nd + HW

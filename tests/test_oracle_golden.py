@@ -187,3 +187,35 @@ def test_resize_oracle_equals_pillow_fixture():
         except ImportError:
             continue
         assert np.array_equal(np.asarray(Image.fromarray(a, mode="L").resize((nw, nh), Image.BILINEAR)), fx[f"out_{i}"])
+
+
+def test_loss_objects():
+    """oracle's loss functions == the reference's RMSELoss / LocalLoss classes and the torch built-ins the plugins call
+    (tests/golden/losses.npz, recorded from the executed reference class texts): values and full gradients."""
+    fx = load("losses")
+    for i, (seed, N, H, W, frac) in enumerate(fx["cases"].tolist()):
+        y_np, m_np = op.synth_batch(seed, N, H, W, fractional_edge=bool(frac))
+        yh_np, _ = op.synth_batch(seed + 50, N, H, W)
+        y, mask = torch.from_numpy(y_np), torch.from_numpy(m_np)
+        fns = dict(l1=lambda t: orc.l1_loss(y, t), mse=lambda t: torch.mean((t - y) ** 2), rmse=lambda t: orc.rmse_loss(t, y),
+                   local_l1=lambda t: orc.local_loss(t, y, mask, "l1"), local_mse=lambda t: orc.local_loss(t, y, mask, "mse"))
+        for tag, fn in fns.items():
+            t = torch.from_numpy(yh_np.copy()).requires_grad_(True)
+            v = fn(t)
+            v.backward()
+            assert relerr(float(v.detach()), fx[f"c{i}_{tag}"]) < 1e-6, (i, tag)
+            ref = fx[f"c{i}_{tag}_grad"]
+            assert np.abs(t.grad.numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (i, tag)
+        assert int(fx[f"c{i}_local_rmse_ctor_raises"]) == 1     # LocalLoss(RMSELoss) cannot be built in the reference
+    for j in range(3):
+        prob, logit = fx[f"adv{j}_prob"], fx[f"adv{j}_logit"]
+        n = len(prob)
+        for tag, src, fn in (("bce1", prob, lambda p: orc.bce_loss(p, torch.ones(n))), ("bce0", prob, lambda p: orc.bce_loss(p, torch.zeros(n))),
+                             ("lsgan1", prob, lambda p: orc.mse_loss(p, torch.ones(n))), ("lsgan0", prob, lambda p: orc.mse_loss(p, torch.zeros(n))),
+                             ("mean", logit, lambda p: p.mean())):
+            p = torch.from_numpy(src.copy()).requires_grad_(True)
+            v = fn(p)
+            v.backward()
+            assert relerr(float(v.detach()), fx[f"adv{j}_{tag}"]) < 1e-6, (j, tag)
+            ref = fx[f"adv{j}_{tag}_grad"]
+            assert np.abs(p.grad.numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (j, tag)

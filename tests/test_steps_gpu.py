@@ -247,3 +247,30 @@ def test_fp16_overflow_guard_skips_the_update_and_backs_off():
     torch.cuda.synchronize()
     assert not torch.equal(D.flat_params(), before) and step.poll_overflow() == 0
     assert torch.isfinite(D.flat_params()).all()
+
+
+def test_one_optimizer_over_two_discriminators_shares_one_overflow_verdict():
+    """Adam over itertools.chain(D_local, D_global) (experiment1_global_local_D.py:123): inf in ONE network's gradients
+    skips the update of BOTH (one verdict per update), counts as one skipped update, and rewinds the bias-correction
+    step by one."""
+    G, (Dg, Dl) = build(51, [52, 53], True, "fp16")
+    oD = optim.Adam(optim.chain(Dl.parameters(), Dg.parameters()), lr=0.0002, betas=(0.5, 0.999))
+    assert oD.guard and len(oD.nets) == 2
+    for d in (Dg, Dl):
+        d.flat_grads().normal_(0, 1e-3)
+    oD.step()
+    torch.cuda.synchronize()
+    assert oD.poll_skipped() == 0 and oD.t == 1
+    wg, wl = Dg.flat_params().clone(), Dl.flat_params().clone()
+    m = [st["m"].clone() for st in oD.state]
+    Dl.flat_grads()[777] = float("nan")                  # only the local discriminator overflows
+    oD.step()
+    torch.cuda.synchronize()
+    assert torch.equal(Dg.flat_params(), wg) and torch.equal(Dl.flat_params(), wl), "a network updated although the step was skipped"
+    assert all(torch.equal(st["m"], mm) for st, mm in zip(oD.state, m))
+    assert oD.t == 2 and oD.poll_skipped() == 1 and oD.t == 1
+    Dl.flat_grads()[777] = 0.0
+    oD.step()
+    torch.cuda.synchronize()
+    assert oD.poll_skipped() == 0 and oD.t == 2
+    assert not torch.equal(Dg.flat_params(), wg) and not torch.equal(Dl.flat_params(), wl)

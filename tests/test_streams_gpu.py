@@ -1,0 +1,67 @@
+"""GPU tier: stream hygiene of the overlapped WGAN step (trainer.WGANStep(overlap=True), the default of the WGAN
+plugins): the critic lives on a side HIP stream and reads the caller's per-batch `ground`. The caching allocator
+must know (record_stream), and readers of the step's results must be ordered behind the side stream."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gan_inpainting_amd  # noqa: F401,E402
+from gan_inpainting_amd import optim, trainer  # noqa: E402
+from gan_inpainting_amd.lib.models import networks  # noqa: E402
+from oracle import params as op  # noqa: E402
+
+
+def _build(seed, hw=64, nd=6, dtype="fp16"):
+    sd = lambda P: {k: torch.from_numpy(np.array(v)) for k, v in P.items()}   # noqa: E731
+    G = networks.UnetGenerator(1, 1, nd, ngf=64, use_dropout="False", dtype=dtype)
+    G.load_state_dict(sd(op.make_unet_params(seed, num_downs=nd)))
+    D = networks.PatchGANDiscriminator(sigmoid=False, image_size=hw, dtype=dtype)
+    D.load_state_dict(sd(op.make_patchgan_params(seed + 1, hw, hw)))
+    G, D = G.cuda(), D.cuda()
+    G.set_dropout_seed(99)
+    return G, D
+
+
+def _run(overlap, batches, churn):
+    """`churn`: like a data loader, every batch's inputs are fresh device allocations that are dropped as soon as
+    the step returns, and the freed blocks are immediately re-used for junk written on the main stream."""
+    torch.manual_seed(0)
+    G, D = _build(11)
+    step = trainer.WGANStep(G, D, optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5), recon="rmse",
+                            clip=0.01, overlap=overlap)
+    losses = []
+    for it in range(batches):
+        g, m = op.synth_batch(5000 + it, 8, 64, 64)
+        ground, mask = torch.from_numpy(g).cuda(), torch.from_numpy(m).cuda()
+        L = step(ground, mask, it % 3 == 2)
+        if churn:
+            shape = ground.shape
+            del ground, mask
+            for _ in range(4):     # grab the freed blocks and scribble over them on the main stream
+                junk = torch.full(shape, 1e4, device="cuda")
+                del junk
+        step.sync_for_logging()
+        losses.append({k: float(v) for k, v in L.items()})
+    torch.cuda.synchronize()
+    return G.flat_params().clone(), D.flat_params().clone(), losses
+
+
+def test_overlapped_step_with_per_batch_inputs_equals_serial_schedule():
+    """Bit for bit: same kernels, same order per network. Without ground.record_stream(side stream) the critic's
+    real half reads blocks the allocator has already handed to the next allocation on the main stream."""
+    g0, d0, l0 = _run(False, 7, False)
+    g1, d1, l1 = _run(True, 7, True)
+    assert torch.equal(d0, d1), "critic weights differ between the serial and the overlapped schedule"
+    assert torch.equal(g0, g1), "generator weights differ between the serial and the overlapped schedule"
+    assert l0 == l1
+
+
+def test_side_stream_contract():
+    G, D = _build(12)
+    step = trainer.WGANStep(G, D, optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5), overlap=True)
+    assert step.side_stream() is step._sD and "d_loss_real" in step.side_keys()
+    G2, D2 = _build(13)
+    step2 = trainer.WGANStep(G2, D2, optim.RMSprop(G2.parameters(), lr=5e-5), optim.RMSprop(D2.parameters(), lr=5e-5), overlap=False)
+    assert step2.side_stream() is None and step2.side_keys() == ()
