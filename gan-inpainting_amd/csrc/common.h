@@ -106,6 +106,11 @@ struct IgemmArgs {
   const void* add; int ldadd, coffadd;   // with mask: a second gradient added where mask > 0 before the slope (the skip
                                          // half of a U-Net concat gradient, which passed the parent's in-place ReLU)
   int mask_applied;
+  // column statistics without partial rows (stat_acc.h): every tile adds its column sum / sum of squares into the exact
+  // per-channel accumulators stat_acc[group][cout][4] (64-bit words, zeroed by the caller). stat_pg > 0: the GEMM rows
+  // (small-grid pixels) are two consecutive BatchNorm populations of stat_pg rows each (a multiple of 256), rows >=
+  // stat_pg add to group 1. Takes precedence over `partials`.
+  unsigned long long* stat_acc; int stat_pg;
 };
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
 
@@ -150,6 +155,24 @@ int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64
                    const float* beta, float* running_mean, float* running_var, float* scale, float* shift,
                    float* save_mean, float* save_invstd, int train, float momentum, float eps, int groups = 1,
                    int64_t part_stride = 0, int out_stride = 0);
+// The same two steps from the exact accumulators the GEMM epilogues added to (IgemmArgs::stat_acc, stat_acc.h), train
+// mode only. acc: [groups][c][4] 64-bit words; count = pixels per population; scale / shift / save_* as above, the
+// populations' vectors out_stride floats apart.
+struct BnAccArgs {
+  const unsigned long long* acc;
+  const float* gamma; const float* beta;
+  float* running_mean; float* running_var;
+  float* scale; float* shift; float* save_mean; float* save_invstd;
+  int64_t count;
+  float momentum, eps;
+  int groups, out_stride;
+  unsigned long long* zero_next; int zero_words;   // optional: a region the pass clears for the layer's next use (ping-pong)
+};
+int op_bn_finalize_acc(hipStream_t st, int c, const BnAccArgs& b);
+// finalize + normalise + activation (+ dropout) in ONE pass: no launch between the GEMM and this one. drop_mask non-null
+// with drop_p > 0: the keep-mask is drawn in the pass (seed drop_seed) and stored there; drop_p == 0: the mask is read.
+int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy, int act,
+                    uint8_t* drop_mask, float drop_scale, uint64_t drop_seed, float drop_p, const BnAccArgs& b);
 // pg in (0, pixels): two BatchNorm populations, pixels >= pg use scale/shift + gstride
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
                 const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale,
@@ -179,6 +202,9 @@ struct ActBnBwdArgs {
                                       // sign(act input) = sign(fma(x, scale, shift)) replaces the read of y
   int groups;                         // 2: the tensor is two consecutive BatchNorm populations (save_mean / save_invstd of
   int stat_stride;                    //    the second at +stat_stride floats), reduced separately in the same launches
+  // non-null (has_bn): exact accumulators [groups][c][4] (stat_acc.h, zeroed): the reduce pass adds into them and the apply
+  // pass derives its coefficients itself - two launches instead of three; the apply pass then clears zero_next.
+  unsigned long long* acc; unsigned long long* zero_next; int zero_words;
 };
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a);
 int op_bwd_rows_per_block(int64_t pixels);   // rows one reduce workgroup covers (groups = 2 needs pixels/2 to be a multiple)

@@ -3,7 +3,10 @@
 // optimizers, gradient statistics, weight packing. All reductions are two-stage and deterministic
 // (per-block partials + fixed-order final sum) except where an accumulate-into-gradient semantic
 // makes a float atomic the natural form.
+#include <stdlib.h>
+
 #include "common.h"
+#include "stat_acc.h"
 
 namespace {
 
@@ -102,13 +105,73 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials,
   }
 }
 
+// The same from the exact accumulators (stat_acc.h) the GEMM epilogues added their tile sums to: acc[group][c][4].
+// Called by one thread per channel; `write` (one block per launch) also stores the vectors the backward needs and
+// moves the running statistics, population by population in the order separate calls would.
+struct BnAccP {
+  const unsigned long long* acc;   // [groups][c][GI_STAT_WORDS]
+  const float* gamma; const float* beta;
+  float* rmean; float* rvar;
+  float* scale; float* shift; float* smean; float* sinv;   // [groups] x out_stride floats apart
+  double count;                    // pixels per population
+  float momentum, eps;
+  int groups, out_stride;
+  unsigned long long* zero_next;   // the layer's OTHER accumulator region: cleared here for its next use (ping-pong), so
+  int zero_words;                  // no memset launch is needed; nothing else touches it while this kernel runs
+};
+__device__ __forceinline__ void zero_words64(unsigned long long* p, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) p[i] = 0ull;
+}
+__device__ __forceinline__ void bn_from_acc(const BnAccP& a, int c, int ch, int j, bool write, float& sc_out, float& sh_out) {
+  const unsigned long long* w = a.acc + ((int64_t)j * c + ch) * GI_STAT_WORDS;
+  const double m = gi_stat_read(w) / a.count;
+  double v = gi_stat_read(w + 2) / a.count - m * m;
+  if (v < 0.0) v = 0.0;
+  const float mean = (float)m, var = (float)v;
+  const float inv = 1.0f / sqrtf(var + a.eps);
+  const float sc = a.gamma[ch] * inv;
+  sc_out = sc;
+  sh_out = a.beta[ch] - mean * sc;
+  if (write) {
+    const float unbiased = a.count > 1.0 ? (float)(v * a.count / (a.count - 1.0)) : var;
+    a.rmean[ch] = (1.f - a.momentum) * a.rmean[ch] + a.momentum * mean;
+    a.rvar[ch] = (1.f - a.momentum) * a.rvar[ch] + a.momentum * unbiased;
+    const int o = j * a.out_stride + ch;
+    a.scale[o] = sc;
+    a.shift[o] = sh_out;
+    a.smean[o] = mean;
+    a.sinv[o] = inv;
+  }
+}
+// stand-alone form (consumers that apply the affine map themselves: C1Affine, HeadArgs::scale4)
+__global__ void __launch_bounds__(256) bn_finalize_acc_kernel(BnAccP a, int c) {
+  if (blockIdx.x == 0 && a.zero_next) zero_words64(a.zero_next, a.zero_words);
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  if (ch >= c) return;
+  float sc, sh;
+  for (int j = 0; j < a.groups; ++j) bn_from_acc(a, c, ch, j, true, sc, sh);
+}
+
+// dropout keep-mask of element i under `seed` (splitmix64 of a counter), keep with probability 1 - p
+__device__ __forceinline__ uint8_t dropout_keep(uint64_t seed, int64_t i, uint32_t thresh) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return ((uint32_t)(z >> 32) >= thresh) ? 1 : 0;
+}
+
 // grid-stride is a multiple of the chunks-per-pixel (a power of two <= 256), so a thread's channel
 // chunk never changes: scale/shift live in registers, index math is shifts.
+// FUSED: scale / shift come from the exact accumulators (every block derives the vectors of all channels into LDS,
+// block 0 also publishes them and updates the running statistics): no finalize launch between GEMM and this pass.
+// GEN: the dropout keep-mask is drawn here (and stored for the backward) instead of by a separate fill launch.
 // G2: two BatchNorm populations in one pass, pixels >= pg use the second scale/shift set (at +gstride floats).
-template <typename T, bool G2>
+template <typename T, bool G2, bool FUSED>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, int64_t pixels, int c, int ldy, int coffy,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int act, const uint8_t* drop, float drop_scale, int64_t pg, int gstride) {
+                                                       int act, uint8_t* drop, float drop_scale, int64_t pg, int gstride,
+                                                       BnAccP fa, uint64_t drop_seed, uint32_t drop_thresh) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int cpp = c / EPC;
   const int lg = 31 - __builtin_clz(cpp);
@@ -116,11 +179,30 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
   const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int cc = (int)(gid0 & (cpp - 1));
   float sc[EPC], sh[EPC], sc1[G2 ? EPC : 1], sh1[G2 ? EPC : 1];
+  if constexpr (FUSED) {
+    extern __shared__ __attribute__((aligned(16))) float aff[];   // [groups][2][c]
+    for (int ch = threadIdx.x; ch < c; ch += 256)
+      for (int j = 0; j < fa.groups; ++j) {
+        float a, b;
+        bn_from_acc(fa, c, ch, j, blockIdx.x == 0, a, b);
+        aff[(j * 2) * c + ch] = a;
+        aff[(j * 2 + 1) * c + ch] = b;
+      }
+    if (blockIdx.x == 0 && fa.zero_next) zero_words64(fa.zero_next, fa.zero_words);
+    __syncthreads();
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { sc[e] = scale ? scale[cc * EPC + e] : 1.f; sh[e] = scale ? shift[cc * EPC + e] : 0.f; }
-  if constexpr (G2) {
+    for (int e = 0; e < EPC; ++e) { sc[e] = aff[cc * EPC + e]; sh[e] = aff[c + cc * EPC + e]; }
+    if constexpr (G2) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { sc1[e] = scale[gstride + cc * EPC + e]; sh1[e] = shift[gstride + cc * EPC + e]; }
+      for (int e = 0; e < EPC; ++e) { sc1[e] = aff[2 * c + cc * EPC + e]; sh1[e] = aff[3 * c + cc * EPC + e]; }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { sc[e] = scale ? scale[cc * EPC + e] : 1.f; sh[e] = scale ? shift[cc * EPC + e] : 0.f; }
+    if constexpr (G2) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sc1[e] = scale[gstride + cc * EPC + e]; sh1[e] = shift[gstride + cc * EPC + e]; }
+    }
   }
   for (int64_t gid = gid0; gid < total; gid += (int64_t)gridDim.x * 256) {
     const int64_t pix = gid >> lg;
@@ -135,8 +217,23 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
       v[e] = t;
     }
     if (drop) {
+      const int64_t e0 = pix * c + cc * EPC;
+      if (drop_thresh) {     // draw the keep-mask here; the backward reads it back
+        uint8_t k[EPC];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) v[e] = drop[pix * c + cc * EPC + e] ? v[e] * drop_scale : 0.f;
+        for (int e = 0; e < EPC; ++e) k[e] = dropout_keep(drop_seed, e0 + e, drop_thresh);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = k[e] ? v[e] * drop_scale : 0.f;
+        if constexpr (EPC == 8) {
+          *(uint2*)(drop + e0) = uint2{(unsigned)k[0] | ((unsigned)k[1] << 8) | ((unsigned)k[2] << 16) | ((unsigned)k[3] << 24),
+                                       (unsigned)k[4] | ((unsigned)k[5] << 8) | ((unsigned)k[6] << 16) | ((unsigned)k[7] << 24)};
+        } else {
+          *(unsigned*)(drop + e0) = (unsigned)k[0] | ((unsigned)k[1] << 8) | ((unsigned)k[2] << 16) | ((unsigned)k[3] << 24);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = drop[e0 + e] ? v[e] * drop_scale : 0.f;
+      }
     }
     store_vec<T, EPC>(y, pix * ldy + coffy + cc * EPC, v);
   }
@@ -188,6 +285,12 @@ struct BwdP {
   int stat_stride;   // floats between the populations' mean / inv vectors; sums are [group][2][c]
   const float* scale; const float* shift;   // non-null: the activation's sign comes from fma(x, scale, shift), the
                                             // forward's own pre-activation value, instead of a read of y
+  // exact-accumulator form (stat_acc.h): the reduce pass adds {sum dz, sum dz*xhat} into acc[group][c][4] and the apply
+  // pass derives its coefficients from them itself (no sums launch). acc null in the apply pass = running-statistics
+  // BatchNorm (both sums zero). Block 0 of the apply pass accumulates dgamma / dbeta and clears zero_next.
+  unsigned long long* acc;
+  float* dgamma; float* dbeta; float inv_loss_scale; float invM;
+  unsigned long long* zero_next; int zero_words;
 };
 
 // The upstream gradients of one 16-byte chunk: g1 (unmasked) and g2 (passes the parent's ReLU, masked by [y > 0]).
@@ -264,9 +367,15 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
     for (int i = 1; i < RL; ++i)
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { s[e] += red[(i * Q + q) * EPC + e]; sx[e] += red[256 * EPC + (i * Q + q) * EPC + e]; }
-    float* ps = p.partials + ((int64_t)blockIdx.x * 2) * p.c + q * EPC;
+    if (p.acc) {
+      unsigned long long* w = p.acc + ((int64_t)(r0 >= p.pg ? p.c : 0) + q * EPC) * GI_STAT_WORDS;
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { ps[e] = s[e]; ps[p.c + e] = sx[e]; }
+      for (int e = 0; e < EPC; ++e) { gi_stat_add(w + e * GI_STAT_WORDS, s[e]); gi_stat_add(w + e * GI_STAT_WORDS + 2, sx[e]); }
+    } else {
+      float* ps = p.partials + ((int64_t)blockIdx.x * 2) * p.c + q * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { ps[e] = s[e]; ps[p.c + e] = sx[e]; }
+    }
   }
 }
 
@@ -313,6 +422,7 @@ __global__ void __launch_bounds__(256) bwd_sums_kernel(const float* partials, in
 //   dx = gamma*inv*(dz - s1/M - xhat*s2/M) = k1*dz + k2*x + k3,   k1 = gamma*inv, k2 = -k1*inv*s2/M, k3 = -k1*s1/M - k2*mean:
 // the grid stride is a multiple of the chunks per pixel, so a thread's channels never change and the coefficients
 // (both populations' with G2) stay in registers.
+// HAS_BN = 2: the coefficients come from the exact accumulators (BwdP::acc), derived by every block into LDS
 template <typename T, int HAS_BN, bool G2>
 __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   constexpr int EPC = 16 / (int)sizeof(T);
@@ -323,7 +433,41 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   const int cc = (int)(gid0 & (cpp - 1));
   constexpr int NG = G2 ? 2 : 1;
   float k1[NG][EPC], k2[NG][EPC], k3[NG][EPC], sc[NG][EPC], sh[NG][EPC];
-  if (HAS_BN) {   // coefficient rows written by bwd_sums_kernel: [group][8][c]
+  if constexpr (HAS_BN == 2) {
+    extern __shared__ __attribute__((aligned(16))) float coef[];   // [groups][5][c]: k1, k2, k3, scale, shift
+    const int c = p.c;
+    for (int ch = threadIdx.x; ch < c; ch += 256)
+      for (int g = 0; g < NG; ++g) {
+        float s1 = 0.f, s2 = 0.f;
+        if (p.acc) {
+          const unsigned long long* w = p.acc + ((int64_t)g * c + ch) * GI_STAT_WORDS;
+          s1 = (float)gi_stat_read(w);
+          s2 = (float)gi_stat_read(w + 2);
+        }
+        const int so = g * p.stat_stride + ch;
+        const float iv = p.inv[so];
+        const float a1 = p.gamma[ch] * iv;
+        const float a2 = -a1 * iv * s2 * p.invM;
+        float* o = coef + (int64_t)g * 5 * c;
+        o[ch] = a1;
+        o[c + ch] = a2;
+        o[2 * c + ch] = -a1 * s1 * p.invM - a2 * p.mean[so];
+        o[3 * c + ch] = p.scale ? p.scale[so] : 0.f;
+        o[4 * c + ch] = p.scale ? p.shift[so] : 0.f;
+        if (blockIdx.x == 0) {     // parameter gradients accumulate population by population, as separate calls would
+          if (p.dbeta) p.dbeta[ch] += s1 * p.inv_loss_scale;
+          if (p.dgamma) p.dgamma[ch] += s2 * p.inv_loss_scale;
+        }
+      }
+    if (blockIdx.x == 0 && p.zero_next) zero_words64(p.zero_next, p.zero_words);
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float* o = coef + (int64_t)g * 5 * c + cc * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { k1[g][e] = o[e]; k2[g][e] = o[c + e]; k3[g][e] = o[2 * c + e]; sc[g][e] = o[3 * c + e]; sh[g][e] = o[4 * c + e]; }
+    }
+  } else if (HAS_BN) {   // coefficient rows written by bwd_sums_kernel: [group][8][c]
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const float* o = p.sums + (int64_t)g * 8 * p.c + cc * EPC;
@@ -643,26 +787,28 @@ __global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n,
 
 // ---- optimizers --------------------------------------------------------------------------------
 // guard (may be null): guard[1] != 0 means "the gradients of this update hold inf/NaN" (gi_check_finite): skip it whole
-__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t count, float lr,
-                                                   float b1, float b2, float eps, float bc1, float sqrt_bc2, float gs,
+// omb1 / omb2 / step_size: 1 - beta1, 1 - beta2 and lr / bias_correction1 are formed in double on the host and rounded once,
+// as torch.optim does with its Python floats (1.f - 0.999f differs from float(1 - 0.999) by 1e-4 relative)
+__global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t count, float step_size,
+                                                   float b1, float b2, float eps, float omb1, float omb2, float sqrt_bc2, float gs,
                                                    const int* guard) {
   if (guard && guard[1]) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const float gg = g[i] * gs;
-    const float mm = b1 * m[i] + (1.f - b1) * gg;
-    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    const float mm = b1 * m[i] + omb1 * gg;
+    const float vv = b2 * v[i] + omb2 * gg * gg;
     m[i] = mm;
     v[i] = vv;
     const float denom = sqrtf(vv) / sqrt_bc2 + eps;
-    p[i] = p[i] - (lr / bc1) * (mm / denom);
+    p[i] = p[i] - step_size * (mm / denom);
   }
 }
 __global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, float* sq, int64_t count, float lr,
-                                                      float alpha, float eps, float clampv, float gs, const int* guard) {
+                                                      float alpha, float oma, float eps, float clampv, float gs, const int* guard) {
   if (guard && guard[1]) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const float gg = g[i] * gs;
-    const float s = alpha * sq[i] + (1.f - alpha) * gg * gg;
+    const float s = alpha * sq[i] + oma * gg * gg;
     sq[i] = s;
     float w = p[i] - lr * (gg / (sqrtf(s) + eps));
     if (clampv > 0.f) w = fminf(fmaxf(w, -clampv), clampv);
@@ -771,13 +917,8 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs P) {
 }
 
 __global__ void __launch_bounds__(256) dropout_fill_kernel(uint8_t* mask, int64_t count, uint64_t seed, uint32_t thresh) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);   // splitmix64 of a counter
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    mask[i] = ((uint32_t)(z >> 32) >= thresh) ? 1 : 0;   // keep with probability 1-p
-  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    mask[i] = dropout_keep(seed, i, thresh);
 }
 __global__ void __launch_bounds__(256) mask_layout_kernel(const uint8_t* src, uint8_t* dst, int n, int c, int hw, int to_nhwc) {
   const int64_t total = (int64_t)n * c * hw;
@@ -814,6 +955,12 @@ int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64
   return GI_OK;
 }
 
+static uint32_t dropout_thresh(float p) {   // keep when the 32-bit draw >= thresh
+  const double t = (double)p * 4294967296.0;
+  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  return thresh ? thresh : 1u;
+}
+
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
                 const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale, int64_t pg,
                 int gstride) {
@@ -822,7 +969,46 @@ int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixel
   const int grid = nblocks(pixels * (c / epc), 4);
   const bool g2 = pg > 0 && pg < pixels;
   GI_REQUIRE(!g2 || scale, "bn_apply: two groups need scale/shift");
-#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G>), dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, drop_mask, drop_scale, pg, gstride)
+  BnAccP fa = {};
+#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G, false>), dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, (uint8_t*)drop_mask, drop_scale, pg, gstride, fa, (uint64_t)0, (uint32_t)0)
+  if (dtype == GI_F16) { if (g2) GI_BN_APPLY(half_t, true); else GI_BN_APPLY(half_t, false); }
+  else { if (g2) GI_BN_APPLY(float, true); else GI_BN_APPLY(float, false); }
+#undef GI_BN_APPLY
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+static void fill_acc_params(BnAccP& fa, const BnAccArgs& b) {
+  fa.acc = b.acc; fa.gamma = b.gamma; fa.beta = b.beta; fa.rmean = b.running_mean; fa.rvar = b.running_var;
+  fa.scale = b.scale; fa.shift = b.shift; fa.smean = b.save_mean; fa.sinv = b.save_invstd;
+  fa.count = (double)b.count; fa.momentum = b.momentum; fa.eps = b.eps; fa.groups = b.groups; fa.out_stride = b.out_stride;
+  fa.zero_next = b.zero_next; fa.zero_words = b.zero_words;
+}
+
+int op_bn_finalize_acc(hipStream_t st, int c, const BnAccArgs& b) {
+  GI_REQUIRE(b.groups == 1 || b.groups == 2, "bn_finalize_acc: groups=%d", b.groups);
+  BnAccP fa;
+  fill_acc_params(fa, b);
+  hipLaunchKernelGGL(bn_finalize_acc_kernel, dim3((c + 255) / 256), dim3(256), 0, st, fa, c);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy, int act,
+                    uint8_t* drop_mask, float drop_scale, uint64_t drop_seed, float drop_p, const BnAccArgs& b) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  GI_REQUIRE(c % epc == 0 && gi_is_pow2(c / epc) && c / epc <= 256, "bn_apply_acc: c=%d", c);
+  GI_REQUIRE(b.groups == 1 || b.groups == 2, "bn_apply_acc: groups=%d", b.groups);
+  GI_REQUIRE(pixels % b.groups == 0 && b.count == pixels / b.groups, "bn_apply_acc: %lld pixels, %d populations of %lld", (long long)pixels,
+             b.groups, (long long)b.count);
+  // fewer, fatter blocks than the plain pass: every block derives the affine maps of all channels first
+  int grid = nblocks(pixels * (c / epc), 8);
+  const bool g2 = b.groups == 2;
+  BnAccP fa;
+  fill_acc_params(fa, b);
+  const size_t lds = (size_t)b.groups * 2 * c * sizeof(float);
+  const uint32_t thresh = drop_p > 0.f ? dropout_thresh(drop_p) : 0u;
+#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G, true>), dim3(grid), dim3(256), lds, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, (const float*)nullptr, (const float*)nullptr, act, drop_mask, drop_scale, (int64_t)b.count, 0, fa, drop_seed, thresh)
   if (dtype == GI_F16) { if (g2) GI_BN_APPLY(half_t, true); else GI_BN_APPLY(half_t, false); }
   else { if (g2) GI_BN_APPLY(float, true); else GI_BN_APPLY(float, false); }
 #undef GI_BN_APPLY
@@ -877,7 +1063,31 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   int blocks = 0;   // per population
   p.rows_per_block = rows_per_block_for(p.pg, &blocks);
   const int grid2 = nblocks(a.pixels * Q, 4);
-  if (a.has_bn && a.eval_bn) {
+  p.acc = nullptr; p.dgamma = a.dgamma; p.dbeta = a.dbeta; p.inv_loss_scale = a.inv_loss_scale; p.invM = 1.f / (float)p.pg;
+  p.zero_next = nullptr; p.zero_words = 0;
+  if (a.has_bn && a.acc) {
+    // exact accumulators: reduce pass (train mode only) + apply pass, no sums launch in between
+    const int grid3 = nblocks(a.pixels * Q, 8);
+    const size_t lds = (size_t)groups * 5 * a.c * sizeof(float);
+    if (!a.eval_bn) {
+      GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
+                 (long long)p.pg, p.rows_per_block);
+      p.acc = a.acc;
+      if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks * groups), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
+      GI_LAUNCH_CHECK();
+      p.zero_next = a.zero_next; p.zero_words = a.zero_words;
+    } else {
+      p.dgamma = nullptr; p.dbeta = nullptr;
+    }
+    if (groups == 2) {
+      if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 2, true>), dim3(grid3), dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 2, true>), dim3(grid3), dim3(256), lds, st, p);
+    } else {
+      if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 2, false>), dim3(grid3), dim3(256), lds, st, p);
+      else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 2, false>), dim3(grid3), dim3(256), lds, st, p);
+    }
+  } else if (a.has_bn && a.eval_bn) {
     // running-statistics BatchNorm is a per-channel affine map: the batch-mean terms vanish (sums = 0)
     hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, 0, a.c, a.sums, (float*)nullptr, (float*)nullptr, 0.f, 1,
                        a.gamma, a.save_mean, a.save_invstd, p.scale, p.shift, 0, 0.f);
@@ -952,8 +1162,7 @@ int op_tanh_bwd(hipStream_t st, const float* dy, const float* y, float* dx, int6
   return GI_OK;
 }
 int op_fill_dropout(hipStream_t st, uint8_t* mask, int64_t count, uint64_t seed, float p) {
-  const double t = (double)p * 4294967296.0;
-  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+  const uint32_t thresh = dropout_thresh(p);
   hipLaunchKernelGGL(dropout_fill_kernel, dim3(nblocks(count)), dim3(256), 0, st, mask, count, seed, thresh);
   GI_LAUNCH_CHECK();
   return GI_OK;
@@ -1082,9 +1291,13 @@ int gi_adam_step(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int6
 int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                          float eps, int step, float grad_scale, const int* guard) {
   GI_REQUIRE(step >= 1, "adam: step=%d must be >= 1", step);
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, m, v, count, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2), grad_scale, guard);
+  // torch.optim forms 1 - beta and lr / bias_correction1 from Python floats (doubles) and rounds once. The hyper-parameters
+  // arrive here as C floats (0.999f = 0.99900001...): recover the decimal the caller wrote (7 significant digits) first
+  auto py = [](float x) { char b[32]; snprintf(b, sizeof b, "%.7g", (double)x); return atof(b); };
+  const double b1 = py(beta1), b2 = py(beta2), lrd = py(lr);
+  const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, m, v, count, (float)(lrd / bc1), beta1, beta2, eps,
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)sqrt(bc2), grad_scale, guard);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
@@ -1094,7 +1307,10 @@ int gi_rmsprop_step(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t co
 }
 int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps,
                             float clamp, float grad_scale, const int* guard) {
-  hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, sq, count, lr, alpha, eps, clamp, grad_scale,
+  char b[32];
+  snprintf(b, sizeof b, "%.7g", (double)alpha);          // the Python float the caller meant (0.99), see gi_adam_step_guarded
+  const float oma = (float)(1.0 - atof(b));
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, sq, count, lr, alpha, oma, eps, clamp, grad_scale,
                      guard);
   GI_LAUNCH_CHECK();
   return GI_OK;

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "stat_acc.h"
 
 namespace {
 
@@ -26,6 +27,7 @@ struct KP {
   char* out;
   const float* bias;
   float* partials;
+  unsigned long long* stat_acc; int stat_pg;   // IgemmArgs::stat_acc
   float* ws;
   int M, Hs, Ws;
   int cin, ldin, coffin;
@@ -336,7 +338,7 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
         v = apply_act(v, p.act_out);
         stg[elem_row(mt, r) * SLD + col] = (T)v;
       }
-    if (p.partials) {
+    if (p.partials || p.stat_acc) {
       if constexpr (F16) {
         s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
         s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
@@ -348,13 +350,19 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
     }
   }
   __syncthreads();
-  if (p.partials && tid < BN) {
+  if ((p.partials || p.stat_acc) && tid < BN) {
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < WGM; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
-    const int64_t trow = (int64_t)blockIdx.x + (int64_t)gridDim.x * ph;
-    p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
-    p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+    if (p.stat_acc) {
+      unsigned long long* w = p.stat_acc + ((int64_t)((p.stat_pg > 0 && m0 >= p.stat_pg) ? p.cout : 0) + n0 + tid) * GI_STAT_WORDS;
+      gi_stat_add(w, s);
+      gi_stat_add(w + 2, q);
+    } else {
+      const int64_t trow = (int64_t)blockIdx.x + (int64_t)gridDim.x * ph;
+      p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
+      p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+    }
   }
   constexpr int CPRO = BN / EPC;          // 16-byte chunks per output row
   constexpr int RPP = 256 / CPRO;         // rows per pass
@@ -374,7 +382,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, const float* bias, char* out,
                                                             float* partials, int64_t pixels, int cout,
                                                             int ldout, int coffout, int act, int rows_per_block,
-                                                            int nsplit, int64_t ws_stride) {
+                                                            int nsplit, int64_t ws_stride, unsigned long long* stat_acc,
+                                                            int64_t stat_pg_out) {
   __shared__ float red[2 * 256 * 4];
   const int Q = cout / 4;            // column quads
   const int RL = 256 / Q;            // row lanes (cout <= 1024)
@@ -398,7 +407,7 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, con
       for (int j = 0; j < 4; ++j) dst[j] = o[j];
     }
   }
-  if (!partials) return;
+  if (!partials && !stat_acc) return;
   // reduce over row lanes
   for (int j = 0; j < 4; ++j) {
     red[(threadIdx.x) * 4 + j] = s[j];
@@ -411,8 +420,13 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, con
         s[j] += red[(i * Q + q) * 4 + j];
         sq[j] += red[1024 + (i * Q + q) * 4 + j];
       }
-    float* ps = partials + ((int64_t)blockIdx.x * 2) * cout + q * 4;
-    for (int j = 0; j < 4; ++j) { ps[j] = s[j]; ps[cout + j] = sq[j]; }
+    if (stat_acc) {   // rows of one block never straddle two BatchNorm populations (rows_per_block divides stat_pg_out)
+      unsigned long long* w = stat_acc + ((int64_t)((stat_pg_out > 0 && r0 >= stat_pg_out) ? cout : 0) + q * 4) * GI_STAT_WORDS;
+      for (int j = 0; j < 4; ++j) { gi_stat_add(w + j * GI_STAT_WORDS, s[j]); gi_stat_add(w + j * GI_STAT_WORDS + 2, sq[j]); }
+    } else {
+      float* ps = partials + ((int64_t)blockIdx.x * 2) * cout + q * 4;
+      for (int j = 0; j < 4; ++j) { ps[j] = s[j]; ps[cout + j] = sq[j]; }
+    }
   }
 }
 
@@ -443,7 +457,8 @@ int run(hipStream_t st, IgemmArgs& a) {
              "igemm: leading dims / channel offsets must be 16-byte aligned");
   KP kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out;
-  kp.bias = a.bias; kp.partials = a.partials; kp.ws = a.ws;
+  kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials; kp.ws = a.ws;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg;
   kp.M = a.n * a.Hs * a.Ws; kp.Hs = a.Hs; kp.Ws = a.Ws;
   kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
   kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
@@ -483,7 +498,9 @@ int run(hipStream_t st, IgemmArgs& a) {
     if (a.ws_bytes >= (int64_t)splitk * out_pixels * a.cout * 4) kp.ws_stride = out_pixels * a.cout;
     else GI_HIP(hipMemsetAsync(a.ws, 0, out_pixels * a.cout * 4, st));
     kp.partials = nullptr;
+    kp.stat_acc = nullptr;
   }
+  GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % 256 == 0, "igemm: stat_pg=%d must be a multiple of 256", a.stat_pg);
   dim3 grid(mt, nt, phases * splitk);
   if (wide) GI_TRY((launch_cfg<T, PHASE, 128, 128, 2, 2>(st, kp, grid)));
   else GI_TRY((launch_cfg<T, PHASE, 256, 64, 4, 1>(st, kp, grid)));
@@ -496,7 +513,8 @@ int run(hipStream_t st, IgemmArgs& a) {
     const int blocks = (int)((out_pixels + rpb - 1) / rpb);
     GI_REQUIRE(a.cout <= 1024, "igemm split-K finish: cout=%d > 1024", a.cout);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, st, a.ws, a.bias, (char*)a.out,
-                       a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb, kp.ws_stride > 0 ? splitk : 1, kp.ws_stride);
+                       a.stat_acc ? nullptr : a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb, kp.ws_stride > 0 ? splitk : 1,
+                       kp.ws_stride, a.stat_acc, (int64_t)a.stat_pg * (PHASE ? 4 : 1));
     GI_LAUNCH_CHECK();
     a.ntiles_out = blocks;
   }

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "stat_acc.h"
 
 namespace {
 
@@ -22,6 +23,7 @@ struct KP3 {
   const char* zero;   // >= 4 KiB of zeros
   const float* bias;
   float* partials;
+  unsigned long long* stat_acc; int stat_pg;   // IgemmArgs::stat_acc
   int M, Hs, Ws;
   int cin, ldin, coffin;
   int cout, ldout, coffout;
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
       }
       *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
     }
-    if (p.partials) {   // sum over the 16 pixels held by lanes with equal lq (xor 1,2,4,8)
+    if (p.partials || p.stat_acc) {   // sum over the 16 pixels held by lanes with equal lq (xor 1,2,4,8)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -332,13 +334,19 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
     }
   }
   __syncthreads();
-  if (p.partials && tid < BN) {   // (NTHREADS >= 256 >= BN)
+  if ((p.partials || p.stat_acc) && tid < BN) {   // (NTHREADS >= 256 >= BN)
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
-    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
-    p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
-    p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+    if (p.stat_acc) {
+      unsigned long long* w = p.stat_acc + ((int64_t)((p.stat_pg > 0 && m0 >= p.stat_pg) ? p.cout : 0) + n0 + tid) * GI_STAT_WORDS;
+      gi_stat_add(w, s);
+      gi_stat_add(w + 2, q);
+    } else {
+      const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
+      p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
+      p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+    }
   }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row
   const int oc = tid % CPRO;
@@ -397,7 +405,9 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   }
   KP3 kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = g_zero_page[dev & 15];
-  kp.bias = a.bias; kp.partials = a.partials;
+  kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg;
+  GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % 256 == 0, "igemm3: stat_pg=%d must be a multiple of 256", a.stat_pg);
   kp.M = M; kp.Hs = a.Hs; kp.Ws = a.Ws;
   kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
   kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;

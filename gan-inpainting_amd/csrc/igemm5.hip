@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "stat_acc.h"
 
 const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
 
@@ -35,6 +36,7 @@ struct KP5 {
   const char* zero;
   const float* bias;
   float* partials;
+  unsigned long long* stat_acc; int stat_pg;   // IgemmArgs::stat_acc
   int Hs, Ws, n;      // the small grid (MODE 1: input, MODE 0: output)
   int TH, TW;         // patch of the small grid, TH*TW = 256; TW a power of two
   int tiles_x, tiles_per_img, mtiles;
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
       }
       *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
     }
-    if (p.partials) {
+    if (p.partials || p.stat_acc) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -325,15 +327,21 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
     }
   }
   __syncthreads();
-  if (p.partials && tid < BN) {
+  if ((p.partials || p.stat_acc) && tid < BN) {
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
     const int phr = MODE == 1 ? ph : (DUAL ? py * 2 + (tid >> 6) : 0);       // sub-pixel phase of this column
     const int col = DUAL ? (tid & 63) : tid;
-    const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * phr;
-    p.partials[(trow * 2 + 0) * p.cout + n0 + col] = s;
-    p.partials[(trow * 2 + 1) * p.cout + n0 + col] = q;
+    if (p.stat_acc) {   // a patch lies inside one image, i.e. inside one BatchNorm population
+      unsigned long long* w = p.stat_acc + ((int64_t)((p.stat_pg > 0 && mt_idx * BM >= p.stat_pg) ? p.cout : 0) + n0 + col) * GI_STAT_WORDS;
+      gi_stat_add(w, s);
+      gi_stat_add(w + 2, q);
+    } else {
+      const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * phr;
+      p.partials[(trow * 2 + 0) * p.cout + n0 + col] = s;
+      p.partials[(trow * 2 + 1) * p.cout + n0 + col] = q;
+    }
   }
   constexpr int CPRO = BN / 8;
   const int oc = tid % CPRO;
@@ -395,7 +403,9 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   GI_REQUIRE(in_px * a.ldin < (1ll << 31) && out_px * a.ldout < (1ll << 31), "igemm5: tensor too large for 32-bit offsets");
   KP5 kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = zero;
-  kp.bias = a.bias; kp.partials = a.partials;
+  kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg;
+  GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % (a.Hs * a.Ws) == 0, "igemm5: stat_pg=%d must be whole images", a.stat_pg);
   kp.Hs = a.Hs; kp.Ws = a.Ws; kp.n = a.n; kp.TH = TH; kp.TW = TW;
   kp.tiles_x = tiles_x; kp.tiles_per_img = tiles_per_img; kp.mtiles = mtiles;
   kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;

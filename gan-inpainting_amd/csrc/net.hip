@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "stat_acc.h"
 
 namespace {
 
@@ -32,6 +33,12 @@ struct BN {
   int64_t stat_off = -1;  // per-slot: [scale|shift|mean|inv] * c floats (offset inside slot)
   int id = -1;            // index into gi_net::eval_gen
   int64_t inf_off = -1;   // shared workspace: [scale|shift|mean|inv] * c floats of the inference affine map
+  // exact-statistics accumulators (stat_acc.h), 64-bit words into the net's region: four blocks of [2 groups][c][4] words,
+  // two for the forward statistics and two for the backward reductions. Each use takes the block its parity bit names
+  // and its consuming pass clears the other one for the next use (ping-pong): no memset launches.
+  int64_t acc_off = -1;
+  mutable int fwd_par = 0, bwd_par = 0;
+  int64_t acc_block() const { return (int64_t)2 * c * GI_STAT_WORDS; }
 };
 
 struct Arena {
@@ -94,6 +101,12 @@ struct gi_net {
   int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
   std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
+  // train-mode BatchNorm statistics without a reduction launch: the GEMM epilogues add their tile sums into exact
+  // per-channel accumulators (stat_acc.h), the normalisation pass derives scale / shift from them itself (and the backward
+  // reductions likewise). Regions per BatchNorm layer: BN::acc_off; all zero after gi_net_bind, then kept zero by the
+  // consuming passes. GI_BN_ACC=0 restores partial rows + finalize / sums launches.
+  int64_t oAcc = -1, acc_words = 0;
+  int use_acc = 1;
   // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
   int64_t oD2 = -1, oTZ = -1, oGimg = -1, oVimg = -1, oGPs = -1, oGPpart = -1, oGPsums = -1, oTh = -1;
@@ -279,6 +292,11 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
   net->slot_base = A.take(S.size * n_slots);
+  for (int k = 1; k <= nd; ++k)
+    for (BN* b : {&net->dnorm[k], &net->unorm[k]})
+      if (b->c) { b->acc_off = net->acc_words; net->acc_words += 4 * b->acc_block(); }
+  net->oAcc = A.take(net->acc_words * 8);
+  { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
   net->slot_fused_u2.assign(n_slots, 0);
@@ -385,6 +403,9 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->eval_gen.assign(n_slots + 1, std::vector<uint64_t>(3, 0));
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
+  for (int i = 2; i <= 4; ++i) { net->dbn[i].acc_off = net->acc_words; net->acc_words += 4 * net->dbn[i].acc_block(); }
+  net->oAcc = A.take(net->acc_words * 8);
+  { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
   net->gp_slot = n_slots;                      // one private activation set for the gradient penalty
   net->slot_base = A.take(S.size * (n_slots + 1));
   net->slot_n.assign(n_slots + 1, 0);
@@ -433,6 +454,7 @@ extern "C" int gi_net_bind(gi_net* net, float* params, float* grads, float* buff
   GI_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)params & 15) == 0, "net_bind: workspace must be 256-byte aligned");
   net->params = params; net->grads = grads; net->buffers = buffers; net->ws = (char*)workspace;
   net->bound = true;
+  if (net->acc_words > 0) GI_HIP(hipMemsetAsync(net->shared(net->oAcc), 0, (size_t)net->acc_words * 8, net->ctx->stream));
   return GI_OK;
 }
 
@@ -544,12 +566,45 @@ BNPtrs bn_ptrs(const gi_net* net, int slot, const BN& b, int group = 0) {
 // statistics (the reference calls the critic separately on the real and on the fake batch: two BatchNorm
 // populations, running statistics updated group by group in that order).
 // apply = false: statistics / scale / shift only (a consumer applies the affine map itself, C1Affine)
+// Statistics plan of one BatchNorm layer, fixed BEFORE its GEMM runs: with `use` the GEMM adds its tile sums to the
+// layer's exact accumulators (IgemmArgs::stat_acc) and bn_forward needs no reduction launch.
+struct StatPlan { unsigned long long* acc = nullptr; unsigned long long* zero_next = nullptr; int zero_words = 0; int pg = 0; bool use = false; };
+StatPlan stat_plan(const gi_net* net, const BN& b, int64_t gemm_rows, int train) {
+  StatPlan sp;
+  const int g = net->kind == 1 ? net->bn_groups : 1;
+  // two populations: every tile (256 / 128 rows, or a patch of one image) must lie inside one of them
+  if (!train || !net->use_acc || b.acc_off < 0 || (g == 2 && (gemm_rows % 2 != 0 || (gemm_rows / 2) % 256 != 0))) return sp;
+  unsigned long long* base = (unsigned long long*)net->shared(net->oAcc) + b.acc_off;
+  sp.use = true;
+  sp.acc = base + b.fwd_par * b.acc_block();
+  sp.zero_next = base + (b.fwd_par ^ 1) * b.acc_block();
+  sp.zero_words = (int)b.acc_block();
+  b.fwd_par ^= 1;
+  sp.pg = g == 2 ? (int)(gemm_rows / 2) : 0;
+  return sp;
+}
+
+// drop_p > 0 with the accumulator path: the keep-mask is drawn inside the normalisation pass (seed drop_seed) and
+// stored at `drop`; otherwise `drop` (if any) is read.
 int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixels, int ntiles, void* dst, int ldy,
-               int coffy, int act, const uint8_t* drop, float drop_scale, int train, bool apply = true) {
+               int coffy, int act, const uint8_t* drop, float drop_scale, int train, bool apply = true,
+               const StatPlan* sp = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
   hipStream_t st = net->ctx->stream;
   const int g = net->kind == 1 ? net->bn_groups : 1;
   const int64_t pg = pixels / g;
   const size_t T = net->tsz();
+  if (sp && sp->use) {
+    BNPtrs p = bn_ptrs(net, slot, b, 0);
+    BnAccArgs a;
+    a.acc = sp->acc; a.gamma = net->params + b.gamma_off; a.beta = net->params + b.beta_off;
+    a.running_mean = net->buffers + b.rmean_off; a.running_var = net->buffers + b.rvar_off;
+    a.scale = p.scale; a.shift = p.shift; a.save_mean = p.mean; a.save_invstd = p.inv;
+    a.count = pg; a.momentum = 0.1f; a.eps = 1e-5f; a.groups = g; a.out_stride = 4 * b.c;
+    a.zero_next = sp->zero_next; a.zero_words = sp->zero_words;
+    if (b.id >= 0) net->eval_gen[slot][b.id] = 0;
+    if (apply) return op_bn_apply_acc(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, act, (uint8_t*)drop, drop_scale, drop_seed, drop_p, a);
+    return op_bn_finalize_acc(st, b.c, a);
+  }
   // the GEMM epilogue's partial rows can be split between the groups when a group is a whole number of tiles
   // (tile heights are 256, 128 or a power of two <= 64); otherwise each group's statistics come from a column pass
   const bool aligned = g == 1 || (pg % 256 == 0 && ntiles % g == 0);
@@ -592,9 +647,10 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
-          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr) {
+          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, const StatPlan* sp = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
+  if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; }
   a.relu_cend = relu_cend;
   a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
   a.add = add; a.ldadd = ldadd; a.coffadd = 0;
@@ -656,6 +712,15 @@ int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, cons
     a.inv_loss_scale = 1.f / net->loss_scale;
     a.partials = (float*)net->shared(net->oPart);
     a.sums = (float*)net->shared(net->oSums);
+    if (bn && net->use_acc && bn->acc_off >= 0 && (merged || g == 1)) {   // exact accumulators: no sums launch (stat_acc.h)
+      unsigned long long* base = (unsigned long long*)net->shared(net->oAcc) + bn->acc_off + 2 * bn->acc_block();
+      a.acc = base + bn->bwd_par * bn->acc_block();
+      if (!net->bwd_eval) {   // (a running-statistics backward adds nothing: the block stays clean)
+        a.zero_next = base + (bn->bwd_par ^ 1) * bn->acc_block();
+        a.zero_words = (int)bn->acc_block();
+        bn->bwd_par ^= 1;
+      }
+    }
     GI_TRY(op_act_bn_bwd(net->ctx->stream, net->dtype, a));
   }
   return GI_OK;
@@ -807,9 +872,10 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     int nt = 0;
     if (k < nd) {
       void* R = net->slot(s, net->oR[k]);
+      const StatPlan sp = stat_plan(net, net->dnorm[k], pix, train);
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), R, net->ch[k],
-                   net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt));
-      GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train));
+                   net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
+      GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train, true, &sp));
     } else {  // innermost: no down-norm; uprelu follows directly (networks.py:299-305)
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), net->slot(s, net->oE),
                    net->ch[k], net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_RELU, false, nullptr));
@@ -822,15 +888,20 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     const int co = net->ch[k - 1];
     void* U = net->slot(s, net->oU[k]);
     int nt = 0;
+    const StatPlan sp = stat_plan(net, net->unorm[k], (int64_t)n * net->Hk[k] * net->Wk[k], train);
     GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
-                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0));
+                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
     const uint8_t* drop = nullptr;
+    float drop_p = 0.f;
+    uint64_t drop_seed = 0;
     if (train && net->dropout_p > 0.f && k >= 5 && k <= nd - 1) {
       uint8_t* m = (uint8_t*)net->slot(s, net->oMask[k]);
       if (net->ext_mask[s][k]) {
         GI_TRY(op_mask_nchw_to_nhwc(st, net->ext_mask[s][k], m, n, co, net->Hk[k - 1] * net->Wk[k - 1], 1));
       } else {
-        GI_TRY(op_fill_dropout(st, m, opix * co, net->drop_seed + 0x1000003ull * (++net->drop_counter), net->dropout_p));
+        drop_seed = net->drop_seed + 0x1000003ull * (++net->drop_counter);
+        if (sp.use) drop_p = net->dropout_p;      // drawn (same hash, same masks) inside the normalisation pass
+        else GI_TRY(op_fill_dropout(st, m, opix * co, drop_seed, net->dropout_p));
       }
       drop = m;
     }
@@ -840,7 +911,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     // kernels while they read the raw tensor (C1Affine), so the upper half of C(1) is never written
     const bool fused = (k == 2) && fuse_u2;
     GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_RELU, drop,
-                      drop ? 1.f / (1.f - net->dropout_p) : 1.f, train, !fused));
+                      drop ? 1.f / (1.f - net->dropout_p) : 1.f, train, !fused, &sp, drop_p, drop_seed));
   }
   float* osave = (float*)net->slot(s, net->oOut);
   if (net->out_c == 1) {
@@ -1002,11 +1073,12 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
     const int Hs = H >> i, Ws = W >> i;
     int nt = 0;
     void* R = net->slot(s, net->oRd[i]);
+    const StatPlan sp = stat_plan(net, net->dbn[i], (int64_t)n * Hs * Ws, train);
     GI_TRY(igemm(net, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, packed_ptr(net, c), R, c.ca, c.ca, 0, n, Hs, Ws, 0, GI_ACT_NONE,
-                 true, &nt));
+                 true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
     // conv4 feeds only the head: its BatchNorm + LeakyReLU is applied by the head kernels from the raw tensor
     GI_TRY(bn_forward(net, s, net->dbn[i], R, (int64_t)n * Hs * Ws, nt, net->slot(s, net->oA[i]), c.ca, 0, GI_ACT_LRELU, nullptr, 1.f, train,
-                      !(i == 4 && fuse_a4)));
+                      !(i == 4 && fuse_a4), &sp));
   }
   HeadArgs h;
   h.a4 = net->slot(s, fuse_a4 ? net->oRd[4] : net->oA[4]);

@@ -104,6 +104,9 @@ def test_stacked_wgan_gp_critic_gradients_vs_oracle(n, overlap):
     bad = []
     for name, p in D.named_parameters():
         g32, g64 = res[torch.float32][0][name].grad, res[torch.float64][0][name].grad
+        if float(g64.abs().max()) < 1e-9:     # Linear bias: d/db (mean D(real) - mean D(fake)) = 1 - 1, the penalty does not see it
+            assert float(p.grad.abs().max()) <= 1e-6, name
+            continue
         ok, msg = close_to_either(f"stacked gp n={n} grad {name}", p.grad.detach().cpu(), g32, g64, 2e-3)
         if not ok and rel_l2(p.grad.detach().cpu(), g64) > 2e-3:
             bad.append(msg)

@@ -108,13 +108,16 @@ def test_optimizer_kernels_elementwise_vs_torch_optim():
     w, m, v = w0.clone(), torch.zeros_like(w0), torch.zeros_like(w0)
     for t, g in enumerate(gs, 1):
         B.check(lib.gi_adam_step(ctx, B.ptr(w), B.ptr(g), B.ptr(m), B.ptr(v), w.numel(), 0.0002, 0.5, 0.999, 1e-8, t, 1.0))
-    err = np.abs(w.cpu().numpy() - fx["w_adam"])
-    print("adam: max abs err", err.max(), "max rel", (err / (np.abs(fx["w_adam"]) + 1e-6)).max())
-    assert relerr(w.cpu().numpy(), fx["w_adam"]) <= 1e-6
+    def close(tag, got, ref):     # every element: the moves are ~lr per step, 1e-6 of the value or 1e-3 of one move
+        err = np.abs(got - ref)
+        print(f"{tag}: max abs err {err.max():.3e}, max err / |ref| {(err / (np.abs(ref) + 1e-30)).max():.3e}")
+        assert (err <= 1e-6 * np.abs(ref) + 5e-8).all(), tag
+
+    close("adam", w.cpu().numpy(), fx["w_adam"])
     w, sq = w0.clone(), torch.zeros_like(w0)
     for g in gs:
         B.check(lib.gi_rmsprop_step(ctx, B.ptr(w), B.ptr(g), B.ptr(sq), w.numel(), 0.00005, 0.99, 1e-8, 0.0, 1.0))
-    assert relerr(w.cpu().numpy(), fx["w_rmsprop"]) <= 1e-6
+    close("rmsprop", w.cpu().numpy(), fx["w_rmsprop"])
     # grad_scale = 1/world after a SUM all-reduce: same as feeding the mean gradient
     w2, sq2 = w0.clone(), torch.zeros_like(w0)
     for g in gs:

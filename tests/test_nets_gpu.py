@@ -44,11 +44,25 @@ def make_d(P, HW, sigmoid, dtype):
     return net.to("cuda").train()
 
 
-def compare_grads(net, OP, OP64, dtype, what):
+def spread(a32, a64):
+    """max-norm distance between the oracle's own fp32 and fp64 evaluations, relative to max|fp64|."""
+    return float((a32.double() - a64).abs().max() / (a64.abs().max() + 1e-30))
+
+
+def compare_grads(net, OP, OP64, dtype, what, chaotic=False):
+    """chaotic: configurations where the reference graph itself is ill-conditioned (one image at 512x512: every
+    BatchNorm population of the bottleneck is 4..64 values of ONE sample): two evaluations of the reference, fp32 and
+    fp64, then differ by up to 1e-2..1e-1 per gradient tensor (measured: DESIGN.md 'parity metric'), so the bound per
+    tensor is 3x that measured spread instead of a fixed 1e-3; the forward output keeps its fixed tolerance."""
     bad = []
     for name, p in net.named_parameters():
+        tol = TOL_GRAD[dtype]
+        if chaotic:
+            sp = spread(OP[name].grad, OP64[name].grad)
+            tol = max(tol, 3.0 * sp)
+            print(f"{what} grad {name}: oracle fp32 vs fp64 spread {sp:.3e} -> tol {tol:.3e}")
         ok, msg = close_to_either(f"{what} grad {name}", p.grad.detach().cpu(), OP[name].grad, OP64[name].grad,
-                                  TOL_GRAD[dtype], TOL_GRAD_L2[dtype])
+                                  tol, TOL_GRAD_L2[dtype])
         if not ok:
             bad.append(msg)
     assert not bad, "\n".join(bad)
@@ -81,8 +95,10 @@ def test_unet_forward_backward_vs_oracle(dtype, cfg):
     (yo64 * R.double()).sum().backward()
     ok, msg = report(f"unet{cfg} {dtype} out", y.detach().cpu(), yo.detach(), TOL_OUT[dtype])
     assert ok, msg
-    compare_grads(net, OP, OP64, dtype, f"unet{cfg} {dtype}")
-    ok, msg = close_to_either(f"unet{cfg} {dtype} dx", xd.grad.cpu(), xo.grad, xo64.grad, TOL_GRAD[dtype], TOL_GRAD_L2[dtype])
+    chaotic = (N == 1 and HW >= 512)
+    compare_grads(net, OP, OP64, dtype, f"unet{cfg} {dtype}", chaotic)
+    tol_dx = max(TOL_GRAD[dtype], 3.0 * spread(xo.grad, xo64.grad)) if chaotic else TOL_GRAD[dtype]
+    ok, msg = close_to_either(f"unet{cfg} {dtype} dx", xd.grad.cpu(), xo.grad, xo64.grad, tol_dx, TOL_GRAD_L2[dtype])
     assert ok, msg
     # BatchNorm running statistics (momentum 0.1, unbiased variance)
     for k, v in net.state_dict().items():
