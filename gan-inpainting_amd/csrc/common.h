@@ -107,10 +107,12 @@ struct IgemmArgs {
                                          // half of a U-Net concat gradient, which passed the parent's in-place ReLU)
   int mask_applied;
   // column statistics without partial rows (stat_acc.h): every tile adds its column sum / sum of squares into the exact
-  // per-channel accumulators stat_acc[group][cout][4] (64-bit words, zeroed by the caller). stat_pg > 0: the GEMM rows
-  // (small-grid pixels) are two consecutive BatchNorm populations of stat_pg rows each (a multiple of 256), rows >=
-  // stat_pg add to group 1. Takes precedence over `partials`.
-  unsigned long long* stat_acc; int stat_pg;
+  // per-channel accumulator block stat_acc (layout: stat_acc.h; zeroed by the caller; stat_reps replicas, a power of two,
+  // tile t adds to replica t mod stat_reps). stat_pg > 0: the GEMM rows (small-grid pixels) are two consecutive BatchNorm
+  // populations of stat_pg rows each (a multiple of 256), rows >= stat_pg add to group 1. Takes precedence over `partials`.
+  unsigned long long* stat_acc; int stat_pg; int stat_reps;
+  int stat_used;   // (returned) 1: the statistics went to stat_acc; 0: to `partials` (split-K layers: their finish pass
+                   // has few rows per block, the partial rows + finalize launch are cheaper there than 4 atomics per channel)
 };
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
 
@@ -159,7 +161,7 @@ int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64
 // mode only. acc: [groups][c][4] 64-bit words; count = pixels per population; scale / shift / save_* as above, the
 // populations' vectors out_stride floats apart.
 struct BnAccArgs {
-  const unsigned long long* acc;
+  const unsigned long long* acc; int reps;   // accumulator block (stat_acc.h) with `reps` replicas
   const float* gamma; const float* beta;
   float* running_mean; float* running_var;
   float* scale; float* shift; float* save_mean; float* save_invstd;
@@ -202,9 +204,9 @@ struct ActBnBwdArgs {
                                       // sign(act input) = sign(fma(x, scale, shift)) replaces the read of y
   int groups;                         // 2: the tensor is two consecutive BatchNorm populations (save_mean / save_invstd of
   int stat_stride;                    //    the second at +stat_stride floats), reduced separately in the same launches
-  // non-null (has_bn): exact accumulators [groups][c][4] (stat_acc.h, zeroed): the reduce pass adds into them and the apply
-  // pass derives its coefficients itself - two launches instead of three; the apply pass then clears zero_next.
-  unsigned long long* acc; unsigned long long* zero_next; int zero_words;
+  // non-null (has_bn): exact accumulator block (stat_acc.h, zeroed, acc_reps replicas): the reduce pass adds into it and the
+  // apply pass derives its coefficients itself - two launches instead of three; the apply pass then clears zero_next.
+  unsigned long long* acc; int acc_reps; unsigned long long* zero_next; int zero_words;
 };
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a);
 int op_bwd_rows_per_block(int64_t pixels);   // rows one reduce workgroup covers (groups = 2 needs pixels/2 to be a multiple)

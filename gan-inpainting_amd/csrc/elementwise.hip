@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials,
 // Called by one thread per channel; `write` (one block per launch) also stores the vectors the backward needs and
 // moves the running statistics, population by population in the order separate calls would.
 struct BnAccP {
-  const unsigned long long* acc;   // [groups][c][GI_STAT_WORDS]
+  const unsigned long long* acc;   // accumulator block (stat_acc.h)
+  int reps;
   const float* gamma; const float* beta;
   float* rmean; float* rvar;
   float* scale; float* shift; float* smean; float* sinv;   // [groups] x out_stride floats apart
@@ -123,9 +124,8 @@ __device__ __forceinline__ void zero_words64(unsigned long long* p, int n) {
   for (int i = threadIdx.x; i < n; i += 256) p[i] = 0ull;
 }
 __device__ __forceinline__ void bn_from_acc(const BnAccP& a, int c, int ch, int j, bool write, float& sc_out, float& sh_out) {
-  const unsigned long long* w = a.acc + ((int64_t)j * c + ch) * GI_STAT_WORDS;
-  const double m = gi_stat_read(w) / a.count;
-  double v = gi_stat_read(w + 2) / a.count - m * m;
+  const double m = gi_stat_read(a.acc, c, a.reps, j, 0, ch) / a.count;
+  double v = gi_stat_read(a.acc, c, a.reps, j, 1, ch) / a.count - m * m;
   if (v < 0.0) v = 0.0;
   const float mean = (float)m, var = (float)v;
   const float inv = 1.0f / sqrtf(var + a.eps);
@@ -204,10 +204,18 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
       for (int e = 0; e < EPC; ++e) { sc1[e] = scale[gstride + cc * EPC + e]; sh1[e] = shift[gstride + cc * EPC + e]; }
     }
   }
-  for (int64_t gid = gid0; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int64_t pix = gid >> lg;
+  // one 16-byte chunk: affine map + activation (+ dropout) + store
+  auto finish = [&](int64_t pix, u4_t raw) {
     float v[EPC];
-    load_vec<T, EPC>(x, pix * c + cc * EPC, v);
+    if constexpr (std::is_same<T, half_t>::value) {
+      const h8_t h = __builtin_bit_cast(h8_t, raw);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = (float)h[e];
+    } else {
+      const f4_t f = __builtin_bit_cast(f4_t, raw);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = f[e];
+    }
     const bool second = G2 && pix >= pg;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
@@ -236,7 +244,20 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
       }
     }
     store_vec<T, EPC>(y, pix * ldy + coffy + cc * EPC, v);
+  };
+  // four independent 16-byte loads in flight per thread before any arithmetic (the pass is HBM-bound: 64 B per lane
+  // outstanding instead of 16)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t esz = (int64_t)sizeof(T);
+  int64_t gid = gid0;
+  for (; gid + 3 * stride < total; gid += 4 * stride) {
+    u4_t r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = *(const u4_t*)(x + (((gid + u * stride) >> lg) * c + cc * EPC) * esz);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) finish((gid + u * stride) >> lg, r[u]);
   }
+  for (; gid < total; gid += stride) finish(gid >> lg, *(const u4_t*)(x + ((gid >> lg) * c + cc * EPC) * esz));
 }
 
 // column sum / sumsq of a dense (pixels,c) tensor -> partials [blocks][2][c]
@@ -288,7 +309,7 @@ struct BwdP {
   // exact-accumulator form (stat_acc.h): the reduce pass adds {sum dz, sum dz*xhat} into acc[group][c][4] and the apply
   // pass derives its coefficients from them itself (no sums launch). acc null in the apply pass = running-statistics
   // BatchNorm (both sums zero). Block 0 of the apply pass accumulates dgamma / dbeta and clears zero_next.
-  unsigned long long* acc;
+  unsigned long long* acc; int acc_reps;
   float* dgamma; float* dbeta; float inv_loss_scale; float invM;
   unsigned long long* zero_next; int zero_words;
 };
@@ -363,19 +384,21 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { red[threadIdx.x * EPC + e] = s[e]; red[256 * EPC + threadIdx.x * EPC + e] = sx[e]; }
   __syncthreads();
-  if (rl == 0) {
+  if (p.acc) {   // one lane per channel: the lanes of an atomic instruction are consecutive words (stat_acc.h)
+    const int grp = r0 >= p.pg ? 1 : 0, rep = blockIdx.x & (p.acc_reps - 1);
+    for (int ch = threadIdx.x; ch < p.c; ch += 256) {
+      float a = 0.f, b = 0.f;
+      for (int i = 0; i < RL; ++i) { a += red[i * Q * EPC + ch]; b += red[256 * EPC + i * Q * EPC + ch]; }
+      gi_stat_add(p.acc, p.c, rep, grp, 0, ch, a);
+      gi_stat_add(p.acc, p.c, rep, grp, 1, ch, b);
+    }
+  } else if (rl == 0) {
     for (int i = 1; i < RL; ++i)
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { s[e] += red[(i * Q + q) * EPC + e]; sx[e] += red[256 * EPC + (i * Q + q) * EPC + e]; }
-    if (p.acc) {
-      unsigned long long* w = p.acc + ((int64_t)(r0 >= p.pg ? p.c : 0) + q * EPC) * GI_STAT_WORDS;
+    float* ps = p.partials + ((int64_t)blockIdx.x * 2) * p.c + q * EPC;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { gi_stat_add(w + e * GI_STAT_WORDS, s[e]); gi_stat_add(w + e * GI_STAT_WORDS + 2, sx[e]); }
-    } else {
-      float* ps = p.partials + ((int64_t)blockIdx.x * 2) * p.c + q * EPC;
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) { ps[e] = s[e]; ps[p.c + e] = sx[e]; }
-    }
+    for (int e = 0; e < EPC; ++e) { ps[e] = s[e]; ps[p.c + e] = sx[e]; }
   }
 }
 
@@ -440,9 +463,8 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
       for (int g = 0; g < NG; ++g) {
         float s1 = 0.f, s2 = 0.f;
         if (p.acc) {
-          const unsigned long long* w = p.acc + ((int64_t)g * c + ch) * GI_STAT_WORDS;
-          s1 = (float)gi_stat_read(w);
-          s2 = (float)gi_stat_read(w + 2);
+          s1 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 0, ch);
+          s2 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 1, ch);
         }
         const int so = g * p.stat_stride + ch;
         const float iv = p.inv[so];
@@ -979,7 +1001,7 @@ int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixel
 }
 
 static void fill_acc_params(BnAccP& fa, const BnAccArgs& b) {
-  fa.acc = b.acc; fa.gamma = b.gamma; fa.beta = b.beta; fa.rmean = b.running_mean; fa.rvar = b.running_var;
+  fa.acc = b.acc; fa.reps = b.reps > 0 ? b.reps : 1; fa.gamma = b.gamma; fa.beta = b.beta; fa.rmean = b.running_mean; fa.rvar = b.running_var;
   fa.scale = b.scale; fa.shift = b.shift; fa.smean = b.save_mean; fa.sinv = b.save_invstd;
   fa.count = (double)b.count; fa.momentum = b.momentum; fa.eps = b.eps; fa.groups = b.groups; fa.out_stride = b.out_stride;
   fa.zero_next = b.zero_next; fa.zero_words = b.zero_words;
@@ -1063,7 +1085,7 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   int blocks = 0;   // per population
   p.rows_per_block = rows_per_block_for(p.pg, &blocks);
   const int grid2 = nblocks(a.pixels * Q, 4);
-  p.acc = nullptr; p.dgamma = a.dgamma; p.dbeta = a.dbeta; p.inv_loss_scale = a.inv_loss_scale; p.invM = 1.f / (float)p.pg;
+  p.acc = nullptr; p.acc_reps = a.acc_reps > 0 ? a.acc_reps : 1; p.dgamma = a.dgamma; p.dbeta = a.dbeta; p.inv_loss_scale = a.inv_loss_scale; p.invM = 1.f / (float)p.pg;
   p.zero_next = nullptr; p.zero_words = 0;
   if (a.has_bn && a.acc) {
     // exact accumulators: reduce pass (train mode only) + apply pass, no sums launch in between

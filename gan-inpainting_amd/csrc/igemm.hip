@@ -27,7 +27,7 @@ struct KP {
   char* out;
   const float* bias;
   float* partials;
-  unsigned long long* stat_acc; int stat_pg;   // IgemmArgs::stat_acc
+  unsigned long long* stat_acc; int stat_pg, stat_reps;   // IgemmArgs::stat_acc
   float* ws;
   int M, Hs, Ws;
   int cin, ldin, coffin;
@@ -355,9 +355,9 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
 #pragma unroll
     for (int i = 0; i < WGM; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
     if (p.stat_acc) {
-      unsigned long long* w = p.stat_acc + ((int64_t)((p.stat_pg > 0 && m0 >= p.stat_pg) ? p.cout : 0) + n0 + tid) * GI_STAT_WORDS;
-      gi_stat_add(w, s);
-      gi_stat_add(w + 2, q);
+      const int grp = (p.stat_pg > 0 && m0 >= p.stat_pg) ? 1 : 0, rep = (blockIdx.x + ph) & (p.stat_reps - 1);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 0, n0 + tid, s);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 1, n0 + tid, q);
     } else {
       const int64_t trow = (int64_t)blockIdx.x + (int64_t)gridDim.x * ph;
       p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, con
                                                             float* partials, int64_t pixels, int cout,
                                                             int ldout, int coffout, int act, int rows_per_block,
                                                             int nsplit, int64_t ws_stride, unsigned long long* stat_acc,
-                                                            int64_t stat_pg_out) {
+                                                            int64_t stat_pg_out, int stat_reps) {
   __shared__ float red[2 * 256 * 4];
   const int Q = cout / 4;            // column quads
   const int RL = 256 / Q;            // row lanes (cout <= 1024)
@@ -414,19 +414,23 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const float* ws, con
     red[1024 + threadIdx.x * 4 + j] = sq[j];
   }
   __syncthreads();
-  if (rl == 0) {
+  if (stat_acc) {   // one lane per channel: the lanes of an atomic instruction are consecutive words (stat_acc.h)
+    // rows of one block never straddle two BatchNorm populations (rows_per_block divides stat_pg_out)
+    const int grp = (stat_pg_out > 0 && r0 >= stat_pg_out) ? 1 : 0, rep = blockIdx.x & (stat_reps - 1);
+    for (int ch = threadIdx.x; ch < cout; ch += 256) {
+      float a = 0.f, b2 = 0.f;
+      for (int i = 0; i < RL; ++i) { a += red[i * Q * 4 + ch]; b2 += red[1024 + i * Q * 4 + ch]; }
+      gi_stat_add(stat_acc, cout, rep, grp, 0, ch, a);
+      gi_stat_add(stat_acc, cout, rep, grp, 1, ch, b2);
+    }
+  } else if (rl == 0) {
     for (int i = 1; i < RL; ++i)
       for (int j = 0; j < 4; ++j) {
         s[j] += red[(i * Q + q) * 4 + j];
         sq[j] += red[1024 + (i * Q + q) * 4 + j];
       }
-    if (stat_acc) {   // rows of one block never straddle two BatchNorm populations (rows_per_block divides stat_pg_out)
-      unsigned long long* w = stat_acc + ((int64_t)((stat_pg_out > 0 && r0 >= stat_pg_out) ? cout : 0) + q * 4) * GI_STAT_WORDS;
-      for (int j = 0; j < 4; ++j) { gi_stat_add(w + j * GI_STAT_WORDS, s[j]); gi_stat_add(w + j * GI_STAT_WORDS + 2, sq[j]); }
-    } else {
-      float* ps = partials + ((int64_t)blockIdx.x * 2) * cout + q * 4;
-      for (int j = 0; j < 4; ++j) { ps[j] = s[j]; ps[cout + j] = sq[j]; }
-    }
+    float* ps = partials + ((int64_t)blockIdx.x * 2) * cout + q * 4;
+    for (int j = 0; j < 4; ++j) { ps[j] = s[j]; ps[cout + j] = sq[j]; }
   }
 }
 
@@ -458,7 +462,8 @@ int run(hipStream_t st, IgemmArgs& a) {
   KP kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out;
   kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials; kp.ws = a.ws;
-  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg; kp.stat_reps = a.stat_reps > 0 ? a.stat_reps : 1;
+  a.stat_used = a.stat_acc ? 1 : 0;
   kp.M = a.n * a.Hs * a.Ws; kp.Hs = a.Hs; kp.Ws = a.Ws;
   kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
   kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
@@ -513,8 +518,9 @@ int run(hipStream_t st, IgemmArgs& a) {
     const int blocks = (int)((out_pixels + rpb - 1) / rpb);
     GI_REQUIRE(a.cout <= 1024, "igemm split-K finish: cout=%d > 1024", a.cout);
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, st, a.ws, a.bias, (char*)a.out,
-                       a.stat_acc ? nullptr : a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb, kp.ws_stride > 0 ? splitk : 1,
-                       kp.ws_stride, a.stat_acc, (int64_t)a.stat_pg * (PHASE ? 4 : 1));
+                       a.partials, out_pixels, a.cout, a.ldout, a.coffout, a.act_out, rpb, kp.ws_stride > 0 ? splitk : 1,
+                       kp.ws_stride, a.partials ? nullptr : a.stat_acc, (int64_t)a.stat_pg * (PHASE ? 4 : 1), kp.stat_reps);
+    a.stat_used = (a.stat_acc && !a.partials) ? 1 : 0;
     GI_LAUNCH_CHECK();
     a.ntiles_out = blocks;
   }

@@ -23,7 +23,7 @@ struct KP3 {
   const char* zero;   // >= 4 KiB of zeros
   const float* bias;
   float* partials;
-  unsigned long long* stat_acc; int stat_pg;   // IgemmArgs::stat_acc
+  unsigned long long* stat_acc; int stat_pg, stat_reps;   // IgemmArgs::stat_acc
   int M, Hs, Ws;
   int cin, ldin, coffin;
   int cout, ldout, coffout;
@@ -339,9 +339,9 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
     if (p.stat_acc) {
-      unsigned long long* w = p.stat_acc + ((int64_t)((p.stat_pg > 0 && m0 >= p.stat_pg) ? p.cout : 0) + n0 + tid) * GI_STAT_WORDS;
-      gi_stat_add(w, s);
-      gi_stat_add(w + 2, q);
+      const int grp = (p.stat_pg > 0 && m0 >= p.stat_pg) ? 1 : 0, rep = (mt_idx + ph) & (p.stat_reps - 1);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 0, n0 + tid, s);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 1, n0 + tid, q);
     } else {
       const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
       p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
@@ -406,7 +406,8 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   KP3 kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = g_zero_page[dev & 15];
   kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials;
-  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg; kp.stat_reps = a.stat_reps > 0 ? a.stat_reps : 1;
+  a.stat_used = a.stat_acc ? 1 : 0;
   GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % 256 == 0, "igemm3: stat_pg=%d must be a multiple of 256", a.stat_pg);
   kp.M = M; kp.Hs = a.Hs; kp.Ws = a.Ws;
   kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;

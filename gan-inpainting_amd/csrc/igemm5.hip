@@ -36,7 +36,7 @@ struct KP5 {
   const char* zero;
   const float* bias;
   float* partials;
-  unsigned long long* stat_acc; int stat_pg;   // IgemmArgs::stat_acc
+  unsigned long long* stat_acc; int stat_pg, stat_reps;   // IgemmArgs::stat_acc
   int Hs, Ws, n;      // the small grid (MODE 1: input, MODE 0: output)
   int TH, TW;         // patch of the small grid, TH*TW = 256; TW a power of two
   int tiles_x, tiles_per_img, mtiles;
@@ -71,7 +71,104 @@ __device__ __forceinline__ void wait_vm(int n) {   // n is wave-uniform
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
     case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+  }
+}
+
+// ---- epilogue shared by igemm5 / igemm6 (contract of igemm3): bias / activation, per-tile column statistics, the tile
+//      staged through LDS and stored with 16-byte rows; optional fused activation backward (IgemmArgs::mask) -------------
+template <int MODE, int BN>
+__device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32], char* smem, int tid, int lane, int wm, int wn,
+                                          int mt_idx, int nt_idx, int ph, int py, int px, int n0, int img, int y0, int x0, int lgTW) {
+  constexpr bool DUAL = MODE == 3;
+  constexpr bool PH = MODE == 1 || MODE == 3;
+  constexpr int BM = 256, WN = BN / 2, MT = 4, NT = WN / 16;
+  const int lr = lane & 15, lq = lane >> 4;
+  auto out_pixel = [&](int m) -> int {
+    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+    if constexpr (PH) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;   // DUAL: + 1 for px 1, by the caller
+    else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;   // MODE 0 / 2: the tile's own pixels
+  };
+  constexpr int SLD = BN + 8;
+  half_t* stg = (half_t*)smem;
+  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = wn * WN + nt * 16 + 4 * lq;           // column of the tile (DUAL: px * 64 + channel)
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][nt][r] + bs[r];
+        s[r] += v;
+        q[r] += v * v;
+        o[r] = (half_t)act5(v, p.act_out);
+      }
+      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
+    }
+    if (p.partials || p.stat_acc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+      }
+    }
+  }
+  __syncthreads();
+  if ((p.partials || p.stat_acc) && tid < BN) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
+    const int phr = MODE == 1 ? ph : (DUAL ? py * 2 + (tid >> 6) : 0);       // sub-pixel phase of this column
+    const int col = DUAL ? (tid & 63) : tid;
+    if (p.stat_acc) {   // a patch lies inside one image, i.e. inside one BatchNorm population
+      const int grp = (p.stat_pg > 0 && mt_idx * BM >= p.stat_pg) ? 1 : 0, rep = (mt_idx + phr) & (p.stat_reps - 1);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 0, n0 + col, s);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 1, n0 + col, q);
+    } else {
+      const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * phr;
+      p.partials[(trow * 2 + 0) * p.cout + n0 + col] = s;
+      p.partials[(trow * 2 + 1) * p.cout + n0 + col] = q;
+    }
+  }
+  constexpr int CPRO = BN / 8;
+  const int oc = tid % CPRO;
+#pragma unroll 1
+  for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
+    const int64_t opx = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
+    const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
+    const int64_t o = opx * p.ldout + p.coffout + och;
+    u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+    if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
+      const h8_t m = *(const h8_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
+      h8_t hv = __builtin_bit_cast(h8_t, v);
+      if (p.add) {
+        const h8_t a8 = *(const h8_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool pos = (float)m[e] > 0.f;
+          const float g = (float)hv[e] + (pos ? (float)a8[e] : 0.f);
+          hv[e] = (half_t)(pos ? g : g * p.mask_slope);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hv[e] = (float)m[e] > 0.f ? hv[e] : (half_t)((float)hv[e] * p.mask_slope);
+      }
+      v = __builtin_bit_cast(u4_t, hv);
+    }
+    *(u4_t*)(p.out + o * 2) = v;
   }
 }
 
@@ -284,92 +381,262 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---- epilogue (contract of igemm3) --------------------------------------------------------------------------
-  auto out_pixel = [&](int m) -> int {
-    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
-    if constexpr (PH) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;   // DUAL: + 1 for px 1, by the caller
-    else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;   // MODE 0 / 2: the tile's own pixels
-  };
-  constexpr int SLD = BN + 8;
-  half_t* stg = (half_t*)smem;
-  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
+  asm volatile("" ::: "memory");
+  epilogue5<MODE, BN>(p, acc, smem, tid, lane, wm, wn, mt_idx, nt_idx, ph, py, px, n0, img, y0, x0, lgTW);
+}
+
+
+// =====================================================================================================================
+// igemm6: the 4-tap modes (0, 1, 3) of igemm5 with the issue stream put on a diet. The counters of igemm5
+// show 3.1 vector instructions per MFMA - address arithmetic of the LDS-DMA pieces and of the fragment reads, the
+// k-half XOR, the ring-stage select - on a 16-cycle MFMA that leaves the SIMD 8 issue cycles (two vector
+// instructions), and every step opened with all 8 waves waiting for their first fragment reads behind the barrier.
+//   * LDS-DMA by `buffer_load_dwordx4 ... lds`: the per-lane part of a piece's source (row, swizzled chunk) is ONE 32-bit
+//     offset register for the whole K loop, the moving part (channel chunk, tap) is the scalar offset; padding rows use an
+//     out-of-range offset, for which the buffer unit writes zeros (no zero page, no select). No vector instruction per piece.
+//   * the weight ring has FOUR stages, so the stage of a step IS its tap (compile-time); the group loop is unrolled over
+//     the halo buffer parity (and over the four parity classes in mode 0): every fragment read is `ds_read_b128 v, vaddr
+//     offset:imm` with vaddr one of 2 x 16 + 2 loop-invariant registers.
+//   * the first k-half of step s+1's fragments is read DURING step s (the pieces of a step land one step earlier: weight
+//     slices are issued three steps ahead, the next halo during taps 0 and 1), so after the barrier the MFMAs start at once.
+template <int MODE, int BN>
+__global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
+  static_assert(MODE == 0 || MODE == 1 || MODE == 3, "4-tap modes");
+  constexpr bool DUAL = MODE == 3;
+  constexpr bool PH = MODE == 1 || MODE == 3;
+  constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups (parity classes) per channel chunk
+  constexpr int NTAP = 4;
+  constexpr int PADX = DUAL ? 2 : 1;
+  static_assert(!DUAL || BN == 128, "dual-px mode: 2 x 64 columns");
+  constexpr int BM = 256, BK = 64, NW = 8;
+  constexpr int AJ = 5;                                 // halo pieces (8 rows x 128 B) per wave and group
+  constexpr int A_BYTES = AJ * 64 * 128;                // 40 KiB per buffer
+  constexpr int B_BYTES = BN * 128;
+  constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;         // + 4 ring stages
+  constexpr int BJ = (BN / 8) / NW;                     // weight-slice pieces per wave and step
+  constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
+  constexpr unsigned OOB = 0x80000000u;                 // beyond any tensor (sizes are checked < 2^31 bytes): reads as zeros
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_t;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware tile order (as igemm5)
+  const int nyz = p.ntiles * (DUAL ? 2 : (PH ? 4 : 1));
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int mt_idx = (local / nyz) * 8 + xcd;
+  if (mt_idx >= p.mtiles) return;
+  const int yz = local % nyz;
+  const int nt_idx = yz % p.ntiles;
+  const int ph = yz / p.ntiles;
+  const int py = DUAL ? ph : (ph >> 1), px = DUAL ? 0 : (ph & 1);
+  const int n0 = nt_idx * (DUAL ? 64 : BN);
+  const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
+  const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
+  const int HC = p.TW + PADX, HR = p.TH + 1;
+  const int Ktot2 = (PH ? 4 : 16) * p.cin * 2;          // bytes per weight row
+  const int64_t phase_bytes = (int64_t)p.cout * Ktot2;
+  const int Win = 2 * p.Ws, Hin = 2 * p.Hs;             // mode 0: the large (input) grid
+
+  // ---- buffer descriptors: the input tensor, and the weight rows this workgroup reads
+  const int64_t in_bytes = (int64_t)p.n * (MODE == 0 ? 4 : 1) * p.Hs * p.Ws * p.ldin * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)in_bytes, 0x00020000);
+  const char* wbase = p.w + (MODE == 1 ? ph * phase_bytes : (DUAL ? (py * 2) * phase_bytes : 0));
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)(DUAL ? 2 * phase_bytes : (MODE == 1 ? phase_bytes : phase_bytes)), 0x00020000);
+
+  // ---- per-lane piece offsets (loop invariant) ---------------------------------------------------------------------
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ (lrow & 7);
+  unsigned voffA[NQ][AJ];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = wn * WN + nt * 16 + 4 * lq;           // column of the tile (DUAL: px * 64 + channel)
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      h4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[mt][nt][r] + bs[r];
-        s[r] += v;
-        q[r] += v * v;
-        o[r] = (half_t)act5(v, p.act_out);
-      }
-      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
-    }
-    if (p.partials || p.stat_acc) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
-      }
-      if (lr == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
-      }
-    }
-  }
-  __syncthreads();
-  if ((p.partials || p.stat_acc) && tid < BN) {
-    float s = 0.f, q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
-    const int phr = MODE == 1 ? ph : (DUAL ? py * 2 + (tid >> 6) : 0);       // sub-pixel phase of this column
-    const int col = DUAL ? (tid & 63) : tid;
-    if (p.stat_acc) {   // a patch lies inside one image, i.e. inside one BatchNorm population
-      unsigned long long* w = p.stat_acc + ((int64_t)((p.stat_pg > 0 && mt_idx * BM >= p.stat_pg) ? p.cout : 0) + n0 + col) * GI_STAT_WORDS;
-      gi_stat_add(w, s);
-      gi_stat_add(w + 2, q);
+  for (int j = 0; j < AJ; ++j) {
+    const int r = (wave * AJ + j) * 8 + lrow;
+    const int hr = r / HC, hc = r - hr * HC;
+    if constexpr (MODE != 0) {
+      const int iy = y0 + py - 1 + hr, ix = x0 + (MODE == 1 ? px : 0) - 1 + hc;   // DUAL: columns x0-1 .. x0+TW
+      const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+      voffA[0][j] = ok ? (unsigned)((((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16) : OOB;
     } else {
-      const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * phr;
-      p.partials[(trow * 2 + 0) * p.cout + n0 + col] = s;
-      p.partials[(trow * 2 + 1) * p.cout + n0 + col] = q;
-    }
-  }
-  constexpr int CPRO = BN / 8;
-  const int oc = tid % CPRO;
-#pragma unroll 1
-  for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
-    const int64_t opx = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
-    const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
-    const int64_t o = opx * p.ldout + p.coffout + och;
-    u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
-    if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
-      const h8_t m = *(const h8_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
-      h8_t hv = __builtin_bit_cast(h8_t, v);
-      if (p.add) {
-        const h8_t a8 = *(const h8_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
+      // halo (hr,hc) of parity class (qy,qx) is input pixel (2*(y0+hr) - qy, 2*(x0+hc) - qx)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const bool pos = (float)m[e] > 0.f;
-          const float g = (float)hv[e] + (pos ? (float)a8[e] : 0.f);
-          hv[e] = (half_t)(pos ? g : g * p.mask_slope);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) hv[e] = (float)m[e] > 0.f ? hv[e] : (half_t)((float)hv[e] * p.mask_slope);
+      for (int q = 0; q < 4; ++q) {
+        const int iy = 2 * (y0 + hr) - (q >> 1), ix = 2 * (x0 + hc) - (q & 1);
+        const bool ok = hr < HR && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        voffA[q][j] = ok ? (unsigned)((((img * Hin + iy) * Win + ix) * p.ldin + p.coffin) * 2 + lchunk * 16) : OOB;
       }
-      v = __builtin_bit_cast(u4_t, hv);
     }
-    *(u4_t*)(p.out + o * 2) = v;
   }
+  unsigned voffB[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int rb = (wave * BJ + j) * 8 + lrow;                     // row of the B tile
+    if constexpr (DUAL) voffB[j] = (unsigned)((rb >> 6) * phase_bytes + (int64_t)(n0 + (rb & 63)) * Ktot2 + lchunk * 16);   // rows 64.. = px 1
+    else voffB[j] = (unsigned)((int64_t)(n0 + rb) * Ktot2 + lchunk * 16);
+  }
+
+  // halo piece j of the group (chunk, class Q) into A buffer BUF; weight piece j of (chunk, class Q, tap) into stage = tap
+  auto issue_a = [&](int chunk, auto Q, auto BUF, auto J) {
+    constexpr int q = decltype(Q)::value, buf = decltype(BUF)::value, j = decltype(J)::value;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_t)(smem + A_OFF + buf * A_BYTES + (wave * AJ + j) * 1024), 16, voffA[q][j], chunk * (BK * 2), 0, 0);
+  };
+  auto issue_b = [&](int chunk, auto Q, auto TAP, auto J) {
+    constexpr int q = decltype(Q)::value, tap = decltype(TAP)::value, j = decltype(J)::value;
+    int koff;
+    if constexpr (MODE != 0) {
+      koff = tap * p.cin + chunk * BK;
+    } else {
+      constexpr int ky = (q >> 1) ? 2 * (tap >> 1) : 2 * (tap >> 1) + 1, kx = (q & 1) ? 2 * (tap & 1) : 2 * (tap & 1) + 1;
+      koff = (ky * 4 + kx) * p.cin + chunk * BK;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_t)(smem + B_OFF + tap * B_BYTES + (wave * BJ + j) * 1024), 16, voffB[j], koff * 2, 0, 0);
+  };
+
+  // ---- fragment read offsets (loop invariant): [k-half][pixel tile][tap] inside an A buffer, [k-half] inside a stage -----
+  const int lr = lane & 15, lq = lane >> 4;
+  const int lgTW = 31 - __builtin_clz(p.TW);
+  int rdA[2][MT][NTAP];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = wm * 64 + mt * 16 + lr;
+    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int R = MODE == 1 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1))
+                  : MODE == 3 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + wn + 1 - (tap & 1))
+                              : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
+      rdA[0][mt][tap] = A_OFF + R * 128 + ((lq ^ (R & 7)) << 4);
+      rdA[1][mt][tap] = rdA[0][mt][tap] ^ 64;          // logical chunk 4 + lq: bit 2 of the physical chunk flipped
+    }
+  }
+  int rdB[2];
+  rdB[0] = B_OFF + (wn * WN + lr) * 128 + ((lq ^ (lr & 7)) << 4);
+  rdB[1] = rdB[0] ^ 64;
+
+  f4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int ngroups = p.nchunk * NQ, nsteps = ngroups * NTAP;
+  const int relu_cend = p.relu_in ? p.relu_cend : 0;
+
+  struct Frag { h8_t a[MT], b[NT]; };
+  // k-half KH of the step (halo buffer BUF, tap TAP); `relu`: the chunk lies in the skip half of a concat buffer
+  auto read_frag = [&](auto BUF, auto TAP, auto KH, bool relu, Frag& f) {
+    constexpr int buf = decltype(BUF)::value, tap = decltype(TAP)::value, kh = decltype(KH)::value;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) f.a[mt] = *(const h8_t*)(smem + rdA[kh][mt][tap] + buf * A_BYTES);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) f.b[nt] = *(const h8_t*)(smem + rdB[kh] + tap * B_BYTES + nt * 2048);
+    if (relu) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) f.a[mt] = relu5(f.a[mt]);
+    }
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  // ---- prologue: halo of group 0, weight slices of steps 0, 1, 2 ------------------------------------------------------
+  static_for<AJ>([&](auto J) { issue_a(0, I0{}, I0{}, J); });
+  static_for<BJ>([&](auto J) { issue_b(0, I0{}, I0{}, J); });
+  if (nsteps > 1) static_for<BJ>([&](auto J) { issue_b(0, I0{}, I1{}, J); });
+  if (nsteps > 2) static_for<BJ>([&](auto J) { issue_b(0, I0{}, std::integral_constant<int, 2>{}, J); });
+  wait_vm(nsteps > 2 ? BJ : 0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  Frag f0;
+  read_frag(I0{}, I0{}, I0{}, 0 < relu_cend, f0);
+
+  // one halo group = four steps. GI = group index modulo 2 (modes 1, 3) or 4 (mode 0): halo buffer GI & 1, parity class GI.
+  auto group = [&](int c, auto GIc) {
+    constexpr int GI = decltype(GIc)::value;
+    constexpr int BUF = GI & 1, Q = MODE == 0 ? GI : 0, QN = MODE == 0 ? ((GI + 1) & 3) : 0;
+    using QT = std::integral_constant<int, Q>;
+    using QNT = std::integral_constant<int, QN>;
+    const int chunk = c / NQ, chunk_n = (c + 1) / NQ;            // channel chunk of this group / of the next one
+    const bool relu = chunk * BK < relu_cend, relu_n = chunk_n * BK < relu_cend;
+    const bool next_a = c + 1 < ngroups;
+    static_for<NTAP>([&](auto TAPc) {
+      constexpr int tap = decltype(TAPc)::value;
+      const int s = c * NTAP + tap;
+      if (s > 0) {
+        // may stay in flight: the issues of step s-1 = its weight slice (step s+2) and its halo pieces (3 in tap 0, 2 in tap 1)
+        constexpr int ptap = (tap + 3) & 3;
+        const int pc = tap == 0 ? c - 1 : c;
+        const int nwait = ((s + 2 < nsteps) ? BJ : 0) + ((pc + 1 < ngroups) ? (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0)) : 0);
+        wait_vm(nwait);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      Frag f1;
+      read_frag(std::integral_constant<int, BUF>{}, TAPc, I1{}, relu, f1);
+      const bool more_b = s + 3 < nsteps;
+      // the step whose weight slice is issued now: s + 3 = (group c, tap + 3) or (group c + 1, tap - 1)
+      auto issue_piece = [&](auto IDX) {
+        constexpr int idx = decltype(IDX)::value;      // MFMA counter of this step, 0 .. 2 * MT * NT - 1
+        if (next_a) {
+          // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
+          constexpr int NM = 2 * MT * NT;                // MFMAs per step and wave (32 or 16)
+          if constexpr (tap == 0) {
+            if constexpr (idx == 1) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, I0{});
+            if constexpr (idx == 1 + NM / 4) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, I1{});
+            if constexpr (idx == 1 + NM / 2) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 2>{});
+          } else if constexpr (tap == 1) {
+            if constexpr (idx == 1) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 3>{});
+            if constexpr (idx == 1 + NM / 3) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 4>{});
+          }
+        }
+        if (more_b) {
+          static_for<BJ>([&](auto Jc) {
+            constexpr int j = decltype(Jc)::value;
+            constexpr int NM = 2 * MT * NT;
+            if constexpr (idx == NM - 2 - (BJ - 1 - j) * (NM / 6)) {
+              if constexpr (tap == 0) issue_b(chunk, QT{}, std::integral_constant<int, 3>{}, Jc);
+              else issue_b(chunk_n, QNT{}, std::integral_constant<int, tap - 1>{}, Jc);
+            }
+          });
+        }
+      };
+      // first k-half: fragments are already in registers; this step's LDS-DMA pieces go between the MFMAs
+      static_for<MT * NT>([&](auto IDX) {
+        constexpr int mt = decltype(IDX)::value / NT, nt = decltype(IDX)::value % NT;
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0.b[nt], f0.a[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+        issue_piece(IDX);
+      });
+      // first k-half of the NEXT step (its data landed one step early)
+      if (s + 1 < nsteps) {
+        if constexpr (tap < 3) read_frag(std::integral_constant<int, BUF>{}, std::integral_constant<int, tap + 1>{}, I0{}, relu, f0);
+        else read_frag(std::integral_constant<int, BUF ^ 1>{}, I0{}, I0{}, relu_n, f0);
+      }
+      static_for<MT * NT>([&](auto IDX) {
+        constexpr int mt = decltype(IDX)::value / NT, nt = decltype(IDX)::value % NT;
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1.b[nt], f1.a[mt], acc[mt][nt], 0, 0, 0);
+        issue_piece(std::integral_constant<int, decltype(IDX)::value + MT * NT>{});
+      });
+    });
+  };
+
+  for (int c = 0; c < ngroups; ++c) {
+    if constexpr (MODE == 0) {
+      switch (c & 3) {
+        case 0: group(c, I0{}); break;
+        case 1: group(c, I1{}); break;
+        case 2: group(c, std::integral_constant<int, 2>{}); break;
+        default: group(c, std::integral_constant<int, 3>{}); break;
+      }
+    } else {
+      if (c & 1) group(c, I1{}); else group(c, I0{});
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  epilogue5<MODE, BN>(p, acc, smem, tid, lane, wm, wn, mt_idx, nt_idx, ph, py, px, n0, img, y0, x0, lgTW);
 }
 
 }  // namespace
@@ -404,7 +671,8 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   KP5 kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = zero;
   kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials;
-  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg; kp.stat_reps = a.stat_reps > 0 ? a.stat_reps : 1;
+  a.stat_used = a.stat_acc ? 1 : 0;
   GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % (a.Hs * a.Ws) == 0, "igemm5: stat_pg=%d must be whole images", a.stat_pg);
   kp.Hs = a.Hs; kp.Ws = a.Ws; kp.n = a.n; kp.TH = TH; kp.TW = TW;
   kp.tiles_x = tiles_x; kp.tiles_per_img = tiles_per_img; kp.mtiles = mtiles;
@@ -429,6 +697,27 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   static bool attr[6] = {false, false, false, false, false, false};
   const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
                        (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
+  static int use6 = -1;   // GI_IGEMM6=0: the first-generation halo kernels (tools: A/B)
+  if (use6 < 0) { const char* e = getenv("GI_IGEMM6"); use6 = e ? atoi(e) : 0; }
+  if (use6 && mode != 2 && in_px * a.ldin * 2 < (1ll << 31) && (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31)) {
+    const int LDS6 = 2 * 320 * 128 + 4 * BNk * 128;
+    static bool attr6[5] = {false, false, false, false, false};
+    const void* fn6[5] = {(const void*)igemm6_kernel<0, 128>, (const void*)igemm6_kernel<1, 128>, (const void*)igemm6_kernel<0, 64>,
+                          (const void*)igemm6_kernel<1, 64>, (const void*)igemm6_kernel<3, 128>};
+    const int v6 = dual ? 4 : (BN == 64 ? 2 : 0) + mode;
+    if (!attr6[v6]) { GI_HIP(hipFuncSetAttribute(fn6[v6], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr6[v6] = true; }
+    const int lds = LDS6 > epi ? LDS6 : epi;
+    switch (v6) {
+      case 0: hipLaunchKernelGGL((igemm6_kernel<0, 128>), dim3(grid), dim3(512), lds, st, kp); break;
+      case 1: hipLaunchKernelGGL((igemm6_kernel<1, 128>), dim3(grid), dim3(512), lds, st, kp); break;
+      case 2: hipLaunchKernelGGL((igemm6_kernel<0, 64>), dim3(grid), dim3(512), lds, st, kp); break;
+      case 3: hipLaunchKernelGGL((igemm6_kernel<1, 64>), dim3(grid), dim3(512), lds, st, kp); break;
+      default: hipLaunchKernelGGL((igemm6_kernel<3, 128>), dim3(grid), dim3(512), lds, st, kp); break;
+    }
+    GI_LAUNCH_CHECK();
+    a.ntiles_out = mtiles * nph;
+    return GI_OK;
+  }
   if (dual) {
     static bool attr_dual = false;
     if (!attr_dual) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<3, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_dual = true; }

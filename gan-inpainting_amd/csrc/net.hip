@@ -38,7 +38,8 @@ struct BN {
   // and its consuming pass clears the other one for the next use (ping-pong): no memset launches.
   int64_t acc_off = -1;
   mutable int fwd_par = 0, bwd_par = 0;
-  int64_t acc_block() const { return (int64_t)2 * c * GI_STAT_WORDS; }
+  mutable int dirty[4] = {0, 0, 0, 0};   // replicas a use has added to in block {fwd 0, fwd 1, bwd 0, bwd 1}, not yet cleared
+  int64_t acc_block() const { return gi_stat_block_words(c, GI_STAT_MAXREP); }
 };
 
 struct Arena {
@@ -568,18 +569,26 @@ BNPtrs bn_ptrs(const gi_net* net, int slot, const BN& b, int group = 0) {
 // apply = false: statistics / scale / shift only (a consumer applies the affine map itself, C1Affine)
 // Statistics plan of one BatchNorm layer, fixed BEFORE its GEMM runs: with `use` the GEMM adds its tile sums to the
 // layer's exact accumulators (IgemmArgs::stat_acc) and bn_forward needs no reduction launch.
-struct StatPlan { unsigned long long* acc = nullptr; unsigned long long* zero_next = nullptr; int zero_words = 0; int pg = 0; bool use = false; };
-StatPlan stat_plan(const gi_net* net, const BN& b, int64_t gemm_rows, int train) {
+struct StatPlan { unsigned long long* acc = nullptr; unsigned long long* zero_next = nullptr; int zero_words = 0; int pg = 0; int reps = 1; bool use = false; };
+// (`use` is cleared by the igemm wrapper when the kernel that ran put its statistics into partial rows instead)
+// replicas for `adders` tiles adding to one block: about 256 requests per 64-byte line (~3 us of queueing at the atomic unit)
+int stat_reps_for(int64_t adders) {
+  int r = 1;
+  while (r < GI_STAT_MAXREP && adders > 256 * r) r <<= 1;
+  return r;
+}
+// tile_rows: an upper bound on the partial rows the GEMM's tiles would write (tiles along M x sub-pixel phases)
+StatPlan stat_plan(const gi_net* net, const BN& b, int64_t gemm_rows, int64_t tile_rows, int train) {
   StatPlan sp;
   const int g = net->kind == 1 ? net->bn_groups : 1;
   // two populations: every tile (256 / 128 rows, or a patch of one image) must lie inside one of them
   if (!train || !net->use_acc || b.acc_off < 0 || (g == 2 && (gemm_rows % 2 != 0 || (gemm_rows / 2) % 256 != 0))) return sp;
   unsigned long long* base = (unsigned long long*)net->shared(net->oAcc) + b.acc_off;
   sp.use = true;
+  sp.reps = stat_reps_for(tile_rows);
   sp.acc = base + b.fwd_par * b.acc_block();
   sp.zero_next = base + (b.fwd_par ^ 1) * b.acc_block();
-  sp.zero_words = (int)b.acc_block();
-  b.fwd_par ^= 1;
+  sp.zero_words = (int)gi_stat_block_words(b.c, b.dirty[b.fwd_par ^ 1]);   // (the state moves when the plan is consumed: bn_forward)
   sp.pg = g == 2 ? (int)(gemm_rows / 2) : 0;
   return sp;
 }
@@ -600,7 +609,11 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
     a.running_mean = net->buffers + b.rmean_off; a.running_var = net->buffers + b.rvar_off;
     a.scale = p.scale; a.shift = p.shift; a.save_mean = p.mean; a.save_invstd = p.inv;
     a.count = pg; a.momentum = 0.1f; a.eps = 1e-5f; a.groups = g; a.out_stride = 4 * b.c;
-    a.zero_next = sp->zero_next; a.zero_words = sp->zero_words;
+    a.zero_next = sp->zero_words > 0 ? sp->zero_next : nullptr; a.zero_words = sp->zero_words;
+    a.reps = sp->reps;
+    b.dirty[b.fwd_par ^ 1] = 0;
+    b.dirty[b.fwd_par] = sp->reps;
+    b.fwd_par ^= 1;
     if (b.id >= 0) net->eval_gen[slot][b.id] = 0;
     if (apply) return op_bn_apply_acc(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, act, (uint8_t*)drop, drop_scale, drop_seed, drop_p, a);
     return op_bn_finalize_acc(st, b.c, a);
@@ -647,10 +660,10 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
-          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, const StatPlan* sp = nullptr) {
+          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
-  if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; }
+  if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; a.stat_reps = sp->reps; }
   a.relu_cend = relu_cend;
   a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
   a.add = add; a.ldadd = ldadd; a.coffadd = 0;
@@ -664,6 +677,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   a.relu_in = relu_in; a.act_out = act_out;
   GI_TRY(op_igemm(net->ctx->stream, net->dtype, phase, a));
   if (mask_applied) *mask_applied = a.mask_applied;
+  if (sp && sp->use && !a.stat_used) sp->use = false;
   if (ntiles) *ntiles = a.ntiles_out;
   if (stats) GI_REQUIRE((int64_t)a.ntiles_out * 2 * cout <= net->part_floats, "internal: partials buffer too small");
   return GI_OK;
@@ -716,8 +730,12 @@ int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, cons
       unsigned long long* base = (unsigned long long*)net->shared(net->oAcc) + bn->acc_off + 2 * bn->acc_block();
       a.acc = base + bn->bwd_par * bn->acc_block();
       if (!net->bwd_eval) {   // (a running-statistics backward adds nothing: the block stays clean)
-        a.zero_next = base + (bn->bwd_par ^ 1) * bn->acc_block();
-        a.zero_words = (int)bn->acc_block();
+        a.acc_reps = stat_reps_for((pg + op_bwd_rows_per_block(pg / a.groups) - 1) / op_bwd_rows_per_block(pg / a.groups));
+        const int other = 2 + (bn->bwd_par ^ 1);
+        a.zero_words = (int)gi_stat_block_words(bn->c, bn->dirty[other]);
+        a.zero_next = a.zero_words > 0 ? base + (bn->bwd_par ^ 1) * bn->acc_block() : nullptr;
+        bn->dirty[other] = 0;
+        bn->dirty[2 + bn->bwd_par] = a.acc_reps;
         bn->bwd_par ^= 1;
       }
     }
@@ -872,7 +890,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     int nt = 0;
     if (k < nd) {
       void* R = net->slot(s, net->oR[k]);
-      const StatPlan sp = stat_plan(net, net->dnorm[k], pix, train);
+      StatPlan sp = stat_plan(net, net->dnorm[k], pix, (pix + 127) / 128, train);
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), R, net->ch[k],
                    net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
       GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train, true, &sp));
@@ -888,9 +906,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     const int co = net->ch[k - 1];
     void* U = net->slot(s, net->oU[k]);
     int nt = 0;
-    const StatPlan sp = stat_plan(net, net->unorm[k], (int64_t)n * net->Hk[k] * net->Wk[k], train);
-    GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
-                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
+    StatPlan sp = stat_plan(net, net->unorm[k], (int64_t)n * net->Hk[k] * net->Wk[k], ((int64_t)n * net->Hk[k] * net->Wk[k] + 127) / 128 * 4, train);
     const uint8_t* drop = nullptr;
     float drop_p = 0.f;
     uint64_t drop_seed = 0;
@@ -900,16 +916,20 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
         GI_TRY(op_mask_nchw_to_nhwc(st, net->ext_mask[s][k], m, n, co, net->Hk[k - 1] * net->Wk[k - 1], 1));
       } else {
         drop_seed = net->drop_seed + 0x1000003ull * (++net->drop_counter);
-        if (sp.use) drop_p = net->dropout_p;      // drawn (same hash, same masks) inside the normalisation pass
-        else GI_TRY(op_fill_dropout(st, m, opix * co, drop_seed, net->dropout_p));
       }
       drop = m;
+    }
+    const bool fused = (k == 2) && fuse_u2;
+    GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
+                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
+    if (drop && !net->ext_mask[s][k]) {
+      if (sp.use) drop_p = net->dropout_p;      // drawn (same hash, same masks) inside the normalisation pass
+      else GI_TRY(op_fill_dropout(st, (uint8_t*)drop, opix * co, drop_seed, net->dropout_p));
     }
     // the decoder half is only ever consumed through the parent's in-place ReLU (networks.py:289): store
     // relu(u) so that consumers need the ReLU on the skip half only; [u > 0] masks are unchanged
     // the last decoder level feeds only the single-channel head: its BatchNorm + ReLU is applied by the head's
     // kernels while they read the raw tensor (C1Affine), so the upper half of C(1) is never written
-    const bool fused = (k == 2) && fuse_u2;
     GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_RELU, drop,
                       drop ? 1.f / (1.f - net->dropout_p) : 1.f, train, !fused, &sp, drop_p, drop_seed));
   }
@@ -1073,7 +1093,7 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
     const int Hs = H >> i, Ws = W >> i;
     int nt = 0;
     void* R = net->slot(s, net->oRd[i]);
-    const StatPlan sp = stat_plan(net, net->dbn[i], (int64_t)n * Hs * Ws, train);
+    StatPlan sp = stat_plan(net, net->dbn[i], (int64_t)n * Hs * Ws, ((int64_t)n * Hs * Ws + 127) / 128, train);
     GI_TRY(igemm(net, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, packed_ptr(net, c), R, c.ca, c.ca, 0, n, Hs, Ws, 0, GI_ACT_NONE,
                  true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
     // conv4 feeds only the head: its BatchNorm + LeakyReLU is applied by the head kernels from the raw tensor

@@ -7,27 +7,53 @@
 // below 2^-40 are cut), kept as hi * 2^32 + lo with lo in [0, 2^32); the halves go to two words. Integer addition
 // commutes and never rounds, so the totals do not depend on the order the tiles finish in: results are
 // bit-reproducible, unlike fp32 atomics. Consumers convert back to double once.
-//   words per quantity: {hi, lo}; bit 63 of lo = "a non-finite or absurd value was added" -> the total reads NaN
+//   bit 63 of lo = "a non-finite or absurd value was added" -> the total reads NaN
 //   range: |value| < 2^43 per addend, up to 2^19 addends
+//
+// Layout of one accumulator block (structure of arrays): word[replica][group][w][c], w = {sum hi, sum lo, sumsq hi,
+// sumsq lo} (or any two quantities), group = BatchNorm population (0 / 1). The 64 lanes of one atomic wave
+// instruction are 64 consecutive channels of one w, i.e. 512 contiguous bytes = eight 64-byte requests at the
+// memory-side atomic unit; with the words of a channel interleaved instead every request would carry two lanes, and
+// requests to one line are served one after the other (~12 ns each: a layer of 2048 tiles queued for 100 us).
+// Replicas (tile index mod R) bound the requests per line to a few hundred; the consumer adds the replicas up.
 #pragma once
 #include <hip/hip_runtime.h>
 
-constexpr int GI_STAT_WORDS = 4;   // per channel: {sum hi, sum lo, sumsq hi, sumsq lo} (or any two quantities)
+constexpr int GI_STAT_WORDS = 4;     // 64-bit words per channel, population and replica
+constexpr int GI_STAT_MAXREP = 4;
 
-__device__ __forceinline__ void gi_stat_add(unsigned long long* w2, float s) {
+// words of one block with `reps` replicas
+__host__ __device__ __forceinline__ long long gi_stat_block_words(int c, int reps) { return (long long)reps * 2 * GI_STAT_WORDS * c; }
+// address of word w of channel 0 (replica, group); channels are consecutive
+__device__ __forceinline__ unsigned long long* gi_stat_ptr(unsigned long long* base, int c, int rep, int group, int w) {
+  return base + ((long long)(rep * 2 + group) * GI_STAT_WORDS + w) * c;
+}
+
+// quantity q (0 / 1) of channel ch
+__device__ __forceinline__ void gi_stat_add(unsigned long long* base, int c, int rep, int group, int q, int ch, float s) {
+  unsigned long long* hi = gi_stat_ptr(base, c, rep, group, 2 * q) + ch;
+  unsigned long long* lo = hi + c;
   if (!(fabsf(s) < 8.0e12f)) {     // inf, NaN, or beyond the fixed-point range
-    atomicOr(w2 + 1, 0x8000000000000000ull);
+    atomicOr(lo, 0x8000000000000000ull);
     return;
   }
   const double d = (double)s * 1099511627776.0;               // * 2^40, exact
   const double h = floor(d * 2.3283064365386963e-10);         // / 2^32
   const double l = d - h * 4294967296.0;                      // in [0, 2^32), exact
-  atomicAdd(w2, (unsigned long long)(long long)h);            // two's complement: negative h wraps correctly
-  atomicAdd(w2 + 1, (unsigned long long)l);
+  atomicAdd(hi, (unsigned long long)(long long)h);            // two's complement: negative h wraps correctly
+  atomicAdd(lo, (unsigned long long)l);
 }
 
-__device__ __forceinline__ double gi_stat_read(const unsigned long long* w2) {
-  const unsigned long long hi = w2[0], lo = w2[1];
-  if (lo >> 63) return __builtin_nan("");
+// total of quantity q of channel ch over `reps` replicas
+__device__ __forceinline__ double gi_stat_read(const unsigned long long* base, int c, int reps, int group, int q, int ch) {
+  unsigned long long hi = 0, lo = 0, bad = 0;
+  for (int r = 0; r < reps; ++r) {
+    const unsigned long long* p = base + ((long long)(r * 2 + group) * GI_STAT_WORDS + 2 * q) * c + ch;
+    const unsigned long long l = p[c];
+    hi += p[0];
+    lo += l & 0x7FFFFFFFFFFFFFFFull;
+    bad |= l >> 63;
+  }
+  if (bad) return __builtin_nan("");
   return ((double)(long long)hi * 4294967296.0 + (double)lo) * 9.094947017729282e-13;   // * 2^-40
 }

@@ -55,14 +55,21 @@ def compare_grads(net, OP, OP64, dtype, what, chaotic=False):
     fp64, then differ by up to 1e-2..1e-1 per gradient tensor (measured: DESIGN.md 'parity metric'), so the bound per
     tensor is 3x that measured spread instead of a fixed 1e-3; the forward output keeps its fixed tolerance."""
     bad = []
+    tol = TOL_GRAD[dtype]
+    if chaotic:
+        # isolated kink flips land in different tensors from evaluation to evaluation: one bound for all tensors from the
+        # largest spread (max-norm), and a per-tensor relative-L2 bound from that tensor's own L2 spread
+        worst = max(spread(OP[n].grad, OP64[n].grad) for n, _ in net.named_parameters())
+        tol = max(tol, 3.0 * worst)
+        print(f"{what}: largest oracle fp32-vs-fp64 gradient spread {worst:.3e} -> max-norm tol {tol:.3e}")
     for name, p in net.named_parameters():
-        tol = TOL_GRAD[dtype]
-        if chaotic:
-            sp = spread(OP[name].grad, OP64[name].grad)
-            tol = max(tol, 3.0 * sp)
-            print(f"{what} grad {name}: oracle fp32 vs fp64 spread {sp:.3e} -> tol {tol:.3e}")
-        ok, msg = close_to_either(f"{what} grad {name}", p.grad.detach().cpu(), OP[name].grad, OP64[name].grad,
-                                  tol, TOL_GRAD_L2[dtype])
+        g = p.grad.detach().cpu()
+        ok, msg = close_to_either(f"{what} grad {name}", g, OP[name].grad, OP64[name].grad, tol, TOL_GRAD_L2[dtype])
+        if ok and chaotic and TOL_GRAD_L2[dtype] is None:
+            l2, l2o = rel_l2(g, OP64[name].grad), rel_l2(OP[name].grad, OP64[name].grad)
+            ok = l2 <= max(2e-3, 5.0 * l2o)
+            msg = f"{what} grad {name}: relL2 vs fp64 oracle {l2:.3e}, the fp32 oracle's own {l2o:.3e}"
+            print(msg)
         if not ok:
             bad.append(msg)
     assert not bad, "\n".join(bad)
