@@ -1,6 +1,8 @@
 // C-ABI glue: error reporting, context, single-layer entry points (see include/ganinpaint.h).
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 static thread_local char g_err[1024] = "";
@@ -116,11 +118,13 @@ int gi_time_convT_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_phase
   hipEvent_t e0, e1;
   GI_HIP(hipEventCreate(&e0));
   GI_HIP(hipEventCreate(&e1));
+  const char* er = getenv("GI_TIME_RELU");     // tools: 0 times the variant without the fused input ReLU (input-gradient use)
+  const int relu = er ? atoi(er) : 1;
   // warm-up
-  GI_TRY(gi_convT_s2_forward(ctx, dtype, in, w_phase, out, n, H, W, ca, ldin, cb, ldout, 1, GI_ACT_NONE, nullptr, 0));
+  GI_TRY(gi_convT_s2_forward(ctx, dtype, in, w_phase, out, n, H, W, ca, ldin, cb, ldout, relu, GI_ACT_NONE, nullptr, 0));
   GI_HIP(hipEventRecord(e0, ctx->stream));
   for (int i = 0; i < iters; ++i)
-    GI_TRY(gi_convT_s2_forward(ctx, dtype, in, w_phase, out, n, H, W, ca, ldin, cb, ldout, 1, GI_ACT_NONE, nullptr, 0));
+    GI_TRY(gi_convT_s2_forward(ctx, dtype, in, w_phase, out, n, H, W, ca, ldin, cb, ldout, relu, GI_ACT_NONE, nullptr, 0));
   GI_HIP(hipEventRecord(e1, ctx->stream));
   GI_HIP(hipEventSynchronize(e1));
   float ms = 0.f;

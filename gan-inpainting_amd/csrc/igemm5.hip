@@ -65,6 +65,11 @@ __device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// one LDS-DMA piece through a buffer descriptor: lane l writes 16 bytes at lds_wave_base + 16 l, read from
+// base + voff (per lane) + soff (wave-uniform); out-of-range offsets write zeros
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
 __device__ __forceinline__ void wait_vm(int n) {   // n is wave-uniform
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -399,7 +404,9 @@ __global__ void __launch_bounds__(512, 2) igemm5_kernel(KP5 p) {
 //     offset:imm` with vaddr one of 2 x 16 + 2 loop-invariant registers.
 //   * the first k-half of step s+1's fragments is read DURING step s (the pieces of a step land one step earlier: weight
 //     slices are issued three steps ahead, the next halo during taps 0 and 1), so after the barrier the MFMAs start at once.
-template <int MODE, int BN>
+// DBG (builds with -DGI_ABLATION only, wrong results): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no fragment reads, 8 halo pieces
+// all from one 4 KiB window (L2-resident), 16 no per-step barrier
+template <int MODE, int BN, bool RELU, int DBG = 0>
 __global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
   static_assert(MODE == 0 || MODE == 1 || MODE == 3, "4-tap modes");
   constexpr bool DUAL = MODE == 3;
@@ -417,7 +424,6 @@ __global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
   constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
   constexpr unsigned OOB = 0x80000000u;                 // beyond any tensor (sizes are checked < 2^31 bytes): reads as zeros
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef __attribute__((address_space(3))) void* lds_t;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,6 +465,7 @@ __global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
       const int iy = y0 + py - 1 + hr, ix = x0 + (MODE == 1 ? px : 0) - 1 + hc;   // DUAL: columns x0-1 .. x0+TW
       const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
       voffA[0][j] = ok ? (unsigned)((((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + lchunk * 16) : OOB;
+      if constexpr ((DBG & 8) != 0) voffA[0][j] &= 0xFF0u;
     } else {
       // halo (hr,hc) of parity class (qy,qx) is input pixel (2*(y0+hr) - qy, 2*(x0+hc) - qx)
 #pragma unroll
@@ -477,27 +484,10 @@ __global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
     else voffB[j] = (unsigned)((int64_t)(n0 + rb) * Ktot2 + lchunk * 16);
   }
 
-  // halo piece j of the group (chunk, class Q) into A buffer BUF; weight piece j of (chunk, class Q, tap) into stage = tap
-  auto issue_a = [&](int chunk, auto Q, auto BUF, auto J) {
-    constexpr int q = decltype(Q)::value, buf = decltype(BUF)::value, j = decltype(J)::value;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_t)(smem + A_OFF + buf * A_BYTES + (wave * AJ + j) * 1024), 16, voffA[q][j], chunk * (BK * 2), 0, 0);
-  };
-  auto issue_b = [&](int chunk, auto Q, auto TAP, auto J) {
-    constexpr int q = decltype(Q)::value, tap = decltype(TAP)::value, j = decltype(J)::value;
-    int koff;
-    if constexpr (MODE != 0) {
-      koff = tap * p.cin + chunk * BK;
-    } else {
-      constexpr int ky = (q >> 1) ? 2 * (tap >> 1) : 2 * (tap >> 1) + 1, kx = (q & 1) ? 2 * (tap & 1) : 2 * (tap & 1) + 1;
-      koff = (ky * 4 + kx) * p.cin + chunk * BK;
-    }
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_t)(smem + B_OFF + tap * B_BYTES + (wave * BJ + j) * 1024), 16, voffB[j], koff * 2, 0, 0);
-  };
-
   // ---- fragment read offsets (loop invariant): [k-half][pixel tile][tap] inside an A buffer, [k-half] inside a stage -----
   const int lr = lane & 15, lq = lane >> 4;
   const int lgTW = 31 - __builtin_clz(p.TW);
-  int rdA[2][MT][NTAP];
+  int rdA[MT][NTAP];   // k-half 0; k-half 1 (logical chunk 4 + lq) = bit 2 of the physical chunk flipped = offset ^ 64
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = wm * 64 + mt * 16 + lr;
@@ -507,8 +497,7 @@ __global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
       const int R = MODE == 1 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1))
                   : MODE == 3 ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + wn + 1 - (tap & 1))
                               : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
-      rdA[0][mt][tap] = A_OFF + R * 128 + ((lq ^ (R & 7)) << 4);
-      rdA[1][mt][tap] = rdA[0][mt][tap] ^ 64;          // logical chunk 4 + lq: bit 2 of the physical chunk flipped
+      rdA[mt][tap] = A_OFF + R * 128 + ((lq ^ (R & 7)) << 4);
     }
   }
   int rdB[2];
@@ -521,117 +510,158 @@ __global__ void __launch_bounds__(512, 2) igemm6_kernel(KP5 p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int ngroups = p.nchunk * NQ, nsteps = ngroups * NTAP;
+  const int ngroups = (DBG & 32) ? 2 : p.nchunk * NQ, nsteps = ngroups * NTAP;   // DBG 32: two groups only (fixed costs)
   const int relu_cend = p.relu_in ? p.relu_cend : 0;
 
   struct Frag { h8_t a[MT], b[NT]; };
-  // k-half KH of the step (halo buffer BUF, tap TAP); `relu`: the chunk lies in the skip half of a concat buffer
-  auto read_frag = [&](auto BUF, auto TAP, auto KH, bool relu, Frag& f) {
-    constexpr int buf = decltype(BUF)::value, tap = decltype(TAP)::value, kh = decltype(KH)::value;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) f.a[mt] = *(const h8_t*)(smem + rdA[kh][mt][tap] + buf * A_BYTES);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) f.b[nt] = *(const h8_t*)(smem + rdB[kh] + tap * B_BYTES + nt * 2048);
-    if (relu) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) f.a[mt] = relu5(f.a[mt]);
+  // One fragment read of k-half KH of the step (halo buffer BUF, tap TAP): I < MT = pixel tile I of A, else column tile
+  // I - MT of B. The reads of a k-half are spread over the MFMAs of the previous k-half, one every RSTEP MFMAs (a burst
+  // of eight b128 reads per wave, from eight waves at once, fills the LDS queue and blocks the MFMA issue behind it; two
+  // waves per SIMD reading one fragment per MFMA each already saturate the LDS array), in the order the next k-half
+  // needs them: a0, all of b, a1, a2, ...
+  constexpr int RSTEP = (MT * NT) / (MT + NT) >= 2 ? 2 : 1;
+  auto rorder = [](int k) constexpr -> int { return k == 0 ? 0 : (k <= NT ? MT + k - 1 : k - NT); };
+  auto read_one = [&](auto BUF, auto TAP, auto KH, auto Ic, Frag& f) {
+    constexpr int buf = decltype(BUF)::value, tap = decltype(TAP)::value, kh = decltype(KH)::value, i = decltype(Ic)::value;
+    if constexpr ((DBG & 4) != 0) {
+      if constexpr (i < MT) { f.a[i] = h8_t{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(f.a[i])); }
+      else { f.b[i - MT] = h8_t{1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(f.b[i - MT])); }
+    } else {
+      if constexpr (i < MT) f.a[i] = *(const h8_t*)(smem + (rdA[i][tap] ^ (kh << 6)) + buf * A_BYTES);
+      else f.b[i - MT] = *(const h8_t*)(smem + rdB[kh] + tap * B_BYTES + (i - MT) * 2048);
     }
   };
+  // RELU kernels: the decoder's ReLU on an A fragment right before its first use. rmin = 0 for the skip half of a concat
+  // buffer, 0x8000 (the smallest 16-bit integer: no change) for the rest - no branch either way
+  auto relu_a = [&](h8_t& v, int rmin) {
+    if constexpr (RELU) {
+      typedef short s8_t __attribute__((ext_vector_type(8)));
+      const short m = (short)rmin;
+      const s8_t lo = {m, m, m, m, m, m, m, m};
+      v = __builtin_bit_cast(h8_t, __builtin_elementwise_max(__builtin_bit_cast(s8_t, v), lo));
+    }
+  };
+  auto rmin_of = [&](int chunk) -> int { return chunk * BK < relu_cend ? 0 : -32768; };
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
 
-  // ---- prologue: halo of group 0, weight slices of steps 0, 1, 2 ------------------------------------------------------
-  static_for<AJ>([&](auto J) { issue_a(0, I0{}, I0{}, J); });
-  static_for<BJ>([&](auto J) { issue_b(0, I0{}, I0{}, J); });
-  if (nsteps > 1) static_for<BJ>([&](auto J) { issue_b(0, I0{}, I1{}, J); });
-  if (nsteps > 2) static_for<BJ>([&](auto J) { issue_b(0, I0{}, std::integral_constant<int, 2>{}, J); });
-  wait_vm(nsteps > 2 ? BJ : 0);
+  // ---- prologue: halo of group 0, weight slices of steps 0, 1, 2 (nsteps >= 4) ------------------------------------------
+  static_for<AJ>([&](auto J) { blds16(rsA, voffA[0][decltype(J)::value], 0, smem + A_OFF + (wave * AJ + decltype(J)::value) * 1024); });
+  auto issue_b = [&](unsigned (&vb)[BJ], int chunk, auto Q, auto TAP, auto J) {
+    constexpr int q = decltype(Q)::value, tap = decltype(TAP)::value, j = decltype(J)::value;
+    int koff;
+    if constexpr (MODE != 0) {
+      koff = tap * p.cin + chunk * BK;
+    } else {
+      constexpr int ky = (q >> 1) ? 2 * (tap >> 1) : 2 * (tap >> 1) + 1, kx = (q & 1) ? 2 * (tap & 1) : 2 * (tap & 1) + 1;
+      koff = (ky * 4 + kx) * p.cin + chunk * BK;
+    }
+    blds16(rsB, vb[j], koff * 2, smem + B_OFF + tap * B_BYTES + (wave * BJ + j) * 1024);
+  };
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I0{}, J); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I1{}, J); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I2{}, J); });
+  Frag f0;
+  wait_vm(BJ);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  Frag f0;
-  read_frag(I0{}, I0{}, I0{}, 0 < relu_cend, f0);
+  static_for<MT + NT>([&](auto Ic) { read_one(I0{}, I0{}, I0{}, Ic, f0); });
 
-  // one halo group = four steps. GI = group index modulo 2 (modes 1, 3) or 4 (mode 0): halo buffer GI & 1, parity class GI.
+  // One halo group = four steps, straight-line code: every step issues the same number of LDS-DMA pieces (beyond the end
+  // of the K loop with out-of-range offsets: zeros into stages nobody reads any more), so the counted waits are immediates
+  // and there is no branch between the MFMAs. GI = group index modulo 2 (modes 1, 3) or 4 (mode 0): halo buffer GI & 1,
+  // parity class GI (mode 0).
   auto group = [&](int c, auto GIc) {
     constexpr int GI = decltype(GIc)::value;
     constexpr int BUF = GI & 1, Q = MODE == 0 ? GI : 0, QN = MODE == 0 ? ((GI + 1) & 3) : 0;
+    using BUFT = std::integral_constant<int, BUF>;
+    using BUFN = std::integral_constant<int, BUF ^ 1>;
     using QT = std::integral_constant<int, Q>;
     using QNT = std::integral_constant<int, QN>;
     const int chunk = c / NQ, chunk_n = (c + 1) / NQ;            // channel chunk of this group / of the next one
-    const bool relu = chunk * BK < relu_cend, relu_n = chunk_n * BK < relu_cend;
+    const int rmin = rmin_of(chunk), rmin_n = rmin_of(chunk_n);
     const bool next_a = c + 1 < ngroups;
+    unsigned va[AJ];                                            // the next group's halo pieces (none after the last group)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) va[j] = next_a ? voffA[QN][j] : OOB;
     static_for<NTAP>([&](auto TAPc) {
       constexpr int tap = decltype(TAPc)::value;
       const int s = c * NTAP + tap;
-      if (s > 0) {
-        // may stay in flight: the issues of step s-1 = its weight slice (step s+2) and its halo pieces (3 in tap 0, 2 in tap 1)
-        constexpr int ptap = (tap + 3) & 3;
-        const int pc = tap == 0 ? c - 1 : c;
-        const int nwait = ((s + 2 < nsteps) ? BJ : 0) + ((pc + 1 < ngroups) ? (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0)) : 0);
-        wait_vm(nwait);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
+      // in flight may stay: the pieces issued during step s-1 = a weight slice (BJ) + its halo pieces (3 in tap 0, 2 in tap 1)
+      constexpr int ptap = (tap + 3) & 3;
+      constexpr int nwait = BJ + (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0));
+      if constexpr (nwait == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if constexpr (nwait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if constexpr (nwait == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if constexpr (nwait == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
       Frag f1;
-      read_frag(std::integral_constant<int, BUF>{}, TAPc, I1{}, relu, f1);
-      const bool more_b = s + 3 < nsteps;
-      // the step whose weight slice is issued now: s + 3 = (group c, tap + 3) or (group c + 1, tap - 1)
+      // weight slice of step s + 3 = (group c, tap 3) during tap 0, else (group c + 1, tap - 1); out of range past the end
+      unsigned vb[BJ];
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) vb[j] = s + 3 < nsteps ? voffB[j] : OOB;
       auto issue_piece = [&](auto IDX) {
-        constexpr int idx = decltype(IDX)::value;      // MFMA counter of this step, 0 .. 2 * MT * NT - 1
-        if (next_a) {
-          // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
-          constexpr int NM = 2 * MT * NT;                // MFMAs per step and wave (32 or 16)
-          if constexpr (tap == 0) {
-            if constexpr (idx == 1) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, I0{});
-            if constexpr (idx == 1 + NM / 4) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, I1{});
-            if constexpr (idx == 1 + NM / 2) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 2>{});
-          } else if constexpr (tap == 1) {
-            if constexpr (idx == 1) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 3>{});
-            if constexpr (idx == 1 + NM / 3) issue_a(chunk_n, QNT{}, std::integral_constant<int, BUF ^ 1>{}, std::integral_constant<int, 4>{});
+        constexpr int idx = decltype(IDX)::value;      // MFMA counter of this step, 0 .. NM - 1
+        constexpr int NM = 2 * MT * NT;                // MFMAs per step and wave (32 or 16)
+        if constexpr ((DBG & 1) != 0) return;
+        // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
+        if constexpr (tap == 0) {
+          if constexpr (idx == NM / 4) blds16(rsA, va[0], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 0) * 1024);
+          if constexpr (idx == NM / 4 + 2) blds16(rsA, va[1], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 1) * 1024);
+          if constexpr (idx == NM / 4 + 4) blds16(rsA, va[2], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 2) * 1024);
+        } else if constexpr (tap == 1) {
+          if constexpr (idx == NM / 4) blds16(rsA, va[3], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 3) * 1024);
+          if constexpr (idx == NM / 4 + 3) blds16(rsA, va[4], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 4) * 1024);
+        }
+        static_for<BJ>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          if constexpr (idx == NM - 2 - (BJ - 1 - j) * 2) {
+            if constexpr (tap == 0) issue_b(vb, chunk, QT{}, I3{}, Jc);
+            else issue_b(vb, chunk_n, QNT{}, std::integral_constant<int, tap - 1>{}, Jc);
           }
-        }
-        if (more_b) {
-          static_for<BJ>([&](auto Jc) {
-            constexpr int j = decltype(Jc)::value;
-            constexpr int NM = 2 * MT * NT;
-            if constexpr (idx == NM - 2 - (BJ - 1 - j) * (NM / 6)) {
-              if constexpr (tap == 0) issue_b(chunk, QT{}, std::integral_constant<int, 3>{}, Jc);
-              else issue_b(chunk_n, QNT{}, std::integral_constant<int, tap - 1>{}, Jc);
-            }
-          });
-        }
+        });
       };
-      // first k-half: fragments are already in registers; this step's LDS-DMA pieces go between the MFMAs
+      // first k-half (fragments f0 are in registers); behind each of its first MT + NT MFMAs one read of the second k-half
       static_for<MT * NT>([&](auto IDX) {
-        constexpr int mt = decltype(IDX)::value / NT, nt = decltype(IDX)::value % NT;
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0.b[nt], f0.a[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+        constexpr int idx = decltype(IDX)::value, mt = idx / NT, nt = idx % NT;
+        if constexpr (nt == 0) relu_a(f0.a[mt], rmin);
+        if constexpr ((DBG & 2) != 0) { asm volatile("" :: "v"(f0.a[mt])); asm volatile("" :: "v"(f0.b[nt])); }
+        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0.b[nt], f0.a[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+        if constexpr (RSTEP * (idx / RSTEP) == idx && idx / RSTEP < MT + NT)
+          read_one(BUFT{}, TAPc, I1{}, std::integral_constant<int, rorder(idx / RSTEP)>{}, f1);
         issue_piece(IDX);
+        __builtin_amdgcn_sched_barrier(0);
       });
-      // first k-half of the NEXT step (its data landed one step early)
-      if (s + 1 < nsteps) {
-        if constexpr (tap < 3) read_frag(std::integral_constant<int, BUF>{}, std::integral_constant<int, tap + 1>{}, I0{}, relu, f0);
-        else read_frag(std::integral_constant<int, BUF ^ 1>{}, I0{}, I0{}, relu_n, f0);
-      }
+      // second k-half; behind its first MFMAs the first k-half of the NEXT step (that data landed one step early; after
+      // the last step: stale bytes, unused)
       static_for<MT * NT>([&](auto IDX) {
-        constexpr int mt = decltype(IDX)::value / NT, nt = decltype(IDX)::value % NT;
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1.b[nt], f1.a[mt], acc[mt][nt], 0, 0, 0);
-        issue_piece(std::integral_constant<int, decltype(IDX)::value + MT * NT>{});
+        constexpr int idx = decltype(IDX)::value, mt = idx / NT, nt = idx % NT;
+        if constexpr (nt == 0) relu_a(f1.a[mt], rmin);
+        if constexpr ((DBG & 2) != 0) { asm volatile("" :: "v"(f1.a[mt])); asm volatile("" :: "v"(f1.b[nt])); }
+        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1.b[nt], f1.a[mt], acc[mt][nt], 0, 0, 0);
+        // f0's registers are free once the first k-half's MFMAs have issued: a[i] after MFMA (i, NT-1), b[j] after (MT-1, j)
+        if constexpr (RSTEP * (idx / RSTEP) == idx && idx / RSTEP < MT + NT) {
+          using RI = std::integral_constant<int, rorder(idx / RSTEP)>;
+          if constexpr (tap < 3) read_one(BUFT{}, std::integral_constant<int, tap + 1>{}, I0{}, RI{}, f0);
+          else read_one(BUFN{}, I0{}, I0{}, RI{}, f0);
+        }
+        issue_piece(std::integral_constant<int, idx + MT * NT>{});
+        __builtin_amdgcn_sched_barrier(0);
       });
     });
   };
 
-  for (int c = 0; c < ngroups; ++c) {
-    if constexpr (MODE == 0) {
-      switch (c & 3) {
-        case 0: group(c, I0{}); break;
-        case 1: group(c, I1{}); break;
-        case 2: group(c, std::integral_constant<int, 2>{}); break;
-        default: group(c, std::integral_constant<int, 3>{}); break;
-      }
-    } else {
-      if (c & 1) group(c, I1{}); else group(c, I0{});
-    }
+  if constexpr (MODE == 0) {
+    for (int c = 0; c < ngroups; c += 4) { group(c, I0{}); group(c + 1, I1{}); group(c + 2, I2{}); group(c + 3, I3{}); }
+  } else {
+    int c = 0;
+    for (; c + 1 < ngroups; c += 2) { group(c, I0{}); group(c + 1, I1{}); }
+    if (c < ngroups) group(c, I0{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -698,22 +728,43 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
                        (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
   static int use6 = -1;   // GI_IGEMM6=0: the first-generation halo kernels (tools: A/B)
-  if (use6 < 0) { const char* e = getenv("GI_IGEMM6"); use6 = e ? atoi(e) : 0; }
-  if (use6 && mode != 2 && in_px * a.ldin * 2 < (1ll << 31) && (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31)) {
-    const int LDS6 = 2 * 320 * 128 + 4 * BNk * 128;
-    static bool attr6[5] = {false, false, false, false, false};
-    const void* fn6[5] = {(const void*)igemm6_kernel<0, 128>, (const void*)igemm6_kernel<1, 128>, (const void*)igemm6_kernel<0, 64>,
-                          (const void*)igemm6_kernel<1, 64>, (const void*)igemm6_kernel<3, 128>};
-    const int v6 = dual ? 4 : (BN == 64 ? 2 : 0) + mode;
-    if (!attr6[v6]) { GI_HIP(hipFuncSetAttribute(fn6[v6], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr6[v6] = true; }
-    const int lds = LDS6 > epi ? LDS6 : epi;
+  if (use6 < 0) { const char* e = getenv("GI_IGEMM6"); use6 = e ? atoi(e) : 1; }
+  if (use6 && mode != 2 && in_px * a.ldin * 2 < (1ll << 31) && (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) &&
+      !(mode == 0 && a.relu_in)) {
+    const int lds6 = 2 * 320 * 128 + 4 * BNk * 128;
+    const int lds = lds6 > epi ? lds6 : epi;
+    const int v6 = (dual ? 4 : (BN == 64 ? 2 : 0) + mode) * 2 + (a.relu_in ? 1 : 0);
+    static bool attr6[10] = {false, false, false, false, false, false, false, false, false, false};
+#define GI_K6(MODE_, BN_, RELU_) do { \
+      if (!attr6[v6]) { GI_HIP(hipFuncSetAttribute((const void*)igemm6_kernel<MODE_, BN_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr6[v6] = true; } \
+      hipLaunchKernelGGL((igemm6_kernel<MODE_, BN_, RELU_>), dim3(grid), dim3(512), lds, st, kp); } while (0)
+#ifdef GI_ABLATION   // timing-only ablation kernels compute wrong results: compiled only with `build.sh -DGI_ABLATION`
+    { const char* e = getenv("GI_IGEMM6_DBG"); const int dbg = e ? atoi(e) : 0;
+      if (dbg && v6 == 3) {
+#define GI_K6D(D_) do { GI_HIP(hipFuncSetAttribute((const void*)igemm6_kernel<1, 128, true, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((igemm6_kernel<1, 128, true, D_>), dim3(grid), dim3(512), lds, st, kp); } while (0)
+        switch (dbg) {
+          case 1: GI_K6D(1); break; case 2: GI_K6D(2); break; case 4: GI_K6D(4); break; case 8: GI_K6D(8); break;
+          case 16: GI_K6D(16); break; case 3: GI_K6D(3); break; case 5: GI_K6D(5); break; case 6: GI_K6D(6); break;
+          case 7: GI_K6D(7); break; case 23: GI_K6D(23); break; case 32: GI_K6D(32); break; case 39: GI_K6D(39); break; default: GI_K6D(9); break;
+        }
+#undef GI_K6D
+        GI_LAUNCH_CHECK();
+        a.ntiles_out = mtiles * nph;
+        return GI_OK;
+      } }
+#endif
     switch (v6) {
-      case 0: hipLaunchKernelGGL((igemm6_kernel<0, 128>), dim3(grid), dim3(512), lds, st, kp); break;
-      case 1: hipLaunchKernelGGL((igemm6_kernel<1, 128>), dim3(grid), dim3(512), lds, st, kp); break;
-      case 2: hipLaunchKernelGGL((igemm6_kernel<0, 64>), dim3(grid), dim3(512), lds, st, kp); break;
-      case 3: hipLaunchKernelGGL((igemm6_kernel<1, 64>), dim3(grid), dim3(512), lds, st, kp); break;
-      default: hipLaunchKernelGGL((igemm6_kernel<3, 128>), dim3(grid), dim3(512), lds, st, kp); break;
+      case 0: GI_K6(0, 128, false); break;
+      case 2: GI_K6(1, 128, false); break;
+      case 3: GI_K6(1, 128, true); break;
+      case 4: GI_K6(0, 64, false); break;
+      case 6: GI_K6(1, 64, false); break;
+      case 7: GI_K6(1, 64, true); break;
+      case 8: GI_K6(3, 128, false); break;
+      default: GI_K6(3, 128, true); break;
     }
+#undef GI_K6
     GI_LAUNCH_CHECK();
     a.ntiles_out = mtiles * nph;
     return GI_OK;
