@@ -46,6 +46,20 @@ def synth(n, seed, device):
     return ground.to(device), mask.to(device)
 
 
+def max_over_ranks(dt, world, device):
+    """The contract's timing rule: the slowest rank's time for the K steps."""
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def whole_job_rate(world, per_rank_batch, steps, dt):
+    """images/s over ALL ranks (weak scaling: every rank processes per_rank_batch images per step)."""
+    return world * per_rank_batch * steps / dt
+
+
 def dominant_kernel(iters):
     """u3 of the generator at 256x256 / bs=32: ConvTranspose2d(512 -> 128) on 32x32 maps, i.e. four
     sub-pixel GEMMs of M=32768, N=128, K=2048 (SURVEY.md 8a2 'u3')."""
@@ -297,10 +311,7 @@ def main():
         it += 1
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt, world, dev)
     losses = {k: float(v.item()) for k, v in step.L.items()}
 
     if rank != 0:
@@ -368,7 +379,7 @@ def main():
     flop_batch = BS * ((F_G + 6 * F_D) + (2 * F_G + 2 * F_D) / G_EVERY)
     out = {
         "metric": "training images/sec at 256x256 bs=32/GPU",
-        "value": world * BS * args.steps / dt,
+        "value": whole_job_rate(world, BS, args.steps, dt),
         "unit": "images/sec",
         "n_gpus": world,
         "steps": args.steps,

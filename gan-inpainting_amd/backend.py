@@ -45,6 +45,12 @@ PROTOTYPES = {
     "gi_net_backward_phase": (_i, [_vp, _i, _vp, _vp, _i, _i]),
     "gi_net_phase_split": (_i64, [_vp]),
     "gi_net_phase_split2": (_i64, [_vp]),
+    "gi_comm_unique_id": (_i, [C.c_char_p]),
+    "gi_comm_create": (_i, [C.c_char_p, _i, _i, _i, C.POINTER(_vp)]),
+    "gi_comm_destroy": (_i, [_vp]),
+    "gi_allreduce_sum_f32": (_i, [_vp, _vp, _i64, _vp]),
+    "gi_net_allreduce_grads_async": (_i, [_vp, _vp, _i64, _i64, _vp]),
+    "gi_allreduce_wait": (_i, [_vp, _vp, _vp]),
     "gi_patchgan_gradient_penalty": (_i, [_vp, _vp, _i, _f, _vp]),
     "gi_interpolate": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "gi_mask_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i]),

@@ -1287,6 +1287,13 @@ extern "C" int gi_patchgan_gradient_penalty(gi_net* net, const float* xhat, int 
   return rc;
 }
 
+// flat fp32 gradient buffer of a bound handle (comm.hip)
+float* gi_net_grads_ptr(gi_net* net, int64_t* floats) {
+  if (!net || !net->bound) return nullptr;
+  if (floats) *floats = net->n_params;
+  return net->grads;
+}
+
 extern "C" int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n) {
   GI_REQUIRE(net && net->bound, "net_forward: net not bound");
   GI_REQUIRE(x && y && n >= 1 && n <= net->max_n, "net_forward: n=%d (max %d)", n, net->max_n);

@@ -15,19 +15,31 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, bucket_floats=8 * 1024 * 1024, group=None, use_side_stream=True):
+    """bucket_floats=None (default): ONE collective per launched range - the ranges are the backward's completion phases
+    (generator: decoder 26.5 M floats, inner encoder 12.6 M, outer encoder 2.7 M; critic: conv4 + head, conv3..1), large
+    messages for 7 x 153 GB/s of xGMI per GPU; a number splits a range into buckets of that many floats.
+    Every network has its own communication stream and pending list (`key`, default id(flat)): the critic's reduction
+    (issued from the critic's side stream) and the generator's never queue behind each other.
+    comm='torch' uses torch.distributed (RCCL behind backend "nccl", gloo on CPU); comm='abi' drives RCCL through the
+    library's own C entry points (gi_comm_* / gi_allreduce_sum_f32: include/ganinpaint.h), one communicator per GradSync."""
+
+    def __init__(self, bucket_floats=None, group=None, use_side_stream=True, comm=None):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised torch.distributed process group")
+        import os
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        self.bucket_floats = int(bucket_floats)
+        self.bucket_floats = None if not bucket_floats else int(bucket_floats)
         self.use_side_stream = use_side_stream
-        self._stream = None
-        self._pending = []
+        self.comm = comm or os.environ.get("GI_COMM", "torch")
+        self._streams, self._pending, self._events = {}, {}, {}
+        self._abi = None
 
     # ---- generic (CPU or GPU) -------------------------------------------------------------------
     def buckets(self, begin, end):
+        if self.bucket_floats is None:
+            return [(begin, end - begin)] if end > begin else []
         out, o = [], begin
         while o < end:
             n = min(self.bucket_floats, end - o)
@@ -35,40 +47,72 @@ class GradSync:
             o += n
         return out
 
-    def _comm_stream(self, device):
-        if self._stream is None:
-            self._stream = torch.cuda.Stream(device=device)
-        return self._stream
+    def _comm_stream(self, device, key):
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
 
-    def launch(self, flat, begin=0, end=None):
+    def _abi_comm(self, device):
+        """Lazily created RCCL communicator behind the C-ABI: rank 0 draws the unique id, torch.distributed carries it."""
+        if self._abi is None:
+            from . import backend as B
+            import ctypes as C
+            lib = B.lib()
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if self.rank == 0:
+                buf = (C.c_char * 128)()
+                B.check(lib.gi_comm_unique_id(buf))
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            holder = uid.to(device) if dist.get_backend(self.group) == "nccl" else uid
+            dist.broadcast(holder, 0, group=self.group)
+            raw = bytes(holder.cpu().numpy().tobytes())
+            h = C.c_void_p()
+            B.check(lib.gi_comm_create(raw, self.rank, self.world, device.index or 0, C.byref(h)))
+            self._abi = h
+        return self._abi
+
+    def launch(self, flat, begin=0, end=None, key=None):
         """Start the SUM all-reduce of flat[begin:end] (asynchronously on GPU tensors)."""
         end = flat.numel() if end is None else end
         if self.world == 1 or end <= begin:
             return
+        key = id(flat) if key is None else key
+        pend = self._pending.setdefault(key, [])
         if flat.is_cuda and self.use_side_stream:
             cur = torch.cuda.current_stream(flat.device)
-            comm = self._comm_stream(flat.device)
+            comm = self._comm_stream(flat.device, key)
             comm.wait_stream(cur)               # gradients of this range are complete on `cur`
             with torch.cuda.stream(comm):
                 for o, n in self.buckets(begin, end):
-                    self._pending.append(dist.all_reduce(flat[o:o + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    if self.comm == "abi":
+                        from . import backend as B
+                        B.check(B.lib().gi_allreduce_sum_f32(self._abi_comm(flat.device), flat.data_ptr() + 4 * o, n, comm.cuda_stream))
+                    else:
+                        pend.append(dist.all_reduce(flat[o:o + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             for o, n in self.buckets(begin, end):
-                self._pending.append(dist.all_reduce(flat[o:o + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                pend.append(dist.all_reduce(flat[o:o + n], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def wait(self, device=None):
-        """Make the current stream (or the host, for CPU tensors) wait for every launched bucket."""
-        for w in self._pending:
-            w.wait()
-        self._pending = []
-        if self._stream is not None and device is not None:
-            torch.cuda.current_stream(device).wait_stream(self._stream)
+    def wait(self, device=None, key=None, flat=None):
+        """Make the current stream (or the host, for CPU tensors) wait for the launched ranges of one network (key /
+        flat) or, with neither, of every network."""
+        if flat is not None and key is None:
+            key = id(flat)
+        keys = list(self._pending) if key is None else [key]
+        for k in keys:
+            for w in self._pending.get(k, []):
+                w.wait()
+            self._pending[k] = []
+        if device is not None:
+            for k in (list(self._streams) if key is None else [key]):
+                if k in self._streams:
+                    torch.cuda.current_stream(device).wait_stream(self._streams[k])
 
     # ---- network-level helpers --------------------------------------------------------------------
     def all_reduce(self, net):
         flat = net.flat_grads()
         self.launch(flat)
-        self.wait(flat.device if flat.is_cuda else None)
+        self.wait(flat.device if flat.is_cuda else None, flat=flat)
 
     def grad_scale(self):
         return 1.0 / self.world
@@ -85,6 +129,12 @@ class GradSync:
                 dist.broadcast(t, src, group=self.group)
             if hasattr(net, "mark_dirty"):
                 net.mark_dirty()
+
+    def close(self):
+        if self._abi is not None:
+            from . import backend as B
+            B.lib().gi_comm_destroy(self._abi)
+            self._abi = None
 
 
 def local_device():

@@ -163,8 +163,19 @@ class _StepBase:
         return self.L[name]
 
     def _reduce(self, net):
+        """Start the all-reduce of a network's whole gradient buffer (no overlap with its backward); _step waits for it."""
         if self.sync is not None:
-            self.sync.all_reduce(net)
+            self.sync.launch(net.flat_grads())
+
+    def _step(self, opt):
+        """Optimizer update of the networks of `opt`. The gradient exchange is awaited HERE, as late as possible: whatever
+        the stream issued between the backward and this call (on critic-only batches of the overlapped WGAN step: nothing
+        on the critic's stream, while the main stream is already in the next batch's generator forward) overlaps it."""
+        if self.sync is not None and self.sync.world > 1:
+            for net in opt.nets:
+                flat = net.flat_grads()
+                self.sync.wait(flat.device if flat.is_cuda else None, flat=flat)
+        opt.step()
 
     def _bwd_G(self, gtok, dy):
         """Generator backward; with a GradSync the gradients start their all-reduce in completion order while the
@@ -182,8 +193,7 @@ class _StepBase:
         B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 3))
         self.sync.launch(flat, split2, split)
         B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 4))
-        self.sync.launch(flat, 0, split2)
-        self.sync.wait(flat.device)
+        self.sync.launch(flat, 0, split2)       # awaited by _step(optG)
 
     def _d_pair(self, net, real, fake, kind, t_real, t_fake, name_real, name_fake, gs_real=1.0, gs_fake=1.0, synced=False, x2=None):
         """A discriminator's two calls of a batch, D(real) and D(fake), as ONE [real | fake] batch whose BatchNorm
@@ -211,7 +221,7 @@ class _StepBase:
 
     def _bwd_D_synced(self, net, tok, dy):
         """Critic backward + gradient all-reduce: the conv4 block and the head (8.5 of 11 MB) are reduced while
-        conv3 .. conv1 are still in their backward. Returns with the reduced gradients visible to the current stream."""
+        conv3 .. conv1 are still in their backward; the optimizer step (_step) waits for both ranges."""
         lib = B.lib()
         if net._slot_gen[tok[0]] != tok[1]:
             raise B.BackendError("critic activations were overwritten before their backward")
@@ -224,8 +234,7 @@ class _StepBase:
         B.check(lib.gi_net_backward_phase(net._handle, tok[0], B.ptr(dy), None, 1, 1))
         self.sync.launch(flat, split, flat.numel())
         B.check(lib.gi_net_backward_phase(net._handle, tok[0], B.ptr(dy), None, 1, 2))
-        self.sync.launch(flat, 0, split)
-        self.sync.wait(flat.device)
+        self.sync.launch(flat, 0, split)        # awaited by _step(optD)
 
     @staticmethod
     def _fwd(net, x, bn_groups=1):
@@ -263,7 +272,7 @@ class MinimaxStep(_StepBase):
             o.adv(p, BCE, 0.0, self._loss("d_loss_fake"), self.dpred)
             self._bwd(self.D, t, self.dpred, False, True)
         self._reduce(self.D)
-        self.optD.step()
+        self._step(self.optD)
         # ---- G step :154-173 (D frozen: input gradient only)
         self.optG.zero_grad()
         p, t = self._fwd(self.D, self.inpainted)
@@ -273,7 +282,7 @@ class MinimaxStep(_StepBase):
         o.add(d_adv, self.g_rec, self.tmp1)
         o.mul(self.tmp1, self.mask_c, self.g_gen)                              # d(inpainted)/d(gen) = mask
         self._bwd_G(gtok, self.g_gen)
-        self.optG.step()
+        self._step(self.optG)
         return self.L
 
 
@@ -357,7 +366,7 @@ class WGANStep(_StepBase):
                 self.L["gp"] = self.D.gradient_penalty(ground, inp, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
             if not self._d_synced:
                 self._reduce(self.D)
-            self.optD.step()
+            self._step(self.optD)
             if self.clip > 0 and not self._fused_clip:
                 util.clamp_parameters(self.D, -self.clip, self.clip)
             if update_g:
@@ -372,7 +381,7 @@ class WGANStep(_StepBase):
             o.add(d_adv, self._g_losses(inp, ground), self.tmp1)
             o.mul(self.tmp1, self.mask_c, self.g_gen)
             self._bwd_G(gtok, self.g_gen)
-            self.optG.step()
+            self._step(self.optG)
         return self.L
 
     def side_stream(self):
@@ -409,7 +418,7 @@ class WGANStep(_StepBase):
             self.L["gp"] = self.D.gradient_penalty(ground, self.inpainted, getattr(self, "gp_eps", None), self.gp_lambda).view(1)
         if not self._d_synced:
             self._reduce(self.D)
-        self.optD.step()                                                        # :147
+        self._step(self.optD)                                                   # :147
         if self.clip > 0 and not self._fused_clip:
             util.clamp_parameters(self.D, -self.clip, self.clip)                # :151-153
         if update_g:                                                            # cadence :157-163 is the caller's
@@ -420,7 +429,7 @@ class WGANStep(_StepBase):
             o.add(d_adv, self._g_losses(self.inpainted, ground), self.tmp1)
             o.mul(self.tmp1, self.mask_c, self.g_gen)
             self._bwd_G(gtok, self.g_gen)
-            self.optG.step()
+            self._step(self.optG)
         return self.L
 
     def _critic_stacked(self, ground, inp, x2=None):
@@ -534,7 +543,7 @@ class DualDStep(_StepBase):
         o.mul(self.g_rec, mask, self.tmp1)
         o.add(self.g_adv, self.tmp1, self.g_gen)
         self._bwd_G(gtok, self.g_gen)
-        self.optG.step()                                                        # :172
+        self._step(self.optG)                                                        # :172
         # ---- D step :178-200
         self.optD.zero_grad()
         for net, real, fake, tag in ((self.Dg, ground, gen, "global"), (self.Dl, self.tmp2, self.inpainted, "local")):
@@ -549,5 +558,5 @@ class DualDStep(_StepBase):
             self._bwd(net, t, self.dpred, False, True)
         self._reduce(self.Dg)
         self._reduce(self.Dl)
-        self.optD.step()
+        self._step(self.optD)
         return self.L

@@ -118,6 +118,23 @@ int gi_net_backward_phase(gi_net* net, int slot, const float* dy, float* dx, int
 int64_t gi_net_phase_split(gi_net* net);
 int64_t gi_net_phase_split2(gi_net* net);
 
+/* ---- data-parallel gradient exchange (NOT in the reference, which is single-device: train.py:44-46).
+ * One process per GPU, replicated networks, per-rank minibatch; before every optimizer update the flat fp32 gradient
+ * buffer of the network is SUM-all-reduced over RCCL (xGMI) and the optimizer divides by the world size (grad_scale).
+ * The communicator is created from a 128-byte unique id (rank 0 draws it with gi_comm_unique_id, the host carries it to
+ * the other ranks - e.g. torch.distributed.broadcast, MPI, a file). All calls are asynchronous on the given streams;
+ * gi_net_allreduce_grads_async takes a range [begin, end) of the flat buffer (end < 0: to the end) so that ranges whose
+ * gradients are final (gi_net_backward_phase / gi_net_phase_split) can be reduced while the backward still runs;
+ * gi_allreduce_wait makes compute_stream wait for everything issued on comm_stream so far. librccl is loaded on
+ * first use: GI_ERR_UNSUPPORTED when it is not installed. */
+typedef struct gi_comm gi_comm;
+int gi_comm_unique_id(char* id128_host);
+int gi_comm_create(const char* id128_host, int rank, int world, int device_id, gi_comm** out);
+int gi_comm_destroy(gi_comm* comm);
+int gi_allreduce_sum_f32(gi_comm* comm, float* buf, int64_t count, void* hip_comm_stream);
+int gi_net_allreduce_grads_async(gi_net* net, gi_comm* comm, int64_t begin, int64_t end, void* hip_comm_stream);
+int gi_allreduce_wait(gi_comm* comm, void* hip_comm_stream, void* hip_compute_stream);
+
 /* WGAN-GP EXTENSION (not in the reference, which clips weights: wgan_l1.py:151-153): accumulates the
  * parameter gradient of  lam * mean_n (||grad_x D(xhat)_n||_2 - 1)^2  into the bound grads and writes the
  * penalty to penalty_out[0] (device). xhat: (n,1,H,W) interpolates, e.g. from gi_interpolate.

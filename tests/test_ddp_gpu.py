@@ -1,17 +1,23 @@
-"""GPU tier: the data-parallel step path with world_size 2. Both ranks share cuda:0 and exchange
-gradients through gloo (RCCL needs one device per rank; the driver's 8-GPU run uses "nccl"): replicas
-start identical (broadcast), run WGAN batches on different data with the two-phase generator backward
-+ bucketed side-stream all-reduce, and must stay bit-identical; the averaged-gradient update must
-equal a single-process emulation that accumulates both ranks' gradients and scales by 1/2."""
+"""GPU tier: the data-parallel step path with world_size 2. Both ranks share cuda:0 and exchange gradients through gloo
+(RCCL needs one device per rank; the driver's 8-GPU run uses "nccl"): replicas start identical (broadcast), run one WGAN
+batch with a generator update on DIFFERENT data (8 images per rank at 128x128: every BatchNorm population has >= 8
+values) through the overlapped two-stream step with the phase-split backward and per-range all-reduces, and
+  * the replicas' parameters stay bit-identical,
+  * the REDUCED gradient buffers (critic and generator) equal, element by element, the gradients a single process
+    accumulates over both ranks' batches with per-rank BatchNorm statistics.
+Plus the C-ABI collective entries (gi_comm_*, gi_allreduce_*) on a one-rank RCCL communicator."""
+import ctypes as C
 import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NB, HW = 8, 128
 
 
 def _free_port():
@@ -23,7 +29,6 @@ def _free_port():
 
 
 def _build(dtype):
-    import numpy as np
     import gan_inpainting_amd  # noqa: F401
     from gan_inpainting_amd.lib.models import networks
     from oracle import params as op
@@ -34,17 +39,16 @@ def _build(dtype):
     return G.to("cuda:0"), D.to("cuda:0")
 
 
-def _batch(rank, it):
-    import numpy as np
+def _batch(rank):
     from oracle import params as op
-    g, m = op.synth_batch(1000 * rank + it, 2, 128, 128)
+    g, m = op.synth_batch(1000 * rank + 17, NB, HW, HW)
     return torch.from_numpy(g).cuda(), torch.from_numpy(m).cuda()
 
 
-def _masks(it):
-    g = torch.Generator().manual_seed(77 + it)
-    return {5: (torch.rand((2, 512, 8, 8), generator=g) < 0.5).to(torch.uint8),
-            6: (torch.rand((2, 512, 4, 4), generator=g) < 0.5).to(torch.uint8)}
+def _masks(rank):
+    g = torch.Generator().manual_seed(77 + rank)
+    return {5: (torch.rand((NB, 512, 8, 8), generator=g) < 0.5).to(torch.uint8),
+            6: (torch.rand((NB, 512, 4, 4), generator=g) < 0.5).to(torch.uint8)}
 
 
 def _worker(rank, world, port, q):
@@ -55,23 +59,19 @@ def _worker(rank, world, port, q):
     from gan_inpainting_amd import optim, parallel, trainer
     parallel.init_from_env()
     G, D = _build("fp32")
-    torch.distributed.broadcast(G.flat_params(), 0)
-    torch.distributed.broadcast(D.flat_params(), 0)
-    G.mark_dirty(), D.mark_dirty()
-    sync = parallel.GradSync(bucket_floats=4 * 1024 * 1024)
+    sync = parallel.GradSync()
     step = trainer.WGANStep(G, D, optim.RMSprop(G.parameters(), lr=5e-5), optim.RMSprop(D.parameters(), lr=5e-5), sync=sync,
-                            overlap=True)   # critic on a side stream, as bench.py runs it
-    for it in range(2):
-        g, m = _batch(rank, it)
-        G.impose_dropout_masks(_masks(it))
-        step(g, m, it == 1)
+                            overlap=True)   # critic on a side stream, as bench.py runs it; replicas broadcast from rank 0
+    g, m = _batch(rank)
+    G.impose_dropout_masks(_masks(rank))
+    step(g, m, True)
     torch.cuda.synchronize()
     # numpy arrays travel by value (torch tensors would be passed as file descriptors of a process that exits)
-    q.put((rank, G.flat_params().cpu().numpy(), D.flat_params().cpu().numpy()))
+    q.put((rank, G.flat_params().cpu().numpy(), D.flat_params().cpu().numpy(), G.flat_grads().cpu().numpy(), D.flat_grads().cpu().numpy()))
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_stay_identical_and_match_accumulated_gradients():
+def test_two_ranks_reduce_to_the_accumulated_gradients_and_stay_identical():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -79,71 +79,112 @@ def test_two_ranks_stay_identical_and_match_accumulated_gradients():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict((r, (torch.from_numpy(g), torch.from_numpy(d))) for r, g, d in [q.get(timeout=300) for _ in procs])
+    res = dict((r, tuple(torch.from_numpy(a) for a in rest)) for r, *rest in [q.get(timeout=300) for _ in procs])
     for p in procs:
         p.join(timeout=60)
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "replicas diverged"
+    for i, what in enumerate(("generator parameters", "critic parameters", "generator gradients", "critic gradients")):
+        assert torch.equal(res[0][i], res[1][i]), f"replicas diverged: {what}"
 
-    # single-process emulation: accumulate both ranks' gradients, update with scale 1/2
+    # single-process emulation: accumulate both ranks' gradients (per-rank forwards: local BatchNorm statistics)
     import gan_inpainting_amd  # noqa: F401
-    from gan_inpainting_amd import backend as B, optim, trainer
+    from gan_inpainting_amd import optim, trainer
     G, D = _build("fp32")
     oG, oD = optim.RMSprop(G.parameters(), lr=5e-5, clamp=0.0), optim.RMSprop(D.parameters(), lr=5e-5, clamp=0.01)
     oG.grad_scale = oD.grad_scale = 0.5
     ops = trainer._Ops("cuda:0")
-    for it in range(2):
-        packs = []
-        oD.zero_grad()
-        for rank in range(2):            # critic step: per-rank forward with LOCAL BatchNorm statistics
-            g, m = _batch(rank, it)
-            mc, masked, inp = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
-            ops.mask_apply(g, m, mc, masked, True)
-            G.impose_dropout_masks(_masks(it))
-            gen, gs, gg = G._forward_raw(masked)
-            ops.composite(masked, gen, mc, inp)
-            dp = torch.empty((2, 1), device="cuda")
-            L = torch.zeros(1, device="cuda")
-            pr, s1, g1 = D._forward_raw(g)
-            pf, s2, g2 = D._forward_raw(inp)
-            ops.adv(pr, 2, 0.0, L, dp, +1.0)
-            D._backward_raw(s1, g1, dp, False, True)
-            ops.adv(pf, 2, 0.0, L, dp, -1.0)
-            D._backward_raw(s2, g2, dp, False, True)
-            packs.append((g, mc, inp, gs, gg))
-        oD.step()
-        if it == 1:
-            oG.zero_grad()
-            # NOTE: each rank's generator activations must still be live: 2 forwards <= n_slots (3)
-            for (g, mc, inp, gs, gg) in packs:
-                dp = torch.empty((2, 1), device="cuda")
-                L = torch.zeros(1, device="cuda")
-                p, s, gn = D._forward_raw(inp)
-                ops.adv(p, 2, 0.0, L, dp, +1.0)
-                d_adv = D._backward_raw(s, gn, dp, True, False)
-                g_rec, tmp, g_gen = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
-                ops.recon("l1", inp, g, L, g_rec)
-                ops.add(d_adv, g_rec, tmp)
-                ops.mul(tmp, mc, g_gen)
-                G._backward_raw(gs, gg, g_gen, False, True)
-            oG.step()
+    packs = []
+    oD.zero_grad()
+    for rank in range(2):
+        g, m = _batch(rank)
+        mc, masked, inp = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+        ops.mask_apply(g, m, mc, masked, True)
+        G.impose_dropout_masks(_masks(rank))
+        gen, gs, gg = G._forward_raw(masked)
+        ops.composite(masked, gen, mc, inp)
+        x2 = torch.cat([g, inp], 0).contiguous()       # the stacked [ground | inpainted] critic pass of the step
+        dp2 = torch.empty((2 * NB, 1), device="cuda")
+        L = torch.zeros(1, device="cuda")
+        p, s1, g1 = D._forward_raw(x2, 2)
+        ops.adv(p[:NB], 2, 0.0, L, dp2[:NB], +1.0)
+        ops.adv(p[NB:], 2, 0.0, L, dp2[NB:], -1.0)
+        D._backward_raw(s1, g1, dp2, False, True)
+        packs.append((g, mc, inp, gs, gg))
+    d_acc = D.flat_grads().cpu().clone()
+    oD.step()
+    oG.zero_grad()
+    for (g, mc, inp, gs, gg) in packs:               # each rank's generator activations are still live (2 <= n_slots)
+        dp = torch.empty((NB, 1), device="cuda")
+        L = torch.zeros(1, device="cuda")
+        p, s, gn = D._forward_raw(inp)
+        ops.adv(p, 2, 0.0, L, dp, +1.0)
+        d_adv = D._backward_raw(s, gn, dp, True, False)
+        g_rec, tmp, g_gen = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+        ops.recon("l1", inp, g, L, g_rec)
+        ops.add(d_adv, g_rec, tmp)
+        ops.mul(tmp, mc, g_gen)
+        G._backward_raw(gs, gg, g_gen, False, True)
+    g_acc = G.flat_grads().cpu().clone()
     torch.cuda.synchronize()
-    eg = (G.flat_params().cpu() - res[0][0]).abs().max().item()
-    ed = (D.flat_params().cpu() - res[0][1]).abs().max().item()
-    print("max |param diff| vs accumulated-gradient emulation: G", eg, "D", ed)
-    # RMSprop's first step is lr*10*sign(g): elements whose gradient is at rounding level may flip
-    assert ed <= 2.1e-3 and eg <= 2.1e-3
-    frac_g = ((G.flat_params().cpu() - res[0][0]).abs() > 1e-6).float().mean().item()
-    frac_d = ((D.flat_params().cpu() - res[0][1]).abs() > 1e-6).float().mean().item()
-    if frac_g >= 2e-2:   # diagnostic: which tensors moved
-        diff = (G.flat_params().cpu() - res[0][0]).abs()
-        for t in G._inv:
+
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+    ed, eg = rel(res[0][3], d_acc), rel(res[0][2], g_acc)
+    print("reduced vs accumulated gradients, max |diff| / max |ref|: critic", ed, "generator", eg)
+    # fp32: sum over ranks by the collective vs accumulation by the kernels (another order of two additions, and the
+    # remaining float atomics of the single-channel weight gradients): a missing range would show as O(1)
+    assert ed <= 2e-6 and eg <= 2e-5, (ed, eg)
+    # every tensor of the inventory took part (no range forgotten): per-tensor check with a relative floor
+    for net, red, acc in ((G, res[0][2], g_acc), (D, res[0][3], d_acc)):
+        for t in net._inv:
             if t["kind"] <= 1:
-                d = diff[t["offset"]: t["offset"] + t["numel"]]
-                f = (d > 1e-6).float().mean().item()
-                if f > 1e-3:
-                    print(f"  {t['name']}: frac {f:.4f}")
-    # With N=2 at 128x128 whole generator layers have gradients at rounding level (BatchNorm over 2-8 values),
-    # and the fp32 atomics of the weight-gradient kernels order their sums differently from run to run: observed
-    # fractions of sign-flipped elements range from 1e-5 to 8e-2 over repeated runs of the SAME code. A missing or
-    # wrong all-reduce flips the sign of ~half of all elements (sign(g0) vs sign(g0+g1)); the bound separates the two.
-    assert frac_g < 0.2 and frac_d < 2e-2, (frac_g, frac_d)
+                a, b = red[t["offset"]: t["offset"] + t["numel"]], acc[t["offset"]: t["offset"] + t["numel"]]
+                assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7, t["name"]
+
+
+def test_c_abi_collective_entries_on_one_rank():
+    """gi_comm_unique_id / gi_comm_create / gi_allreduce_sum_f32 / gi_net_allreduce_grads_async / gi_allreduce_wait on a
+    world-size-1 RCCL communicator (the only size one GPU can hold): SUM over one rank is the identity, ranges are
+    checked, the wait orders the compute stream behind the communication stream."""
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import backend as B
+    from gan_inpainting_amd.lib.models import networks
+    lib = B.lib()
+    uid = (C.c_char * 128)()
+    B.check(lib.gi_comm_unique_id(uid))
+    comm = C.c_void_p()
+    B.check(lib.gi_comm_create(bytes(uid.raw), 0, 1, 0, C.byref(comm)))
+    side = torch.cuda.Stream()
+    buf = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    ref = buf.clone()
+    side.wait_stream(torch.cuda.current_stream())
+    B.check(lib.gi_allreduce_sum_f32(comm, B.ptr(buf), buf.numel(), side.cuda_stream))
+    B.check(lib.gi_allreduce_wait(comm, side.cuda_stream, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(buf, ref)
+    D = networks.PatchGANDiscriminator(sigmoid=False, image_size=64, dtype="fp32").cuda()
+    D(torch.rand(2, 1, 64, 64, device="cuda")).sum().backward()
+    g0 = D.flat_grads().clone()
+    split = lib.gi_net_phase_split(D._handle)
+    side.wait_stream(torch.cuda.current_stream())
+    B.check(lib.gi_net_allreduce_grads_async(D._handle, comm, split, -1, side.cuda_stream))
+    B.check(lib.gi_net_allreduce_grads_async(D._handle, comm, 0, split, side.cuda_stream))
+    B.check(lib.gi_allreduce_wait(comm, side.cuda_stream, torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(D.flat_grads(), g0)
+    assert lib.gi_net_allreduce_grads_async(D._handle, comm, 10, 5, side.cuda_stream) != 0      # empty / reversed range refused
+    B.check(lib.gi_comm_destroy(comm))
+    # the same through GradSync(comm='abi') needs an initialised process group: one rank, gloo
+    import torch.distributed as dist
+    from gan_inpainting_amd import parallel
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
+    try:
+        sync = parallel.GradSync(comm="abi")
+        h = sync._abi_comm(torch.device("cuda", 0))       # a one-rank communicator ...
+        assert h.value
+        sync.world = 2            # ... then force the exchange path (launch / wait skip it for world 1): SUM over the one rank
+        sync.launch(D.flat_grads())
+        sync.wait(torch.device("cuda", 0), flat=D.flat_grads())
+        torch.cuda.synchronize()
+        assert torch.equal(D.flat_grads(), g0)
+        sync.close()
+    finally:
+        dist.destroy_process_group()

@@ -39,6 +39,20 @@ def _worker(rank, world, port, q):
     expect = torch.arange(n, dtype=torch.float32) * sum(range(1, world + 1))
     ok = bool(torch.equal(flat, expect)) and abs(sync.grad_scale() - 1.0 / world) < 1e-12
     assert len(sync.buckets(0, n)) == 5
+    # default: one collective per launched range; every network (key) has its own pending list
+    s2 = parallel.GradSync(use_side_stream=False)
+    assert s2.buckets(10, 4567) == [(10, 4557)] and s2.buckets(5, 5) == []
+    fa = torch.full((100,), float(rank + 1))
+    fb = torch.full((50,), 10.0 * (rank + 1))
+    s2.launch(fa, 0, 60, key="G")
+    s2.launch(fb, key="D")
+    s2.launch(fa, 60, 100, key="G")
+    assert len(s2._pending["G"]) == 2 and len(s2._pending["D"]) == 1
+    s2.wait(key="D")
+    assert s2._pending["D"] == [] and len(s2._pending["G"]) == 2
+    s2.wait(key="G")
+    tot = float(sum(range(1, world + 1)))
+    ok = ok and bool(torch.all(fa == tot)) and bool(torch.all(fb == 10.0 * tot))
     # replicas start from rank 0's weights and running statistics, whatever each rank's RNG did before
     torch.manual_seed(100 + rank)
     net = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4))
@@ -63,3 +77,37 @@ def test_gradsync_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      GI_DIST_BACKEND="gloo")
+    import bench
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import parallel
+    r, w = parallel.init_from_env()               # what bench.main() does first under torch.distributed.run
+    dt = bench.max_over_ranks(0.5 + rank, w, torch.device("cpu"))      # rank 1 is the slow one
+    rate = bench.whole_job_rate(w, bench.BS, 10, dt)
+    # identical replicas: the broadcast bench.main() issues for both networks
+    flat = torch.full((7,), float(rank))
+    dist.broadcast(flat, 0)
+    q.put((rank, r, w, dt, rate, float(flat.sum())))
+    dist.destroy_process_group()
+
+
+def test_bench_multi_rank_plumbing_world2_gloo():
+    """bench.py's N > 1 path without a GPU: rank / world from the torch.distributed.run environment, MAX over ranks of the
+    timed region, whole-job rate = world x per-rank batch x steps / that time, replicas broadcast from rank 0."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for rank, (rk, r, w, dt, rate, bsum) in enumerate(res):
+        assert (rk, r, w) == (rank, rank, 2)
+        assert dt == 1.5 and abs(rate - 2 * 32 * 10 / 1.5) < 1e-9 and bsum == 0.0
