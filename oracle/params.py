@@ -72,24 +72,30 @@ def _bn(rng, P, prefix, c):
     P[f"{prefix}.num_batches_tracked"] = np.array(0, dtype=np.int64)
 
 
-def make_unet_params(seed, num_downs=7, ngf=64, in_c=1, out_c=1):
+def make_unet_params(seed, num_downs=7, ngf=64, in_c=1, out_c=1, norm="batch"):
+    """norm: 'batch' (get_network's choice, networks.py:18), 'instance' (get_norm_layer('instance'): InstanceNorm2d without
+    affine parameters or running statistics, and every convolution gets a bias, networks.py:279-286,300-309) or 'none'
+    (Identity norm layers, no biases but the outermost up-convolution's)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     P = OrderedDict()
     levels = unet_channels(num_downs, ngf, in_c, out_c)
     keys = unet_key_layout(num_downs)
+    use_bias = norm == "instance"
 
     def emit(k):
         lv, ky = levels[k - 1], keys[k - 1]
         P[f"{ky['down']}.weight"] = _uniform(rng, (lv["ch"], lv["cin"], 4, 4), 1.0 / np.sqrt(lv["cin"] * 16))
-        if ky["dnorm"]:
+        if use_bias:
+            P[f"{ky['down']}.bias"] = _uniform(rng, (lv["ch"],), 1.0 / np.sqrt(lv["cin"] * 16))
+        if ky["dnorm"] and norm == "batch":
             _bn(rng, P, ky["dnorm"], lv["ch"])
         if k < num_downs:
             emit(k + 1)
         # ConvTranspose2d weight is [in, out, kh, kw]; torch takes fan_in from dim 1
         P[f"{ky['up']}.weight"] = _uniform(rng, (lv["up_in"], lv["up_out"], 4, 4), 1.0 / np.sqrt(lv["up_out"] * 16))
-        if k == 1:
+        if k == 1 or use_bias:
             P[f"{ky['up']}.bias"] = _uniform(rng, (lv["up_out"],), 1.0 / np.sqrt(lv["up_out"] * 16))
-        if ky["unorm"]:
+        if ky["unorm"] and norm == "batch":
             _bn(rng, P, ky["unorm"], lv["up_out"])
 
     emit(1)

@@ -48,7 +48,17 @@ def _bn(P, prefix, x, train):
                         P[prefix + ".weight"], P[prefix + ".bias"], train, BN_MOMENTUM, BN_EPS)
 
 
-def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None):
+def _norm(P, prefix, x, train, norm):
+    """The norm_layer of a block (networks.py:30-45): BatchNorm2d(affine, running statistics), InstanceNorm2d(affine=False,
+    track_running_stats=False: instance statistics in train AND eval mode, eps 1e-5) or Identity."""
+    if norm == "batch":
+        return _bn(P, prefix, x, train)
+    if norm == "instance":
+        return F.instance_norm(x, eps=BN_EPS)
+    return x
+
+
+def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None, norm="batch"):
     """UnetGenerator.forward (networks.py:246-253) through the recursive
     UnetSkipConnectionBlock.forward (networks.py:320-324), unrolled.
 
@@ -64,20 +74,20 @@ def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None):
     keys = _p.unet_key_layout(num_downs)
     drops = _p.dropout_levels(num_downs)
     skips = {}
-    h = F.conv2d(x, P[keys[0]["down"] + ".weight"], None, stride=2, padding=1)
+    h = F.conv2d(x, P[keys[0]["down"] + ".weight"], P.get(keys[0]["down"] + ".bias"), stride=2, padding=1)
     for k in range(2, num_downs + 1):
         s = F.leaky_relu(h, 0.2)
         skips[k - 1] = s
-        h = F.conv2d(s, P[keys[k - 1]["down"] + ".weight"], None, stride=2, padding=1)
+        h = F.conv2d(s, P[keys[k - 1]["down"] + ".weight"], P.get(keys[k - 1]["down"] + ".bias"), stride=2, padding=1)
         if keys[k - 1]["dnorm"]:
-            h = _bn(P, keys[k - 1]["dnorm"], h, train)
+            h = _norm(P, keys[k - 1]["dnorm"], h, train, norm)
     u = h
     for k in range(num_downs, 0, -1):
         inp = F.relu(u) if k == num_downs else F.relu(torch.cat([skips[k], u], 1))
         bias = P.get(keys[k - 1]["up"] + ".bias")
         u = F.conv_transpose2d(inp, P[keys[k - 1]["up"] + ".weight"], bias, stride=2, padding=1)
         if keys[k - 1]["unorm"]:
-            u = _bn(P, keys[k - 1]["unorm"], u, train)
+            u = _norm(P, keys[k - 1]["unorm"], u, train, norm)
         if train and k in drops:
             u = u * dropout_masks[k].to(u.dtype) * 2.0
     return torch.tanh(u)

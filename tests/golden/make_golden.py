@@ -149,6 +149,47 @@ def case_unet(networks, name, seed, N, HW, num_downs, train):
     return fx
 
 
+def case_unet_norm(networks, name, seed, N, HW, num_downs, norm):
+    """UnetGenerator built with get_norm_layer('instance') / ('none') (networks.py:30-45; never chosen by get_network, but
+    part of the class's surface): InstanceNorm2d without affine parameters or running statistics, every convolution with
+    a bias (:279-286), resp. Identity norm layers. Train-mode forward + backward and an eval-mode forward (InstanceNorm
+    uses instance statistics in both) on the reference class; the oracle is asserted equal."""
+    torch.manual_seed(2000 + seed)
+    P = op.make_unet_params(seed, num_downs=num_downs, ngf=64, norm=norm)
+    net = networks.UnetGenerator(1, 1, num_downs, ngf=64, norm_layer=networks.get_norm_layer(norm_type=norm), use_dropout="False")
+    assert [k for k in net.state_dict().keys()] == [k for k in P.keys()], "state_dict layout"
+    load(net, P)
+    net.train(True)
+    cap = MaskCapture(net, num_downs)
+    ground, mask = op.synth_batch(seed + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask))
+    rng = np.random.Generator(np.random.PCG64(seed + 99))
+    R = torch.from_numpy(rng.standard_normal(size=(N, 1, HW, HW), dtype=np.float32))
+    xr = x.clone().requires_grad_(True)
+    out = net(xr)
+    (out * R).sum().backward()
+    names, absmean, head = grad_stats(net)
+    fx = dict(seed=seed, N=N, HW=HW, num_downs=num_downs, norm=np.array(norm), out=out.detach().numpy(), dx=xr.grad.numpy().copy(),
+              grad_names=np.array(names), grad_absmean=absmean, **{f"ghead_{i}": h for i, h in enumerate(head)})
+    fx.update(pack_masks(cap.masks))
+    OP = orc.to_torch(P)
+    xo = x.clone().requires_grad_(True)
+    oout = orc.unet_forward(OP, xo, num_downs, True, dict(cap.masks), norm=norm)
+    e = close(oout.detach().numpy(), fx["out"], 1e-6, name + ".out")
+    (oout * R).sum().backward()
+    for i, n in enumerate(names):
+        close(float(OP[n].grad.abs().mean()), absmean[i], 1e-5, f"{name}.grad[{n}]")
+    close(xo.grad.numpy(), fx["dx"], 1e-5, name + ".dx")
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+        oev = orc.unet_forward(OP, x, num_downs, False, None, norm=norm)
+    close(oev.numpy(), ev.numpy(), 1e-6, name + ".eval_out")
+    fx["eval_out"] = ev.numpy()
+    print(f"  {name}: out err {e:.2e}")
+    return fx
+
+
 def case_patchgan(networks, name, seed, N):
     P = op.make_patchgan_params(seed, 128, 128)
     fx = dict(seed=seed, N=N)
@@ -793,6 +834,8 @@ def main():
         resize=lambda: case_resize("resize"),
         config5_steps=lambda: case_config5(networks, util, args.ref, "config5_steps", 97, 2, [0, 1]),
         losses=lambda: case_losses(args.ref, "losses"),
+        unet128_instance=lambda: case_unet_norm(networks, "unet128_instance", 15, 2, 128, 7, "instance"),
+        unet128_none=lambda: case_unet_norm(networks, "unet128_none", 16, 2, 128, 7, "none"),
     )
     for name, fn in cases.items():
         if args.only and name not in args.only.split(","):

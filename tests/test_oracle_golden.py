@@ -219,3 +219,27 @@ def test_loss_objects():
             assert relerr(float(v.detach()), fx[f"adv{j}_{tag}"]) < 1e-6, (j, tag)
             ref = fx[f"adv{j}_{tag}_grad"]
             assert np.abs(p.grad.numpy() - ref).max() <= 1e-6 * np.abs(ref).max(), (j, tag)
+
+
+@pytest.mark.parametrize("name", ["unet128_instance", "unet128_none"])
+def test_unet_other_norm_layers(name):
+    """UnetGenerator with get_norm_layer('instance') / ('none') (networks.py:30-45, :279-286): oracle == the reference
+    class, train-mode forward + backward and eval-mode forward."""
+    fx = load(name)
+    seed, N, HW, nd, norm = int(fx["seed"]), int(fx["N"]), int(fx["HW"]), int(fx["num_downs"]), str(fx["norm"])
+    P = op.make_unet_params(seed, num_downs=nd, norm=norm)
+    OP = orc.to_torch(P)
+    ground, mask = op.synth_batch(seed + 7, N, HW, HW)
+    x = torch.from_numpy(ground * (1 - mask)).requires_grad_(True)
+    R = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 99)).standard_normal(size=(N, 1, HW, HW), dtype=np.float32))
+    y = orc.unet_forward(OP, x, nd, True, unpack_masks(fx), norm=norm)
+    assert relerr(y.detach().numpy(), fx["out"], floor=1e-3) < 1e-4
+    (y * R).sum().backward()
+    assert np.abs(x.grad.numpy() - fx["dx"]).max() <= 1e-4 * np.abs(fx["dx"]).max()
+    names = [str(n) for n in fx["grad_names"]]
+    assert names == orc.named_parameter_keys(P)
+    for n, ref in zip(names, fx["grad_absmean"]):
+        assert abs(float(OP[n].grad.abs().mean()) - ref) <= 1e-4 * abs(ref) + 1e-7, n
+    with torch.no_grad():
+        ev = orc.unet_forward(OP, x.detach(), nd, False, None, norm=norm)
+    assert relerr(ev.numpy(), fx["eval_out"], floor=1e-3) < 1e-4
