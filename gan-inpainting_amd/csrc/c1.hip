@@ -23,7 +23,7 @@ __device__ __forceinline__ float act_f(float v, int act) {
 template <typename T>
 __global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                         char* out, int n, int Hs, int Ws, int c, int ldout,
-                                                        int coffout, int act, float in_scale) {
+                                                        int coffout, int act, float in_scale, const float* __restrict__ bias) {
   constexpr int G = 8;  // channels per thread
   extern __shared__ __attribute__((aligned(16))) float swT[];  // [16][c]
   for (int i = threadIdx.x; i < c * 16; i += 256) swT[(i & 15) * c + (i >> 4)] = w[i];
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict_
     const float* ip = img + (int64_t)nn * H * W;
     float o[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) o[j] = 0.f;
+    for (int j = 0; j < G; ++j) o[j] = bias ? bias[grp * G + j] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky) {
       const int iy = 2 * y - 1 + ky;
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) c1_gather_kernel(const float* __restrict_
 template <typename T>
 __global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                               char* out, int n, int Hs, int Ws, int c, int ldout,
-                                                              int coffout, int act, float in_scale) {
+                                                              int coffout, int act, float in_scale, const float* __restrict__ bias) {
   constexpr int G = 8;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   const int groups = c / G;
@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __res
     const float* tl = tile + buf * 4 * TW + 2 * pi;
     float o[G];
 #pragma unroll
-    for (int j = 0; j < G; ++j) o[j] = 0.f;
+    for (int j = 0; j < G; ++j) o[j] = bias ? bias[grp * G + j] : 0.f;
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
 #pragma unroll
@@ -1058,11 +1058,11 @@ int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh) {
 }
 
 int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs, int Ws, int c,
-                 int ldout, int coffout, int act_out, float in_scale) {
+                 int ldout, int coffout, int act_out, float in_scale, const float* bias) {
   GI_REQUIRE(c % 8 == 0 && c <= 1024, "c1_gather: c=%d", c);
   const int64_t total = (int64_t)n * Hs * Ws * (c / 8);
   const int groups = c / 8;
-  if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 8 == 0 && coffout % 8 == 0) {
+  if (dtype == GI_F16 && !bias && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 8 == 0 && coffout % 8 == 0) {
     const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
     const int grid = grid_for(ngroups, 4, 256 * 8);
     if (c == 64)
@@ -1079,20 +1079,20 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
     const size_t lds = (size_t)(16 * c + 2 * 4 * (2 * S + 2)) * 4;
     if (dtype == GI_F16)
       hipLaunchKernelGGL(c1_gather_strip_kernel<half_t>, dim3(grid), dim3(256), lds, st, img, w, (char*)out, n, Hs, Ws, c, ldout,
-                         coffout, act_out, in_scale);
+                         coffout, act_out, in_scale, bias);
     else
       hipLaunchKernelGGL(c1_gather_strip_kernel<float>, dim3(grid), dim3(256), lds, st, img, w, (char*)out, n, Hs, Ws, c, ldout,
-                         coffout, act_out, in_scale);
+                         coffout, act_out, in_scale, bias);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
   const int grid = grid_for(total, 256, 256 * 16);
   if (dtype == GI_F16)
     hipLaunchKernelGGL(c1_gather_kernel<half_t>, dim3(grid), dim3(256), c * 16 * 4, st, img, w, (char*)out, n, Hs, Ws, c,
-                       ldout, coffout, act_out, in_scale);
+                       ldout, coffout, act_out, in_scale, bias);
   else
     hipLaunchKernelGGL(c1_gather_kernel<float>, dim3(grid), dim3(256), c * 16 * 4, st, img, w, (char*)out, n, Hs, Ws, c,
-                       ldout, coffout, act_out, in_scale);
+                       ldout, coffout, act_out, in_scale, bias);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

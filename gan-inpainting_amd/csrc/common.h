@@ -135,7 +135,7 @@ int64_t op_wgrad_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb)
 // conv): weights fp32 [c][16] (= [a][ky][kx][b] with b == 1)
 // out[p][c] = act(sum_tap img[n,2y-1+ky,2x-1+kx] * w[c][tap])      img fp32 (n,2Hs,2Ws)
 int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs,
-                 int Ws, int c, int ldout, int coffout, int act_out, float in_scale);
+                 int Ws, int c, int ldout, int coffout, int act_out, float in_scale, const float* bias = nullptr);
 // img[n,Y,X] = post( bias + sum_{c,tap} relu?(X[p][c]) * w[c][tap] ) (overlap-add of the 4x4 taps)
 // post: 0 none, 1 tanh. img fp32 (n,2Hs,2Ws); out_scale multiplies the result (loss-scale removal)
 // col_scratch (fp16 path): >= n*Hs*Ws*16 halves; null selects the register-reduction kernel
@@ -209,7 +209,15 @@ struct ActBnBwdArgs {
   unsigned long long* acc; int acc_reps; unsigned long long* zero_next; int zero_words;
 };
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a);
-int op_bwd_rows_per_block(int64_t pixels);   // rows one reduce workgroup covers (groups = 2 needs pixels/2 to be a multiple)
+int op_bwd_rows_per_block(int64_t pixels);
+// InstanceNorm2d(affine=False, track_running_stats=False) (get_norm_layer('instance'), networks.py:38-40): per (image, channel)
+// statistics over hw pixels; x dense (n*hw, c); stats [n][c][2] = mean, inv (kept for the backward)
+int op_in_forward(hipStream_t st, int dtype, const void* x, void* y, int n, int hw, int c, int ldy, int coffy, int act,
+                  const uint8_t* drop_mask, float drop_scale, float eps, float* stats);
+// backward through [dropout] -> activation -> InstanceNorm (ActBnBwdArgs: g1, g2, y, x, dx, pixels, c, act, drop_scale)
+int op_act_in_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a, int n, int hw, const float* stats);
+// dbias[ch] += scale * sum_pixels dz[p][ch]; partials: scratch for the column pass ((pixels/32 + 8) * 2 * c floats)
+int op_bias_grad(hipStream_t st, int dtype, const void* dz, int64_t pixels, int c, float scale, float* dbias, float* partials);   // rows one reduce workgroup covers (groups = 2 needs pixels/2 to be a multiple)
 
 // discriminator head: conv(512->1,k4,s1,p0) + Flatten + Linear(P,1) [+ sigmoid]
 struct HeadArgs {

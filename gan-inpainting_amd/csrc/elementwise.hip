@@ -4,6 +4,7 @@
 // (per-block partials + fixed-order final sum) except where an accumulate-into-gradient semantic
 // makes a float atomic the natural form.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 #include "stat_acc.h"
@@ -529,6 +530,113 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
     }
     store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, dz);
   }
+}
+
+// ---- InstanceNorm2d(affine=False, track_running_stats=False), get_norm_layer('instance') (networks.py:38-40) -------------
+// Statistics per (image, channel) over the H*W pixels, eps 1e-5, the same in train and eval mode; no parameters. One
+// workgroup owns (image, 16-byte channel chunk): a first sweep over the image's pixels sums x and x^2 (fp32 per thread,
+// double across the block, fixed order), a second one writes act((x - mean) * inv) (+ dropout) - the plane is re-read
+// from L2. stats [n][c][2] keeps mean / inv for the backward.
+template <typename T>
+__global__ void __launch_bounds__(256) in_forward_kernel(const char* x, char* y, int hw, int c, int ldy, int coffy, int act,
+                                                         const uint8_t* drop, float drop_scale, float eps, float* stats) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ double sh[8];
+  __shared__ float aff[2 * 8];
+  const int cpp = c / EPC;
+  const int img = blockIdx.x / cpp, cc = blockIdx.x % cpp;
+  const int64_t p0 = (int64_t)img * hw;
+  float s[EPC], q[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s[e] = q[e] = 0.f;
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    float v[EPC];
+    load_vec<T, EPC>(x, (p0 + i) * c + cc * EPC, v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s[e] += v[e]; q[e] = fmaf(v[e], v[e], q[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    double a = s[e], b = q[e];
+    block_sum2(a, b, sh);
+    if (threadIdx.x == 0) {
+      const double m = a / hw;
+      double var = b / hw - m * m;
+      if (var < 0.0) var = 0.0;
+      const float inv = 1.0f / sqrtf((float)var + eps);
+      aff[e] = (float)m; aff[8 + e] = inv;
+      stats[((int64_t)img * c + cc * EPC + e) * 2] = (float)m;
+      stats[((int64_t)img * c + cc * EPC + e) * 2 + 1] = inv;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    float v[EPC];
+    load_vec<T, EPC>(x, (p0 + i) * c + cc * EPC, v);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float t = (v[e] - aff[e]) * aff[8 + e];
+      if (act == GI_ACT_RELU) t = t > 0.f ? t : 0.f;
+      else if (act == GI_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
+      v[e] = t;
+    }
+    if (drop) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = drop[(p0 + i) * c + cc * EPC + e] ? v[e] * drop_scale : 0.f;
+    }
+    store_vec<T, EPC>(y, (p0 + i) * ldy + coffy + cc * EPC, v);
+  }
+}
+
+// backward through [dropout] -> activation -> InstanceNorm: dz as in act_bn_bwd (the masks come from the saved output y),
+//   dx = inv * (dz - mean_p dz - xhat * mean_p (dz * xhat)),  the means over the pixels of ONE (image, channel)
+template <typename T>
+__global__ void __launch_bounds__(256) act_in_bwd_kernel(BwdP p, int hw, const float* stats) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ double sh[8];
+  __shared__ float red[2 * 8];
+  const int cpp = p.c / EPC;
+  const int img = blockIdx.x / cpp, cc = blockIdx.x % cpp;
+  const int64_t p0 = (int64_t)img * hw;
+  float mu[EPC], iv[EPC], s[EPC], sx[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    mu[e] = stats[((int64_t)img * p.c + cc * EPC + e) * 2];
+    iv[e] = stats[((int64_t)img * p.c + cc * EPC + e) * 2 + 1];
+    s[e] = sx[e] = 0.f;
+  }
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    float dz[EPC], xv[EPC];
+    compute_dz<T, EPC>(p, p0 + i, cc * EPC, dz);
+    load_vec<T, EPC>(p.x, (p0 + i) * p.c + cc * EPC, xv);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { s[e] += dz[e]; sx[e] = fmaf(dz[e], (xv[e] - mu[e]) * iv[e], sx[e]); }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    double a = s[e], b = sx[e];
+    block_sum2(a, b, sh);
+    if (threadIdx.x == 0) { red[e] = (float)(a / hw); red[8 + e] = (float)(b / hw); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < hw; i += 256) {
+    float dz[EPC], xv[EPC];
+    compute_dz<T, EPC>(p, p0 + i, cc * EPC, dz);
+    load_vec<T, EPC>(p.x, (p0 + i) * p.c + cc * EPC, xv);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) dz[e] = iv[e] * (dz[e] - red[e] - (xv[e] - mu[e]) * iv[e] * red[8 + e]);
+    store_vec<T, EPC>(p.dx, (p0 + i) * p.c + cc * EPC, dz);
+  }
+}
+
+// bias gradient of a convolution: dbias[ch] += scale * sum over the partial rows of column sums (col_stats_kernel)
+__global__ void __launch_bounds__(256) bias_grad_kernel(const float* partials, int rows, int c, float scale, float* dbias) {
+  __shared__ double sh[8];
+  const int ch = blockIdx.x;
+  double s = 0.0, dummy = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) s += (double)partials[((int64_t)r * 2) * c + ch];
+  block_sum2(s, dummy, sh);
+  if (threadIdx.x == 0) dbias[ch] += (float)(s * scale);
 }
 
 // ---- gradient-penalty helpers (WGAN-GP extension) ------------------------------------
@@ -1136,6 +1244,42 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
     if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 0, false>), dim3(grid2), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 0, false>), dim3(grid2), dim3(256), 0, st, p);
   }
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_in_forward(hipStream_t st, int dtype, const void* x, void* y, int n, int hw, int c, int ldy, int coffy, int act,
+                  const uint8_t* drop_mask, float drop_scale, float eps, float* stats) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  GI_REQUIRE(c % epc == 0 && n >= 1 && hw >= 1, "in_forward: n=%d hw=%d c=%d", n, hw, c);
+  const dim3 grid((unsigned)n * (c / epc));
+  if (dtype == GI_F16) hipLaunchKernelGGL(in_forward_kernel<half_t>, grid, dim3(256), 0, st, (const char*)x, (char*)y, hw, c, ldy, coffy, act, drop_mask, drop_scale, eps, stats);
+  else hipLaunchKernelGGL(in_forward_kernel<float>, grid, dim3(256), 0, st, (const char*)x, (char*)y, hw, c, ldy, coffy, act, drop_mask, drop_scale, eps, stats);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_act_in_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a, int n, int hw, const float* stats) {
+  const int epc = dtype == GI_F16 ? 8 : 4;
+  GI_REQUIRE(a.c % epc == 0 && (int64_t)n * hw == a.pixels && a.x && stats, "act_in_bwd: n=%d hw=%d pixels=%lld c=%d", n, hw, (long long)a.pixels, a.c);
+  BwdP p;
+  memset(&p, 0, sizeof(p));
+  p.g1 = (const char*)a.g1; p.ldg1 = a.ldg1; p.coffg1 = a.coffg1;
+  p.g2 = (const char*)a.g2; p.ldg2 = a.ldg2; p.coffg2 = a.coffg2;
+  p.y = (const char*)a.y; p.ldy = a.ldy; p.coffy = a.coffy;
+  p.x = (const char*)a.x; p.dx = (char*)a.dx;
+  p.pixels = a.pixels; p.c = a.c; p.act = a.act; p.drop_scale = a.drop_scale;
+  const dim3 grid((unsigned)n * (a.c / epc));
+  if (dtype == GI_F16) hipLaunchKernelGGL(act_in_bwd_kernel<half_t>, grid, dim3(256), 0, st, p, hw, stats);
+  else hipLaunchKernelGGL(act_in_bwd_kernel<float>, grid, dim3(256), 0, st, p, hw, stats);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
+int op_bias_grad(hipStream_t st, int dtype, const void* dz, int64_t pixels, int c, float scale, float* dbias, float* partials) {
+  int rows = 0;
+  GI_TRY(op_col_stats(st, dtype, dz, pixels, c, partials, &rows));
+  hipLaunchKernelGGL(bias_grad_kernel, dim3(c), dim3(256), 0, st, partials, rows, c, scale, dbias);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

@@ -37,6 +37,7 @@ struct BN {
   // two for the forward statistics and two for the backward reductions. Each use takes the block its parity bit names
   // and its consuming pass clears the other one for the next use (ping-pong): no memset launches.
   int64_t acc_off = -1;
+  int64_t in_off = -1;    // InstanceNorm generator: per-slot [n][c][2] mean / inv of the last forward
   mutable int fwd_par = 0, bwd_par = 0;
   mutable int dirty[4] = {0, 0, 0, 0};   // replicas a use has added to in block {fwd 0, fwd 1, bwd 0, bwd 1}, not yet cleared
   int64_t acc_block() const { return gi_stat_block_words(c, GI_STAT_MAXREP); }
@@ -99,6 +100,10 @@ struct gi_net {
   int inference = 0;                 // gi_net_set_inference: eval-mode forwards will never be differentiated
   std::vector<int> slot_inference;
   std::vector<std::vector<uint64_t>> eval_gen;   // [slot][BN id]: generation the slot's scale / shift were computed at
+  // generator norm layer (get_norm_layer, networks.py:29-45): 0 BatchNorm2d, 1 InstanceNorm2d(affine=False,
+  // track_running_stats=False) - every convolution then carries a bias (use_bias, networks.py:270-273) -, 2 none (Identity)
+  int norm_kind = 0;
+  int64_t oInStats = -1;
   int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
   std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
@@ -161,9 +166,10 @@ int64_t part_rows(int64_t pixels) { return max64(pixels / 64 + 8, 1100); }
 // =================================================================================================
 // creation
 // =================================================================================================
-extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float dropout_p, int H, int W, int max_n,
-                                 int dtype, int n_slots, gi_net** out) {
+extern "C" int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_c, int norm_kind, float dropout_p, int H, int W,
+                                   int max_n, int dtype, int n_slots, gi_net** out) {
   GI_REQUIRE(out, "unet_create: null argument");  // ctx may be null: inventory-only handle
+  GI_REQUIRE(norm_kind >= 0 && norm_kind <= 2, "unet_create: norm_kind=%d (0 batch, 1 instance, 2 none)", norm_kind);
   GI_REQUIRE(dtype == GI_F16 || dtype == GI_F32, "unet_create: dtype=%d", dtype);
   GI_REQUIRE(num_downs >= 5 && num_downs <= 9, "unet_create: num_downs=%d (supported 5..9)", num_downs);
   if (ctx) GI_REQUIRE(ngf % 64 == 0 && ngf >= 64, "unet_create: ngf=%d must be a multiple of 64", ngf);
@@ -174,7 +180,7 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   GI_REQUIRE(max_n >= 1 && n_slots >= 1 && n_slots <= 8, "unet_create: max_n=%d n_slots=%d", max_n, n_slots);
   gi_net* net = new gi_net();
   net->ctx = ctx; net->kind = 0; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
-  net->nd = num_downs; net->ngf = ngf; net->dropout_p = dropout_p; net->out_c = out_c;
+  net->nd = num_downs; net->ngf = ngf; net->dropout_p = dropout_p; net->out_c = out_c; net->norm_kind = norm_kind;
   net->loss_scale = dtype == GI_F16 ? 65536.f : 1.f;
   const int nd = num_downs;
   net->ch.assign(nd + 1, 0); net->Hk.assign(nd + 1, 0); net->Wk.assign(nd + 1, 0);
@@ -200,8 +206,13 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
       const std::string upn = p + ((outer || inner) ? ".3" : ".5");
       Conv& cv = net->conv[k];
       cv.ca = net->ch[k]; cv.cb = outer ? 1 : net->ch[k - 1];
+      const bool inorm = net->norm_kind == 1;
       add_tensor(net, down + ".weight", 0, {cv.ca, cv.cb, 4, 4}, &cv.w_off);
-      if (!outer && !inner) add_bn(net, p + ".2", net->dnorm[k], net->ch[k], bns);
+      if (inorm) add_tensor(net, down + ".bias", 1, {cv.ca}, &cv.bias_off);
+      if (!outer && !inner) {
+        if (net->norm_kind == 0) add_bn(net, p + ".2", net->dnorm[k], net->ch[k], bns);
+        else net->dnorm[k].c = net->ch[k];     // parameter-free (or absent) norm: only the channel count
+      }
       if (!inner) {
         prefix[k + 1] = p + (outer ? ".1" : ".3") + ".model";
         run(k + 1);
@@ -210,8 +221,11 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
       uv.ca = inner ? net->ch[k] : 2 * net->ch[k];
       uv.cb = outer ? net->out_c : net->ch[k - 1];
       add_tensor(net, upn + ".weight", 0, {uv.ca, uv.cb, 4, 4}, &uv.w_off);
-      if (outer) add_tensor(net, upn + ".bias", 1, {net->out_c}, &uv.bias_off);
-      if (!outer) add_bn(net, p + (inner ? ".4" : ".6"), net->unorm[k], net->ch[k - 1], bns);
+      if (outer || inorm) add_tensor(net, upn + ".bias", 1, {uv.cb}, &uv.bias_off);
+      if (!outer) {
+        if (net->norm_kind == 0) add_bn(net, p + (inner ? ".4" : ".6"), net->unorm[k], net->ch[k - 1], bns);
+        else net->unorm[k].c = net->ch[k - 1];
+      }
     }
   } emit{net, nd, prefix, bns};
   emit.run(1);
@@ -291,11 +305,18 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
     for (BN* b : {&net->dnorm[k], &net->unorm[k]})
       if (b->c) { b->stat_off = stat_floats; stat_floats += 4 * b->c; b->id = nbn++; }
   net->oStats = S.take(stat_floats * 4);
+  if (norm_kind == 1) {
+    int64_t in_floats = 0;
+    for (int k = 1; k <= nd; ++k)
+      for (BN* b : {&net->dnorm[k], &net->unorm[k]})
+        if (b->c) { b->in_off = in_floats; in_floats += 2 * N * b->c; }
+    net->oInStats = S.take(in_floats * 4);
+  }
   net->slot_bytes = S.size;
   net->slot_base = A.take(S.size * n_slots);
   for (int k = 1; k <= nd; ++k)
     for (BN* b : {&net->dnorm[k], &net->unorm[k]})
-      if (b->c) { b->acc_off = net->acc_words; net->acc_words += 4 * b->acc_block(); }
+      if (b->c && norm_kind == 0) { b->acc_off = net->acc_words; net->acc_words += 4 * b->acc_block(); }
   net->oAcc = A.take(net->acc_words * 8);
   { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
   net->slot_n.assign(n_slots, 0);
@@ -307,6 +328,11 @@ extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c,
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
   return GI_OK;
+}
+
+extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float dropout_p, int H, int W, int max_n,
+                                 int dtype, int n_slots, gi_net** out) {
+  return gi_unet_create_norm(ctx, num_downs, ngf, out_c, 0, dropout_p, H, W, max_n, dtype, n_slots, out);
 }
 
 extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, int W, int max_n, int dtype,
@@ -448,7 +474,8 @@ extern "C" int64_t gi_net_buffer_floats(gi_net* net) { return net ? net->n_buffe
 extern "C" int64_t gi_net_workspace_bytes(gi_net* net) { return net ? net->arena.size : GI_ERR_INVALID; }
 
 extern "C" int gi_net_bind(gi_net* net, float* params, float* grads, float* buffers, void* workspace, int64_t workspace_bytes) {
-  GI_REQUIRE(net && params && grads && buffers && workspace, "net_bind: null pointer");
+  GI_REQUIRE(net && params && grads && workspace, "net_bind: null pointer");
+  GI_REQUIRE(buffers || net->n_buffers == 0, "net_bind: null buffers for a net with %lld buffer floats", (long long)net->n_buffers);
   GI_REQUIRE(net->ctx != nullptr, "net_bind: handle was created without a context (inventory only)");
   GI_REQUIRE(workspace_bytes >= net->arena.size, "net_bind: workspace %lld < required %lld", (long long)workspace_bytes,
              (long long)net->arena.size);
@@ -869,9 +896,34 @@ int unet_forward_inference(gi_net* net, int s, const float* x, float* y, int n) 
   return GI_OK;
 }
 
+// generator with InstanceNorm2d / without norm layers: the normalisation step after a convolution (raw -> dst with
+// activation and dropout). InstanceNorm keeps (mean, inv) per image and channel in the slot for the backward.
+int plain_norm_forward(gi_net* net, int slot, const BN& b, const void* raw, int n, int hw, void* dst, int ldy, int coffy, int act,
+                       const uint8_t* drop, float drop_scale) {
+  hipStream_t st = net->ctx->stream;
+  if (net->norm_kind == 1)
+    return op_in_forward(st, net->dtype, raw, dst, n, hw, b.c, ldy, coffy, act, drop, drop_scale, 1e-5f,
+                         (float*)net->slot(slot, net->oInStats) + b.in_off);
+  return op_bn_apply(st, net->dtype, raw, dst, (int64_t)n * hw, b.c, ldy, coffy, nullptr, nullptr, act, drop, drop_scale);
+}
+
+const float* conv_bias(const gi_net* net, const Conv& c) { return c.bias_off >= 0 ? net->params + c.bias_off : nullptr; }
+
+// dbias += (1 / loss scale) * column sums of the convolution's output gradient (InstanceNorm generator: use_bias)
+int bias_grad(gi_net* net, const Conv& c, const void* dz, int64_t pixels, int ch) {
+  if (c.bias_off < 0) return GI_OK;
+  GI_REQUIRE((pixels / 32 + 8) * 2 * ch <= net->part_floats, "internal: partials buffer too small for a bias gradient");
+  return op_bias_grad(net->ctx->stream, net->dtype, dz, pixels, ch, 1.f / net->loss_scale, net->grads + c.bias_off,
+                      (float*)net->shared(net->oPart));
+}
+
+int unet_forward_plain(gi_net* net, int s, const float* x, float* y, int n);
+int unet_backward_plain(gi_net* net, int s, const float* dy, float* dx, int need_wgrad, int phase);
+
 int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   hipStream_t st = net->ctx->stream;
   const int nd = net->nd, dt = net->dtype, train = net->train;
+  if (net->norm_kind != 0) return unet_forward_plain(net, s, x, y, n);
   if (!train && net->inference && nd >= 3) return unet_forward_inference(net, s, x, y, n);
   net->slot_inference[s] = 0;
   if (train) ++net->affine_gen;   // running statistics change below
@@ -967,6 +1019,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
 // of the flat gradient buffer and are complete when this returns); 2 = encoder half (d_nd .. d1).
 // Splitting lets the host start the decoder gradients' all-reduce while the encoder half runs.
 int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad, int phase) {
+  if (net->norm_kind != 0) return unet_backward_plain(net, s, dy, dx, need_wgrad, phase);
   hipStream_t st = net->ctx->stream;
   const int nd = net->nd, dt = net->dtype;
   const int H = net->H, W = net->W, n = net->slot_n[s];
@@ -1071,6 +1124,175 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
                          0, 0, iLS, 1.f));
     if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS,
                                  net->shared(net->oCol)));
+  }
+  return GI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generator built with get_norm_layer('instance') or ('none') (networks.py:29-45, 270-318). Same skeleton as above on
+// the unfused building blocks: convolution (+ bias) -> raw tensor -> normalisation pass (InstanceNorm statistics per
+// image, or identity) with the activation and dropout. InstanceNorm has no running statistics: train and eval differ
+// only by dropout. A bias in front of an InstanceNorm cancels in the forward and has a zero gradient up to rounding; it
+// is still applied and differentiated like the reference does.
+int unet_forward_plain(gi_net* net, int s, const float* x, float* y, int n) {
+  hipStream_t st = net->ctx->stream;
+  const int nd = net->nd, dt = net->dtype, train = net->train;
+  const int H = net->H, W = net->W;
+  net->slot_inference[s] = 0;
+  net->slot_n[s] = n;
+  net->slot_train[s] = train;
+  net->slot_fused_u2[s] = 0;
+  auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
+  GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
+  GI_TRY(op_c1_gather(st, dt, x, net->params + net->conv[1].w_off, C(1), n, net->Hk[1], net->Wk[1], net->ch[1], 2 * net->ch[1], 0,
+                      GI_ACT_LRELU, 1.f, conv_bias(net, net->conv[1])));
+  for (int k = 2; k <= nd; ++k) {
+    if (k < nd) {
+      void* R = net->slot(s, net->oR[k]);
+      GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), R, net->ch[k], net->ch[k], 0, n,
+                   net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, false, nullptr, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, conv_bias(net, net->conv[k])));
+      GI_TRY(plain_norm_forward(net, s, net->dnorm[k], R, n, net->Hk[k] * net->Wk[k], C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f));
+    } else {
+      GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), net->slot(s, net->oE), net->ch[k],
+                   net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_RELU, false, nullptr, 0, nullptr, 0, 0.f, nullptr, nullptr, 0,
+                   conv_bias(net, net->conv[k])));
+    }
+  }
+  for (int k = nd; k >= 2; --k) {
+    const void* in = (k == nd) ? (const void*)net->slot(s, net->oE) : C(k);
+    const int cin = net->up[k].ca, co = net->ch[k - 1];
+    const int64_t opix = (int64_t)n * net->Hk[k - 1] * net->Wk[k - 1];
+    void* U = net->slot(s, net->oU[k]);
+    const uint8_t* drop = nullptr;
+    if (train && net->dropout_p > 0.f && k >= 5 && k <= nd - 1) {
+      uint8_t* m = (uint8_t*)net->slot(s, net->oMask[k]);
+      if (net->ext_mask[s][k]) GI_TRY(op_mask_nchw_to_nhwc(st, net->ext_mask[s][k], m, n, co, net->Hk[k - 1] * net->Wk[k - 1], 1));
+      else GI_TRY(op_fill_dropout(st, m, opix * co, net->drop_seed + 0x1000003ull * (++net->drop_counter), net->dropout_p));
+      drop = m;
+    }
+    GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0, GI_ACT_NONE,
+                 false, nullptr, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, conv_bias(net, net->up[k])));
+    GI_TRY(plain_norm_forward(net, s, net->unorm[k], U, n, net->Hk[k - 1] * net->Wk[k - 1], C(k - 1), 2 * co, co, GI_ACT_RELU, drop,
+                              drop ? 1.f / (1.f - net->dropout_p) : 1.f));
+  }
+  float* osave = (float*)net->slot(s, net->oOut);
+  if (net->out_c == 1)
+    return op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1], net->Wk[1],
+                         2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y);
+  void* U1 = net->shared(net->oU1);
+  const int c1 = 2 * net->ch[1];
+  GI_TRY(igemm(net, 1, C(1), c1, c1, 0, net->shared(net->oUp1Phase), U1, 64, 64, 0, n, net->Hk[1], net->Wk[1], 1, GI_ACT_NONE, false, nullptr,
+               net->ch[1]));
+  const int64_t total = (int64_t)n * net->out_c * H * W;
+  if (dt == GI_F16)
+    hipLaunchKernelGGL(head_tanh_kernel<half_t>, dim3(grid1d(total)), dim3(256), 0, st, (const half_t*)U1, net->params + net->up[1].bias_off, osave,
+                       n, net->out_c, H * W);
+  else
+    hipLaunchKernelGGL(head_tanh_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, (const float*)U1, net->params + net->up[1].bias_off, osave, n,
+                       net->out_c, H * W);
+  GI_LAUNCH_CHECK();
+  GI_HIP(hipMemcpyAsync(y, osave, (size_t)n * net->out_c * H * W * 4, hipMemcpyDeviceToDevice, st));
+  return GI_OK;
+}
+
+// backward of one normalisation step of the plain generator: dz of [dropout] -> activation, then through InstanceNorm
+int plain_norm_backward(gi_net* net, int s, const BN& b, const void* g1, int ldg1, const void* g2, int ldg2, int coffg2, const void* y, int ldy,
+                        int coffy, const void* x, void* dx, int n, int hw, int act, float drop_scale) {
+  if (net->norm_kind != 1)
+    return act_bn_bwd(net, s, g1, ldg1, 0, g2, ldg2, coffg2, y, ldy, coffy, nullptr, dx, (int64_t)n * hw, b.c, act, drop_scale, nullptr, 0);
+  ActBnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.g1 = g1; a.ldg1 = ldg1; a.g2 = g2; a.ldg2 = ldg2; a.coffg2 = coffg2;
+  a.y = y; a.ldy = ldy; a.coffy = coffy; a.x = x; a.dx = dx;
+  a.pixels = (int64_t)n * hw; a.c = b.c; a.act = act; a.drop_scale = drop_scale;
+  return op_act_in_bwd(net->ctx->stream, net->dtype, a, n, hw, (const float*)net->slot(s, net->oInStats) + b.in_off);
+}
+
+int unet_backward_plain(gi_net* net, int s, const float* dy, float* dx, int need_wgrad, int phase) {
+  hipStream_t st = net->ctx->stream;
+  const int nd = net->nd, dt = net->dtype;
+  const int H = net->H, W = net->W, n = net->slot_n[s];
+  GI_REQUIRE(n > 0, "unet_backward: slot %d holds no forward", s);
+  GI_REQUIRE(net->out_c == 1 || !need_wgrad, "unet_backward: parameter gradients of a %d-channel generator are not built", net->out_c);
+  net->bwd_eval = 0;
+  const float LS = net->loss_scale, iLS = 1.f / LS;
+  auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
+  auto gC = [&](int k) { return (void*)net->shared(net->ogC[k]); };
+  auto gA = [&](int k) { return (void*)net->shared(net->ogA[k]); };
+  void* D = net->shared(net->oD);
+  float* G0 = (float*)net->shared(net->oG0);
+  const int64_t npx = (int64_t)n * H * W;
+  const bool dropped = net->slot_train[s] && net->dropout_p > 0.f;
+  if (phase == 0 || phase == 1) {
+    GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx * net->out_c, LS));
+    const int c1 = 2 * net->ch[1];
+    if (need_wgrad) {
+      hipLaunchKernelGGL(sum_acc_kernel, dim3(256), dim3(256), 0, st, G0, npx, net->grads + net->up[1].bias_off, iLS);
+      GI_LAUNCH_CHECK();
+      GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, nullptr));
+    }
+    if (net->out_c == 1) {
+      GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
+    } else {
+      void* U1 = net->shared(net->oU1);
+      if (dt == GI_F16) hipLaunchKernelGGL(pad_dy_kernel<half_t>, dim3(grid1d(npx * 64)), dim3(256), 0, st, G0, (half_t*)U1, n, net->out_c, H * W);
+      else hipLaunchKernelGGL(pad_dy_kernel<float>, dim3(grid1d(npx * 64)), dim3(256), 0, st, G0, (float*)U1, n, net->out_c, H * W);
+      GI_LAUNCH_CHECK();
+      const void* wp = net->oUp1Packed >= 0 ? (const void*)net->shared(net->oUp1Packed) : (const void*)net->shared(net->oUp1Pad);
+      GI_TRY(igemm(net, 0, U1, 64, 64, 0, wp, gC(1), c1, c1, 0, n, net->Hk[1], net->Wk[1], 0, GI_ACT_NONE, false, nullptr));
+    }
+    for (int k = 1; k <= nd - 1; ++k) {
+      const int kk = k + 1, ck = net->ch[k];
+      const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
+      const float ds = (dropped && kk >= 5 && kk <= nd - 1) ? 1.f / (1.f - net->dropout_p) : 1.f;
+      GI_TRY(plain_norm_backward(net, s, net->unorm[kk], nullptr, 0, gC(k), 2 * ck, ck, C(k), 2 * ck, ck, net->slot(s, net->oU[kk]), D, n,
+                                 net->Hk[k] * net->Wk[k], GI_ACT_NONE, ds));
+      const void* Sin = (kk == nd) ? (const void*)net->slot(s, net->oE) : C(kk);
+      const int ca = net->up[kk].ca;
+      if (need_wgrad) {
+        GI_TRY(bias_grad(net, net->up[kk], D, pix, ck));
+        GI_TRY(wgrad(net, Sin, ca, ca, 0, kk < nd ? 1 : 0, D, ck, ck, 0, n, net->Hk[kk], net->Wk[kk], net->grads + net->up[kk].w_off));
+      }
+      void* gout = (kk == nd) ? (void*)net->shared(net->ogE) : gC(kk);
+      GI_TRY(igemm(net, 0, D, ck, ck, 0, packed_ptr(net, net->up[kk]), gout, ca, ca, 0, n, net->Hk[kk], net->Wk[kk], 0, GI_ACT_NONE, false, nullptr));
+    }
+  }
+  if (phase == 1) return GI_OK;
+  const bool run_inner = phase != 4, run_outer = phase != 3;
+  if (run_inner) {
+    const int c = net->ch[nd];
+    const int64_t pix = (int64_t)n * net->Hk[nd] * net->Wk[nd];
+    GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, net->shared(net->ogE), c, 0, net->slot(s, net->oE), c, 0, nullptr, D, pix, c, GI_ACT_NONE, 1.f,
+                      nullptr, need_wgrad));
+    const int cb = net->ch[nd - 1];
+    if (need_wgrad) {
+      GI_TRY(bias_grad(net, net->conv[nd], D, pix, c));
+      GI_TRY(wgrad(net, D, c, c, 0, 0, C(nd - 1), cb, 2 * cb, 0, n, net->Hk[nd], net->Wk[nd], net->grads + net->conv[nd].w_off));
+    }
+    GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[nd]), gA(nd - 1), cb, cb, 0, n, net->Hk[nd], net->Wk[nd], 0, GI_ACT_NONE, false, nullptr));
+  }
+  for (int k = nd - 1; k >= 2; --k) {
+    if (k >= 5 ? !run_inner : !run_outer) continue;
+    const int c = net->ch[k];
+    const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
+    GI_TRY(plain_norm_backward(net, s, net->dnorm[k], gA(k), c, gC(k), 2 * c, 0, C(k), 2 * c, 0, net->slot(s, net->oR[k]), D, n, net->Hk[k] * net->Wk[k],
+                               GI_ACT_LRELU, 1.f));
+    const int cb = net->ch[k - 1];
+    if (need_wgrad) {
+      GI_TRY(bias_grad(net, net->conv[k], D, pix, c));
+      GI_TRY(wgrad(net, D, c, c, 0, 0, C(k - 1), cb, 2 * cb, 0, n, net->Hk[k], net->Wk[k], net->grads + net->conv[k].w_off));
+    }
+    GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[k]), gA(k - 1), cb, cb, 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, false, nullptr));
+  }
+  if (run_outer) {
+    const int c = net->ch[1];
+    const int64_t pix = (int64_t)n * net->Hk[1] * net->Wk[1];
+    GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
+    if (need_wgrad) {
+      GI_TRY(bias_grad(net, net->conv[1], D, pix, c));
+      GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c, 0, 0, iLS, 1.f));
+    }
+    if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS, net->shared(net->oCol)));
   }
   return GI_OK;
 }

@@ -36,8 +36,7 @@ class Identity(nn.Module):
 
 
 def get_norm_layer(norm_type="instance"):
-    """networks.py:30-45. Only 'batch' is executed by the HIP backend (it is the only one
-    get_network ever builds, networks.py:18)."""
+    """networks.py:30-45. get_network only ever builds 'batch' (networks.py:18); UnetGenerator accepts all three."""
     if norm_type == "batch":
         return functools.partial(nn.BatchNorm2d, affine=True, track_running_stats=True)
     if norm_type == "instance":
@@ -358,6 +357,28 @@ def _init_conv(cout, cin, transposed=False, bias=False):
     return m.weight.detach(), (m.bias.detach() if bias else None)
 
 
+def _norm_kind(norm_layer):
+    """0 BatchNorm2d, 1 InstanceNorm2d (parameter-free, instance statistics in train and eval), 2 no norm: the three
+    results of get_norm_layer (networks.py:29-45). use_bias follows the reference's test `func == nn.InstanceNorm2d`."""
+    fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
+    kw = norm_layer.keywords if isinstance(norm_layer, functools.partial) else {}
+    if fn is nn.BatchNorm2d:
+        if not kw.get("affine", True) or not kw.get("track_running_stats", True):
+            raise NotImplementedError("HIP backend: BatchNorm2d generators are built with affine=True, track_running_stats=True")
+        return 0
+    if fn is nn.InstanceNorm2d:
+        if kw.get("affine", False) or kw.get("track_running_stats", False):
+            raise NotImplementedError("HIP backend: InstanceNorm2d generators are built with affine=False, track_running_stats=False")
+        return 1
+    try:
+        probe = norm_layer(8)
+    except Exception as e:      # noqa: BLE001
+        raise NotImplementedError(f"HIP backend: norm_layer {norm_layer!r} is not one of get_norm_layer's results") from e
+    if isinstance(probe, (Identity, nn.Identity)):
+        return 2
+    raise NotImplementedError(f"HIP backend: norm_layer {norm_layer!r} is not one of get_norm_layer's results")
+
+
 class UnetGenerator(HipNet):
     """networks.py:216-253 (+ UnetSkipConnectionBlock :255-324). input_nc = 1; output_nc = 1 (the inpainting
     generator) or up to 64 (the frozen face-parsing network UnetGenerator(1,4,7,ngf=32), train.py:171-172:
@@ -375,9 +396,7 @@ class UnetGenerator(HipNet):
         if input_nc != 1 or not (1 <= output_nc <= 64):
             raise NotImplementedError("HIP backend: UnetGenerator takes 1-channel images and emits 1..64 channels")
         self.output_nc = output_nc
-        fn = norm_layer.func if isinstance(norm_layer, functools.partial) else norm_layer
-        if fn is not nn.BatchNorm2d:
-            raise NotImplementedError("HIP backend: only BatchNorm2d generators (the get_network default) are built")
+        self.norm_kind = _norm_kind(norm_layer)
         if use_sigmoid_output:
             raise NotImplementedError("use_sigmoid_output is never enabled by the reference (networks.py:250)")
         self.num_downs, self.ngf = num_downs, ngf
@@ -386,7 +405,8 @@ class UnetGenerator(HipNet):
         lib = B.lib()
         h = C.c_void_p()
         size0 = 1 << max(num_downs, 7)
-        B.check(lib.gi_unet_create_ex(None, num_downs, ngf, output_nc, self.dropout_p, size0, size0, 1, self._dtype, 1, C.byref(h)))
+        B.check(lib.gi_unet_create_norm(None, num_downs, ngf, output_nc, self.norm_kind, self.dropout_p, size0, size0, 1, self._dtype, 1,
+                                        C.byref(h)))
         self._build_tree(self._inventory(h), lib.gi_net_param_floats(h), lib.gi_net_buffer_floats(h))
         lib.gi_net_destroy(h)
         self.reset_parameters()
@@ -402,13 +422,18 @@ class UnetGenerator(HipNet):
 
     def reset_parameters(self):
         """Same RNG consumption order as the reference constructor: blocks are built innermost
-        first (networks.py:236-243), each drawing downconv then upconv(+bias) (:285-309);
-        BatchNorm draws nothing (weight 1, bias 0, running stats 0/1)."""
+        first (networks.py:236-243), each drawing downconv(+bias) then upconv(+bias) (:285-309; with InstanceNorm
+        every convolution has a bias, :270-273); norm layers draw nothing (BatchNorm: weight 1, bias 0, running
+        stats 0/1)."""
         with torch.no_grad():
             for down, up in reversed(self._level_names()):
                 a, b = self._tensor(down).shape[:2]
-                w, _ = _init_conv(a, b)                                   # Conv2d weight [out=a, in=b, 4, 4]
+                bias_name = down[:-len("weight")] + "bias"
+                has_bias = bias_name in self._tensor_refs
+                w, bias = _init_conv(a, b, bias=has_bias)                 # Conv2d weight [out=a, in=b, 4, 4]
                 self._tensor(down).copy_(w)
+                if has_bias:
+                    self._tensor(bias_name).copy_(bias)
                 a, b = self._tensor(up).shape[:2]
                 bias_name = up[:-len("weight")] + "bias"
                 has_bias = bias_name in self._tensor_refs
@@ -421,8 +446,8 @@ class UnetGenerator(HipNet):
 
     def _create_handle(self, ctx, H, W, max_n):
         h = C.c_void_p()
-        B.check(B.lib().gi_unet_create_ex(ctx, self.num_downs, self.ngf, self.output_nc, self.dropout_p, H, W, max_n, self._dtype,
-                                          self.n_slots, C.byref(h)))
+        B.check(B.lib().gi_unet_create_norm(ctx, self.num_downs, self.ngf, self.output_nc, self.norm_kind, self.dropout_p, H, W, max_n,
+                                            self._dtype, self.n_slots, C.byref(h)))
         if getattr(self, "_drop_seed", None) is not None:      # a seed chosen before the handle existed
             B.check(B.lib().gi_net_set_dropout_seed(h, self._drop_seed))
         return h
@@ -484,6 +509,8 @@ class EmbeddedUnetGenerator(nn.Module):
     def __init__(self, input_nc=1, output_nc=1, num_downs=7, ngf=32, norm_layer=nn.BatchNorm2d, use_dropout=False,
                  use_sigmoid_output=False, dtype=None):
         super().__init__()
+        if _norm_kind(norm_layer) != 0:
+            raise NotImplementedError("HIP backend: generators narrower than 64 channels are built with BatchNorm2d only")
         self.ngf, self.num_downs, self.output_nc = ngf, num_downs, output_nc
         self.ngf_phys = 64 * ((ngf + 63) // 64)
         lib = B.lib()

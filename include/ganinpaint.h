@@ -66,6 +66,13 @@ int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout_p, int H, 
  * bound handle; an inventory-only handle (ctx NULL) accepts multiples of 8 (Python embeds ngf=32 in 64). */
 int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float dropout_p, int H, int W,
                       int max_n, int dtype, int n_slots, gi_net** out);
+/* The same with the generator's norm layer chosen as get_norm_layer does (lib/models/networks.py:29-45):
+ * norm_kind 0 = BatchNorm2d(affine, running statistics) - gi_unet_create_ex -, 1 = InstanceNorm2d(affine=False,
+ * track_running_stats=False): statistics per image and channel in train AND eval mode, and every convolution carries a
+ * bias (use_bias, networks.py:270-273; inventory names "<conv>.bias"), 2 = none (Identity). Kinds 1 and 2 run on the
+ * unfused building blocks (no inference folding, no fused head). */
+int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_c, int norm_kind, float dropout_p, int H,
+                        int W, int max_n, int dtype, int n_slots, gi_net** out);
 /* PatchGANDiscriminator(c=1, sigmoid): Linear(25,1) generalised to ((H/16-3)*(W/16-3),1). */
 int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots,
                        gi_net** out);
