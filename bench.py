@@ -75,35 +75,53 @@ def dominant_kernel(iters):
     B.check(B.lib().gi_time_convT_s2(B.get_ctx(), B.GI_F16, B.ptr(x), B.ptr(phase), B.ptr(out), n, hs, ws, ca, ca, cb, cb, iters,
                                      C.byref(ms)))
     flop = 2.0 * 4 * (n * hs * ws) * cb * (4 * ca)
-    return dict(name="igemm5_kernel<128> fp16 halo-resident LDS-DMA implicit GEMM (ConvTranspose2d 512->128, 32x32->64x64, bs=32; generator u3)", ms=ms.value, flop=flop)
+    return dict(name="igemm6_kernel<1, 128, true> fp16 halo-resident LDS-DMA implicit GEMM (ConvTranspose2d 512->128 with the fused input ReLU, "
+                     "32x32->64x64, bs=32; generator u3)", ms=ms.value, flop=flop)
 
 
 def cpu_baseline():
-    """The oracle's WGAN schedule on the host cores: bs=8 at 256x256, one critic-only batch and one
-    batch with a generator update, combined 4:1 like the GPU cadence."""
+    """The oracle's WGAN schedule (oracle/torch_ref.wgan_step, fp32) on the host cores at the GPU workload's own batch,
+    bs=32 at 256x256: critic-only batches and one batch with a generator update, combined 4:1 like the GPU cadence. A bs=32
+    batch takes several seconds on the box's host cores, so the sample is 1 warm-up + 2 critic-only + 1 generator-update
+    batch (stated in `sample`); a second figure restricts torch to 8 threads (the reference's own
+    CPU-runnable setting) on bs=8."""
     import numpy as np
     from oracle import params as op
     from oracle import torch_ref as orc
-    n = 8
+
+    def run(n, warm, n_critic, n_gen):
+        PG = orc.to_torch(op.make_unet_params(1234))
+        PD = orc.to_torch(op.make_patchgan_params(4321, H, W))
+        oG, oD = orc.RMSprop(orc.trainable(PG)), orc.RMSprop(orc.trainable(PD))
+        ground, mask = op.synth_batch(0x5EED, n, H, W)
+        ground, mask = torch.from_numpy(ground), torch.from_numpy(mask)
+        rng = np.random.Generator(np.random.PCG64(1))
+        masks = {5: torch.from_numpy((rng.random((n, 512, 16, 16)) < 0.5).astype(np.uint8)),
+                 6: torch.from_numpy((rng.random((n, 512, 8, 8)) < 0.5).astype(np.uint8))}
+        for _ in range(warm):
+            orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, False, recon="rmse")
+        t = []
+        for upd, reps in ((False, n_critic), (True, n_gen)):
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, upd, recon="rmse")
+            t.append((time.perf_counter() - t0) / reps)
+        return n / (((G_EVERY - 1) * t[0] + t[1]) / G_EVERY), t
+
     threads = torch.get_num_threads()
-    PG = orc.to_torch(op.make_unet_params(1234))
-    PD = orc.to_torch(op.make_patchgan_params(4321, H, W))
-    oG, oD = orc.RMSprop(orc.trainable(PG)), orc.RMSprop(orc.trainable(PD))
-    ground, mask = op.synth_batch(0x5EED, n, H, W)
-    ground, mask = torch.from_numpy(ground), torch.from_numpy(mask)
-    rng = np.random.Generator(np.random.PCG64(1))
-    masks = {5: torch.from_numpy((rng.random((n, 512, 16, 16)) < 0.5).astype(np.uint8)),
-             6: torch.from_numpy((rng.random((n, 512, 8, 8)) < 0.5).astype(np.uint8))}
-    orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, True, recon="rmse")   # warm-up
-    t = []
-    for upd in (False, True):
-        t0 = time.perf_counter()
-        orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, upd, recon="rmse")
-        t.append(time.perf_counter() - t0)
-    per_batch = ((G_EVERY - 1) * t[0] + t[1]) / G_EVERY
-    return dict(value=n / per_batch, unit="images/sec", cores=threads, kind="port",
-                sample=f"oracle/torch_ref.wgan_step fp32, bs={n} at {H}x{W}: 1 warm-up + 1 critic-only batch ({t[0]:.2f} s) "
-                       f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1")
+    v, t = run(BS, 1, 2, 1)
+    out = dict(value=v, unit="images/sec", cores=threads, kind="port",
+               sample=f"oracle/torch_ref.wgan_step fp32, bs={BS} at {H}x{W}: 1 warm-up + 2 critic-only batches ({t[0]:.2f} s each) "
+                      f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1 (reduced from 10 + 3 batches to keep the default run short)")
+    if threads > 8:
+        torch.set_num_threads(8)
+        try:
+            v8, t8 = run(8, 0, 1, 1)
+            out["threads8"] = dict(value=v8, unit="images/sec", cores=8,
+                                   sample=f"same, torch.set_num_threads(8), bs=8: 1 critic-only batch ({t8[0]:.2f} s) + 1 batch with G update ({t8[1]:.2f} s)")
+        finally:
+            torch.set_num_threads(threads)
+    return out
 
 
 def ssim_workload(args, dev):
@@ -368,11 +386,14 @@ def main():
 
     k = dominant_kernel(args.kernel_iters)
     achieved = k["flop"] / (k["ms"] * 1e-3) / 1e12
-    traffic = None
+    traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tp))
+            traffic = tj.get("hbm_bytes_per_launch")
+            # the PMC passes are separate rocprofv3 runs (tools/pmc_dominant.sh): say which round's file this number is
+            traffic_src = f"profiles/dominant_kernel_traffic.json (round {tj.get('round')}, kernel {tj.get('kernel')}, commit {tj.get('commit')})"
         except Exception:
             traffic = None
     # algorithmic FLOP of one batch: D-only = F_G + 6 F_D ; with G update + 2 F_G + 2 F_D
@@ -401,7 +422,8 @@ def main():
         "step_algorithmic_tflops": flop_batch / (dt / args.steps) / 1e12,
         "losses": losses,
         "roofline": {"bound": "mfma", "kernel": k["name"], "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F16_TFLOPS, "avg_launch_ms": k["ms"], "flop_per_launch": k["flop"], "traffic": traffic},
+                     "frac": achieved / PEAK_F16_TFLOPS, "avg_launch_ms": k["ms"], "flop_per_launch": k["flop"], "traffic": traffic,
+                     "traffic_source": traffic_src},
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

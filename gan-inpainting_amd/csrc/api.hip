@@ -38,6 +38,7 @@ int gi_ctx_create(int device_id, void* hip_stream, gi_ctx** out) {
   return GI_OK;
 }
 int gi_ctx_destroy(gi_ctx* ctx) {
+  if (ctx && ctx->tickets) (void)hipFree(ctx->tickets);
   delete ctx;
   return GI_OK;
 }
@@ -47,6 +48,14 @@ int gi_ctx_sync(gi_ctx* ctx) {
   return GI_OK;
 }
 
+static unsigned* ctx_tickets(gi_ctx* ctx) {
+  if (!ctx->tickets) {
+    if (hipMalloc((void**)&ctx->tickets, GI_IGEMM_TICKETS * 4) != hipSuccess) { ctx->tickets = nullptr; return nullptr; }
+    if (hipMemset(ctx->tickets, 0, GI_IGEMM_TICKETS * 4) != hipSuccess) { (void)hipFree(ctx->tickets); ctx->tickets = nullptr; }
+  }
+  return ctx->tickets;
+}
+
 int gi_conv_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out, int n, int H, int W, int cb, int ldin,
                        int ca, int ldout, int relu_in, int act_out, float* ws, int64_t ws_bytes) {
   GI_REQUIRE(ctx && in && w_packed && out, "conv_s2_forward: null pointer");
@@ -54,6 +63,7 @@ int gi_conv_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_pac
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in; a.w = w_packed; a.out = out; a.ws = ws; a.ws_bytes = ws_bytes;
+  a.tickets = ws ? ctx_tickets(ctx) : nullptr;
   a.n = n; a.Hs = H / 2; a.Ws = W / 2;
   a.cin = cb; a.ldin = ldin; a.cout = ca; a.ldout = ldout;
   a.relu_in = relu_in; a.act_out = act_out;
@@ -66,6 +76,7 @@ int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_ph
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.in = in; a.w = w_phase; a.out = out; a.ws = ws; a.ws_bytes = ws_bytes;
+  a.tickets = ws ? ctx_tickets(ctx) : nullptr;
   a.n = n; a.Hs = H; a.Ws = W;
   a.cin = ca; a.ldin = ldin; a.cout = cb; a.ldout = ldout;
   a.relu_in = relu_in; a.act_out = act_out;

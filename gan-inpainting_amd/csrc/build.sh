@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libganinpaint.so
-SRCS="api.hip igemm.hip igemm3.hip igemm5.hip wgrad.hip wgrad2.hip c1.hip elementwise.hip ssim.hip evalmetrics.hip auxloss.hip vgg.hip resize.hip comm.hip net.hip"
+SRCS="api.hip igemm.hip igemm3.hip igemm5.hip igemm7.hip wgrad.hip wgrad2.hip c1.hip elementwise.hip ssim.hip evalmetrics.hip auxloss.hip vgg.hip resize.hip comm.hip net.hip"
 OBJS=""
 mkdir -p build
 pids=""

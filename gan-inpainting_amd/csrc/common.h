@@ -64,6 +64,7 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
 struct gi_ctx {
   int device;
   hipStream_t stream;
+  unsigned* tickets = nullptr;   // IgemmArgs::tickets for the single-layer entry points (allocated on first use)
 };
 
 static inline size_t gi_dtype_size(int dtype) { return dtype == GI_F16 ? 2 : 4; }
@@ -98,6 +99,8 @@ struct IgemmArgs {
                        // idempotent, kernels may apply it to more channels)
   int act_out;         // gi_act on the result
   int force_splitk;    // 0 = heuristic, >0 forces that split
+  unsigned* tickets;   // GI_IGEMM_TICKETS counters, zero before the first launch (every launch leaves them zero), or null:
+                       // split-K layers then reduce inside the GEMM kernel (last arriver per tile) instead of a finish launch
   int ntiles_out;      // (returned) number of partial rows written
   // optional fused activation backward on the result (input-gradient GEMMs): out *= (mask > 0 ? 1 : mask_slope), with
   // mask the forward activation of the producing layer, laid out like out (pixels x channels, ld = ldmask). Kernels
@@ -114,6 +117,7 @@ struct IgemmArgs {
   int stat_used;   // (returned) 1: the statistics went to stat_acc; 0: to `partials` (split-K layers: their finish pass
                    // has few rows per block, the partial rows + finalize launch are cheaper there than 4 atomics per channel)
 };
+constexpr int GI_IGEMM_TICKETS = 1024;
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
 
 struct WgradArgs {

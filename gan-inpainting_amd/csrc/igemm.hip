@@ -13,7 +13,11 @@
 // fp16: v_mfma_f32_16x16x32_f16, fp32: v_mfma_f32_32x32x2_f32 (exact fp32), fp32 accumulate.
 // Epilogue: optional bias + activation, per-tile column sum / sum-of-squares (BatchNorm batch
 // statistics, deterministic: no atomics), result staged through LDS and stored with 16-byte
-// coalesced rows. Small-M layers use split-K with fp32 atomics into a scratch + a finish kernel.
+// coalesced rows.
+// Small-M layers split the reduction (split-K): every split stores its fp32 tile in the thread-linear register layout
+// (16 bytes per lane, coalesced) and takes a ticket; the LAST arriver of a tile adds the splits up in split order (a
+// fixed order: results do not depend on which workgroup happens to be last) and runs the normal epilogue - no finish
+// launch, statistics straight from the final values. Without a ticket buffer: per-split buffers + splitk_finish_kernel.
 #include <stdlib.h>
 
 #include "common.h"
@@ -29,6 +33,7 @@ struct KP {
   float* partials;
   unsigned long long* stat_acc; int stat_pg, stat_reps;   // IgemmArgs::stat_acc
   float* ws;
+  unsigned* tickets;   // split-K fix-up by the last arriver of each tile (zero before and after every launch), or null
   int M, Hs, Ws;
   int cin, ldin, coffin;
   int cout, ldout, coffout;
@@ -297,7 +302,57 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
   };
   constexpr int NR = F16 ? 4 : 16;
 
-  if (p.splitk > 1) {
+  if (p.splitk > 1 && p.tickets) {
+    // Coherence across the XCDs' L2 caches WITHOUT agent-scope fences (a fence is buffer_wbl2 + buffer_inv: it writes back
+    // and invalidates the whole L2 under the other workgroups' weight streams): the tiles are stored and loaded with the
+    // sc1 bit (what the compiler emits for agent-scope relaxed atomics: write-through / miss-always), the stores are
+    // waited for (vmcnt) before the ticket is taken.
+    constexpr int Q4 = NR / 4, NF = MT * NT * Q4;
+    const int tile = (ph * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int ntile = gridDim.x * gridDim.y * (gridDim.z / p.splitk);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, 0x7FFFFF00u, 0x00020000);
+    constexpr int TILE_BYTES = BM * BN * 4;
+    const unsigned mine = (unsigned)(ks * ntile + tile) * TILE_BYTES + tid * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < Q4; ++q) {
+          const f4_t v = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), rsW, mine + ((mt * NT + nt) * Q4 + q) * 4096, 0, 16);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile has reached the coherent level
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == (unsigned)p.splitk - 1u) ? 1 : 0;
+      if (s_last) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all arrived: ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[mt][nt][r] = 0.f;
+    for (int k = 0; k < p.splitk; ++k) {   // split order, whoever is last
+      const unsigned src = (unsigned)(k * ntile + tile) * TILE_BYTES + tid * 16;
+      f4_t v[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) v[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < Q4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mt][nt][4 * q + j] += v[(mt * NT + nt) * Q4 + q][j];
+    }
+  } else if (p.splitk > 1) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -461,7 +516,7 @@ int run(hipStream_t st, IgemmArgs& a) {
              "igemm: leading dims / channel offsets must be 16-byte aligned");
   KP kp;
   kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out;
-  kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials; kp.ws = a.ws;
+  kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials; kp.ws = a.ws; kp.tickets = nullptr;
   kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg; kp.stat_reps = a.stat_reps > 0 ? a.stat_reps : 1;
   a.stat_used = a.stat_acc ? 1 : 0;
   kp.M = a.n * a.Hs * a.Ws; kp.Hs = a.Hs; kp.Ws = a.Ws;
@@ -478,12 +533,33 @@ int run(hipStream_t st, IgemmArgs& a) {
   GI_REQUIRE(in_elems < (1ll << 31) && out_pixels * a.ldout < (1ll << 31), "igemm: tensor too large for 32-bit offsets");
 
   const bool wide = (a.cout % 128 == 0);
-  const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+  int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
   const int phases = PHASE ? 4 : 1;
-  const int mt = (kp.M + BM - 1) / BM, nt = a.cout / BN;
-  const int tiles = mt * nt * phases;
+  int mt = (kp.M + BM - 1) / BM, nt = a.cout / BN;
+  int tiles = mt * nt * phases;
   int splitk = 1;
-  if (a.force_splitk > 0) splitk = a.force_splitk;
+  // in-kernel fix-up: the last arriver reads splits x tile bytes on ONE CU (~100 GB/s), so the split count is capped
+  // and very small M gets 128 x 64 tiles instead (twice the workgroups for the same tail)
+  static int fix = -1, fix_max = 8;   // GI_IGEMM_FIXUP=0: finish-kernel path; GI_IGEMM_FIX_MAXSPLIT (tools: A/B)
+  if (fix < 0) {
+    const char* e = getenv("GI_IGEMM_FIXUP"); fix = e ? atoi(e) : 1;
+    e = getenv("GI_IGEMM_FIX_MAXSPLIT"); if (e && atoi(e) > 1) fix_max = atoi(e);
+  }
+  bool fixup = fix && a.tickets && a.ws && a.force_splitk == 0 && tiles < 256 && kp.nk >= 8;
+  bool half_n = false;
+  if (fixup) {
+    if (wide && tiles * fix_max < 256) { half_n = true; BN = 64; nt = a.cout / BN; tiles = mt * nt * phases; }
+    splitk = (256 + tiles - 1) / tiles;
+    if (splitk > fix_max) splitk = fix_max;
+    if (splitk > kp.nk / 4) splitk = kp.nk / 4;
+    if (splitk < 1) splitk = 1;
+    if (tiles > GI_IGEMM_TICKETS || a.ws_bytes < (int64_t)splitk * tiles * BM * BN * 4) {
+      fixup = false; splitk = 1;
+      if (half_n) { half_n = false; BN = 128; nt = a.cout / BN; tiles = mt * nt * phases; }
+    }
+  }
+  if (fixup) {
+  } else if (a.force_splitk > 0) splitk = a.force_splitk;
   else if (tiles < 256 && kp.nk >= 8) {   // fewer workgroups than CUs: split the reduction
     static int target = -1;   // workgroups to aim for (GI_IGEMM_SPLIT_BLOCKS: tools only)
     if (target < 0) { const char* e = getenv("GI_IGEMM_SPLIT_BLOCKS"); target = e ? atoi(e) : 384; }
@@ -497,7 +573,9 @@ int run(hipStream_t st, IgemmArgs& a) {
   splitk = (kp.nk + kp.kt_per_split - 1) / kp.kt_per_split;
   kp.splitk = splitk;
   kp.ws_stride = 0;
-  if (splitk > 1) {
+  if (splitk <= 1) fixup = false;
+  if (fixup) kp.tickets = a.tickets;
+  if (splitk > 1 && !fixup) {
     // scratch for one buffer per split: plain stores + a summing finish pass (deterministic, no memset);
     // otherwise fp32 atomics into a single zeroed buffer
     if (a.ws_bytes >= (int64_t)splitk * out_pixels * a.cout * 4) kp.ws_stride = out_pixels * a.cout;
@@ -507,10 +585,11 @@ int run(hipStream_t st, IgemmArgs& a) {
   }
   GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % 256 == 0, "igemm: stat_pg=%d must be a multiple of 256", a.stat_pg);
   dim3 grid(mt, nt, phases * splitk);
-  if (wide) GI_TRY((launch_cfg<T, PHASE, 128, 128, 2, 2>(st, kp, grid)));
+  if (half_n) GI_TRY((launch_cfg<T, PHASE, 128, 64, 2, 2>(st, kp, grid)));
+  else if (wide) GI_TRY((launch_cfg<T, PHASE, 128, 128, 2, 2>(st, kp, grid)));
   else GI_TRY((launch_cfg<T, PHASE, 256, 64, 4, 1>(st, kp, grid)));
   a.ntiles_out = mt * phases;
-  if (splitk > 1) {
+  if (splitk > 1 && !fixup) {
     const int RL = 256 / (a.cout / 4) > 0 ? 256 / (a.cout / 4) : 1;   // row lanes per block
     int rpb = 64;
     while (rpb > RL && (out_pixels + rpb - 1) / rpb < 256) rpb >>= 1;   // fill the chip on small tensors
@@ -530,13 +609,16 @@ int run(hipStream_t st, IgemmArgs& a) {
 }  // namespace
 
 int op_igemm3(hipStream_t st, int mode, IgemmArgs& a);   // igemm3.hip: 256xBN tiles, LDS-DMA ring
+int op_igemm7(hipStream_t st, int mode, IgemmArgs& a);   // igemm7.hip: 128xBN tiles, 4-stage ring, split-K with in-kernel fix-up
 
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a) {
   // GI_IGEMM_VARIANT (tools / A-B timing only): 3 = LDS-DMA kernel (default), 1 = register-staged kernel only
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("GI_IGEMM_VARIANT"); variant = e ? atoi(e) : 3; }
   if (dtype == GI_F16 && a.force_splitk == 0 && variant >= 3) {
-    const int rc = op_igemm3(st, phase_mode, a);
+    int rc = op_igemm3(st, phase_mode, a);
+    if (rc != GI_ERR_UNSUPPORTED) return rc;
+    rc = op_igemm7(st, phase_mode, a);      // small-M layers: deep LDS-DMA ring + in-kernel split-K reduction
     if (rc != GI_ERR_UNSUPPORTED) return rc;
   }
   if (dtype == GI_F16) return phase_mode ? run<half_t, 1>(st, a) : run<half_t, 0>(st, a);

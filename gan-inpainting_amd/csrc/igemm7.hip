@@ -1,0 +1,440 @@
+// fp16 implicit GEMM for the small-M layers (the bottleneck of the U-Net: 16x16 maps and below at the headline batch,
+// everything in small test nets): few output tiles, long K (4..16 taps x 512..1024 channels), 8..17 MB of weights per
+// layer. Two things bound such a layer: how deep each workgroup's K pipeline is (a 2-stage register-staged loop pays the
+// full global-load latency per K tile: 1.4 us per tile measured on igemm.hip) and how many launches it takes.
+//
+//   * 128 x BN output tile (BN = 128 or 64), 4 waves (2 x 2; wave tile 64 x BN/2), K tile = 64 halves;
+//   * FOUR-stage LDS ring filled by LDS-DMA (global_load_lds_dwordx4), counted vmcnt, one raw s_barrier per K tile: two
+//     tiles are in flight while one is multiplied (48..64 KB per CU outstanding), the DMA instructions of tile t+3 are
+//     issued between the MFMAs of tile t (same LDS image, swizzle and gather scheme as igemm3.hip);
+//   * split-K over the workgroups of a tile; every split stores its fp32 tile in thread-linear order with the sc1 bit
+//     (write-through to the level all XCDs share), waits for the stores, takes a ticket; the LAST arriver adds the splits
+//     up in split order (sc1 loads: miss-always) - a fixed order whoever is last - and runs the epilogue (bias,
+//     activation, BatchNorm column statistics, 16-byte coalesced rows). No finish launch, no agent-scope fence (a fence is
+//     buffer_wbl2 + buffer_inv of the whole L2 under the other workgroups' weight streams: measured 1.6x slower).
+#include <stdlib.h>
+
+#include "common.h"
+#include "stat_acc.h"
+
+namespace {
+
+struct KP7 {
+  const char* in;
+  const char* w;
+  char* out;
+  const char* zero;   // >= 4 KiB of zeros (padding taps)
+  const float* bias;
+  float* partials;
+  unsigned long long* stat_acc; int stat_pg, stat_reps;
+  float* ws;          // split-K tiles: [split][tile][BM * BN] fp32
+  unsigned* tickets;
+  int M, Hs, Ws;
+  int cin, ldin, coffin;
+  int cout, ldout, coffout;
+  int Ktot, nk, splitk, kt_per_split;
+  int relu_in, act_out, relu_cend;
+  int Hin, Win, Hout, Wout;
+  int mtiles, ntiles;
+};
+
+__device__ __forceinline__ float act7(float v, int act) {
+  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ h8_t relu7(h8_t v) {
+  typedef short s8_t __attribute__((ext_vector_type(8)));
+  s8_t h = __builtin_bit_cast(s8_t, v);
+  const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  h = __builtin_elementwise_max(h, z);
+  return __builtin_bit_cast(h8_t, h);
+}
+__device__ __forceinline__ void glds16_7(const char* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_wave_base,
+                                   16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm7() {
+  static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "unexpected DMA count");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+template <int PHASE, int BN>
+__global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
+  constexpr int BM = 128, BK = 64, NW = 4;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 32 / 24 KiB
+  constexpr int NSTG = 4;
+  constexpr int AJ = (BM / 8) / NW, BJ = (BN / 8) / NW;   // 8-row blocks per wave per tile: 4 + (4 | 2)
+  constexpr int NPC = AJ + BJ;
+  constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int s_last;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- work decode: (M tile, N tile, phase, split). With >= 8 M tiles the workgroups of one XCD (bid & 7) share M tiles
+  //      (gathered rows from that XCD's L2); with fewer, consecutive workgroups walk the N tiles / splits so that all XCDs work
+  const int nph = PHASE == 1 ? 4 : 1;
+  const int nyz = p.ntiles * nph * p.splitk;
+  const int bid = blockIdx.x;
+  int mt_idx, yz;
+  if (p.mtiles >= 8) {
+    const int xcd = bid & 7, local = bid >> 3;
+    mt_idx = (local / nyz) * 8 + xcd;
+    yz = local % nyz;
+    if (mt_idx >= p.mtiles) return;
+  } else {
+    mt_idx = bid % p.mtiles;
+    yz = bid / p.mtiles;
+  }
+  const int ks = yz % p.splitk;
+  const int t2 = yz / p.splitk;
+  const int nt_idx = t2 % p.ntiles;
+  const int ph = t2 / p.ntiles;
+  const int py = ph >> 1, px = ph & 1;
+  const int m0 = mt_idx * BM, n0 = nt_idx * BN;
+  const char* wptr = p.w + (PHASE == 1 ? (int64_t)ph * p.cout * p.Ktot * 2 : 0);
+  const int kt0 = ks * p.kt_per_split;
+  const int kt1 = min(p.nk, kt0 + p.kt_per_split);
+  const int nk = kt1 - kt0;
+
+  // ---- per-lane gather rows (igemm3.hip) -----------------------------------------------------------
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ (lrow & 7);
+  int abase[AJ];
+  unsigned amask[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int m = m0 + (wave * AJ + j) * 8 + lrow;
+    abase[j] = 0;
+    amask[j] = 0;
+    if (m < p.M) {
+      const int x = m % p.Ws;
+      const int t = m / p.Ws;
+      const int y = t % p.Hs;
+      const int n = t / p.Hs;
+      if (PHASE) {
+        const int y0 = y + py, x0 = x + px;
+        abase[j] = ((n * p.Hs + y0) * p.Ws + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          const int iy = y0 - (tt >> 1), ix = x0 - (tt & 1);
+          if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) amask[j] |= 1u << tt;
+        }
+      } else {
+        const int y0 = 2 * y - 1, x0 = 2 * x - 1;
+        abase[j] = ((n * p.Hin + y0) * p.Win + x0) * p.ldin + p.coffin;
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+          const int iy = y0 + (tt >> 2), ix = x0 + (tt & 3);
+          if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) amask[j] |= 1u << tt;
+        }
+      }
+    }
+  }
+  const char* pa[AJ];
+  const char* pb[BJ];
+  int tap = (kt0 * BK) / p.cin, c0 = (kt0 * BK) % p.cin;
+  auto set_tap = [&]() {
+    int toff;
+    if (PHASE) toff = -((tap >> 1) * p.Win + (tap & 1)) * p.ldin;
+    else toff = ((tap >> 2) * p.Win + (tap & 3)) * p.ldin;
+#pragma unroll
+    for (int j = 0; j < AJ; ++j)
+      pa[j] = ((amask[j] >> tap) & 1u) ? p.in + (int64_t)(abase[j] + toff) * 2 + lchunk * 16 : p.zero + lchunk * 16;
+  };
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) pb[j] = wptr + (int64_t)(n0 + (wave * BJ + j) * 8 + lrow) * p.Ktot * 2 + lchunk * 16;
+  set_tap();
+
+  int kt_issue = kt0;
+  auto issue_piece = [&](auto STG, auto PIECE) {
+    constexpr int stage = decltype(STG)::value;
+    constexpr int j = decltype(PIECE)::value;
+    if constexpr (j < AJ) glds16_7(pa[j] + c0 * 2, smem + stage * STAGE + wave * (AJ * 1024) + j * 1024);
+    else glds16_7(pb[j - AJ] + (int64_t)kt_issue * (BK * 2), smem + stage * STAGE + A_BYTES + wave * (BJ * 1024) + (j - AJ) * 1024);
+  };
+  auto issue_done = [&]() {
+    ++kt_issue;
+    c0 += BK;
+    if (c0 >= p.cin) { c0 = 0; ++tap; set_tap(); }
+  };
+  auto issue = [&](auto STG) {
+    static_for<NPC>([&](auto J) { issue_piece(STG, J); });
+    issue_done();
+  };
+
+  f4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rdA0 = (wm * 64 + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdA1 = (wm * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+  const int rdB0 = A_BYTES + (wn * WN + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdB1 = A_BYTES + (wn * WN + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+  const int relu_cend = p.relu_in ? p.relu_cend : 0;
+  int cc0 = c0;   // channel offset of the tile being computed
+
+  // multiply the tile in stage CUR; with ISS the NPC DMA pieces of the tile three ahead go out one at a time between the MFMAs
+  auto compute = [&](auto STG, auto NXT, auto ISS) {
+    constexpr int stage = decltype(STG)::value;
+    constexpr bool iss = decltype(ISS)::value;
+    constexpr int NMF = 2 * MT * NT;
+    const bool relu_in = cc0 < relu_cend;   // wave-uniform
+    const char* s = smem + stage * STAGE;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+      h8_t af[MT], bf[NT];
+      const int oa = k2 ? rdA1 : rdA0, ob = k2 ? rdB1 : rdB0;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(s + oa + mt * 2048);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(s + ob + nt * 2048);
+      if (relu_in) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) af[mt] = relu7(af[mt]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int idx = k2 * MT * NT + mt * NT + nt;
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+          if constexpr (iss) {
+            static_for<NPC>([&](auto Q) {
+              constexpr int q = decltype(Q)::value;
+              if (idx == ((q + 1) * NMF) / (NPC + 1) - 1) issue_piece(NXT, Q);
+            });
+          }
+        }
+    }
+    if constexpr (iss) issue_done();
+    cc0 += BK;
+    if (cc0 >= p.cin) cc0 = 0;
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  using T1 = std::integral_constant<bool, true>;
+  using T0 = std::integral_constant<bool, false>;
+  // ---- 4-stage ring: tiles t+1, t+2 stay in flight while tile t is multiplied; tile t+3 is issued during that step into the
+  //      stage tile t-1 was read from (free once every wave has passed the barrier of step t) -------------------------------
+  issue(S0{});
+  if (nk > 1) issue(S1{});
+  if (nk > 2) issue(S2{});
+  auto wait_tile = [&](int newer) {   // `newer` tiles issued after tile t may stay in flight
+    if (newer >= 2) wait_vm7<2 * NPC>();
+    else if (newer == 1) wait_vm7<NPC>();
+    else wait_vm7<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  int t = 0;
+  for (; t + 3 < nk - 3; t += 4) {   // steady state (every step issues), stage indices are compile-time
+    wait_tile(2); compute(S0{}, S3{}, T1{});
+    wait_tile(2); compute(S1{}, S0{}, T1{});
+    wait_tile(2); compute(S2{}, S1{}, T1{});
+    wait_tile(2); compute(S3{}, S2{}, T1{});
+  }
+  for (; t < nk; ++t) {
+    wait_tile(min(2, nk - 1 - t));
+    const bool is = t + 3 < nk;
+    switch (t & 3) {
+      case 0: if (is) compute(S0{}, S3{}, T1{}); else compute(S0{}, S3{}, T0{}); break;
+      case 1: if (is) compute(S1{}, S0{}, T1{}); else compute(S1{}, S0{}, T0{}); break;
+      case 2: if (is) compute(S2{}, S1{}, T1{}); else compute(S2{}, S1{}, T0{}); break;
+      default: if (is) compute(S3{}, S2{}, T1{}); else compute(S3{}, S2{}, T0{}); break;
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- split-K fix-up by the last arriver of the tile ---------------------------------------------------------------------
+  if (p.splitk > 1) {
+    constexpr int NF = MT * NT;
+    constexpr int TILE_BYTES = BM * BN * 4;
+    const int tile = (ph * p.ntiles + nt_idx) * p.mtiles + mt_idx;
+    const int ntile = p.mtiles * p.ntiles * nph;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.ws, 0, 0x7FFFFF00u, 0x00020000);
+    const unsigned mine = (unsigned)(ks * ntile + tile) * TILE_BYTES + tid * 16;
+#pragma unroll
+    for (int i = 0; i < NF; ++i)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, acc[i / NT][i % NT]), rsW, mine + i * 4096, 0, 16);   // sc1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned tk = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (tk == (unsigned)p.splitk - 1u) ? 1 : 0;
+      if (s_last) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int i = 0; i < NF; ++i) acc[i / NT][i % NT] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < p.splitk; ++k) {   // split order, whoever is last
+      const unsigned src = (unsigned)(k * ntile + tile) * TILE_BYTES + tid * 16;
+      f4_t v[NF];
+#pragma unroll
+      for (int i = 0; i < NF; ++i) v[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+#pragma unroll
+      for (int i = 0; i < NF; ++i) acc[i / NT][i % NT] += v[i];
+    }
+  }
+
+  // ---- epilogue (contract of igemm3.hip) ----------------------------------------------------------------------------------
+  auto out_pixel = [&](int m) -> int {
+    if (PHASE != 1) return m;
+    const int x = m % p.Ws;
+    const int tt = m / p.Ws;
+    const int y = tt % p.Hs;
+    const int n = tt / p.Hs;
+    return (n * p.Hout + 2 * y + py) * p.Wout + 2 * x + px;
+  };
+  constexpr int SLD = BN + 8;
+  half_t* stg = (half_t*)smem;
+  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [2][BN][2]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = wn * WN + nt * 16 + 4 * lq;           // this lane's 4 consecutive channels
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[mt][nt][r] + bs[r];
+        s[r] += v;
+        q[r] += v * v;
+        o[r] = (half_t)act7(v, p.act_out);
+      }
+      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
+    }
+    if (p.partials || p.stat_acc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+      }
+    }
+  }
+  __syncthreads();
+  if ((p.partials || p.stat_acc) && tid < BN) {
+    const float s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+    if (p.stat_acc) {
+      const int grp = (p.stat_pg > 0 && m0 >= p.stat_pg) ? 1 : 0, rep = (mt_idx + ph) & (p.stat_reps - 1);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 0, n0 + tid, s);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 1, n0 + tid, q);
+    } else {
+      const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * ph;
+      p.partials[(trow * 2 + 0) * p.cout + n0 + tid] = s;
+      p.partials[(trow * 2 + 1) * p.cout + n0 + tid] = q;
+    }
+  }
+  constexpr int CPRO = BN / 8;   // 16-byte chunks per output row
+  const int oc = tid % CPRO;
+#pragma unroll 1
+  for (int r = tid / CPRO; r < BM; r += 256 / CPRO) {
+    const int m = m0 + r;
+    if (m < p.M) {
+      const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
+      *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+    }
+  }
+}
+
+}  // namespace
+
+const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
+
+// modes 0 (Conv2d 4x4/s2/p1 gather) and 1 (sub-pixel phases), fp16, layers with fewer than 256 tiles of 128 x 128.
+// Returns GI_ERR_UNSUPPORTED for what it does not serve (the caller falls back to igemm.hip).
+int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
+  if (mode != 0 && mode != 1) return GI_ERR_UNSUPPORTED;
+  if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.force_splitk != 0) return GI_ERR_UNSUPPORTED;
+  static int use7 = -1, max_split = 16;   // GI_IGEMM7=0: igemm.hip serves these layers; GI_IGEMM7_MAXSPLIT (tools: A/B)
+  if (use7 < 0) {
+    const char* e = getenv("GI_IGEMM7"); use7 = e ? atoi(e) : 1;
+    e = getenv("GI_IGEMM7_MAXSPLIT"); if (e && atoi(e) >= 1) max_split = atoi(e);
+  }
+  if (!use7) return GI_ERR_UNSUPPORTED;
+  const int M = a.n * a.Hs * a.Ws;
+  const int nph = mode == 1 ? 4 : 1;
+  const int mtiles = (M + 127) / 128;
+  int BN = (a.cout % 128 == 0 && mtiles * (a.cout / 128) * nph >= 64) ? 128 : 64;
+  {   // GI_IGEMM7_BN (tools: A/B): force the N tile
+    static int force_bn = -1;
+    if (force_bn < 0) { const char* e = getenv("GI_IGEMM7_BN"); force_bn = e ? atoi(e) : 0; }
+    if (force_bn == 64 || (force_bn == 128 && a.cout % 128 == 0)) BN = force_bn;
+  }
+  const int ntiles = a.cout / BN;
+  const int tiles = mtiles * ntiles * nph;
+  const int Ktot = (mode == 1 ? 4 : 16) * a.cin, nk = Ktot / 64;
+  int splitk = (256 + tiles - 1) / tiles;
+  if (splitk > max_split) splitk = max_split;
+  if (splitk > nk / 4) splitk = nk / 4;
+  if (splitk < 1) splitk = 1;
+  int kps = (nk + splitk - 1) / splitk;
+  splitk = (nk + kps - 1) / kps;
+  if (splitk > 1 && (!a.tickets || !a.ws || tiles > GI_IGEMM_TICKETS || a.ws_bytes < (int64_t)splitk * tiles * 128 * BN * 4)) return GI_ERR_UNSUPPORTED;
+  int dev = 0;
+  GI_HIP(hipGetDevice(&dev));
+  const char* zero = gi_igemm3_zero_page(dev);
+  if (!zero) return GI_ERR_HIP;
+  KP7 kp;
+  kp.in = (const char*)a.in; kp.w = (const char*)a.w; kp.out = (char*)a.out; kp.zero = zero;
+  kp.bias = a.bias; kp.partials = a.stat_acc ? nullptr : a.partials;
+  kp.stat_acc = a.stat_acc; kp.stat_pg = a.stat_pg; kp.stat_reps = a.stat_reps > 0 ? a.stat_reps : 1;
+  a.stat_used = a.stat_acc ? 1 : 0;
+  GI_REQUIRE(!a.stat_acc || a.stat_pg == 0 || a.stat_pg % 128 == 0, "igemm7: stat_pg=%d must be a multiple of 128", a.stat_pg);
+  kp.ws = a.ws; kp.tickets = a.tickets;
+  kp.M = M; kp.Hs = a.Hs; kp.Ws = a.Ws;
+  kp.cin = a.cin; kp.ldin = a.ldin; kp.coffin = a.coffin;
+  kp.cout = a.cout; kp.ldout = a.ldout; kp.coffout = a.coffout;
+  kp.Ktot = Ktot; kp.nk = nk; kp.splitk = splitk; kp.kt_per_split = kps;
+  kp.relu_in = a.relu_in; kp.act_out = a.act_out;
+  kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
+  if (mode == 1) { kp.Hin = a.Hs; kp.Win = a.Ws; kp.Hout = 2 * a.Hs; kp.Wout = 2 * a.Ws; }
+  else { kp.Hin = 2 * a.Hs; kp.Win = 2 * a.Ws; kp.Hout = a.Hs; kp.Wout = a.Ws; }
+  GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
+             "igemm7: tensor too large for 32-bit offsets");
+  kp.mtiles = mtiles; kp.ntiles = ntiles;
+  const int nyz = ntiles * nph * splitk;
+  const int grid = mtiles >= 8 ? ((mtiles + 7) / 8) * 8 * nyz : mtiles * nyz;
+  const int ring = 4 * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
+  const int LDS = ring > epi ? ring : epi;
+  static bool attr_set[4] = {false, false, false, false};
+  const void* fn[4] = {(const void*)igemm7_kernel<0, 128>, (const void*)igemm7_kernel<1, 128>, (const void*)igemm7_kernel<0, 64>,
+                       (const void*)igemm7_kernel<1, 64>};
+  const int vi = (BN == 64 ? 2 : 0) + mode;
+  if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128)); attr_set[vi] = true; }
+  switch (vi) {
+    case 0: hipLaunchKernelGGL((igemm7_kernel<0, 128>), dim3(grid), dim3(256), LDS, st, kp); break;
+    case 1: hipLaunchKernelGGL((igemm7_kernel<1, 128>), dim3(grid), dim3(256), LDS, st, kp); break;
+    case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
+    default: hipLaunchKernelGGL((igemm7_kernel<1, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
+  }
+  GI_LAUNCH_CHECK();
+  a.ntiles_out = mtiles * nph;
+  return GI_OK;
+}

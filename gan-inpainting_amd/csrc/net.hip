@@ -113,6 +113,7 @@ struct gi_net {
   // consuming passes. GI_BN_ACC=0 restores partial rows + finalize / sums launches.
   int64_t oAcc = -1, acc_words = 0;
   int use_acc = 1;
+  int64_t oTickets = -1;             // split-K fix-up counters (IgemmArgs::tickets): zero at bind, zero after every launch
   // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
   int64_t oD2 = -1, oTZ = -1, oGimg = -1, oVimg = -1, oGPs = -1, oGPpart = -1, oGPsums = -1, oTh = -1;
@@ -318,6 +319,7 @@ extern "C" int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_
     for (BN* b : {&net->dnorm[k], &net->unorm[k]})
       if (b->c && norm_kind == 0) { b->acc_off = net->acc_words; net->acc_words += 4 * b->acc_block(); }
   net->oAcc = A.take(net->acc_words * 8);
+  net->oTickets = A.take((int64_t)GI_IGEMM_TICKETS * 4);
   { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
@@ -432,6 +434,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->slot_bytes = S.size;
   for (int i = 2; i <= 4; ++i) { net->dbn[i].acc_off = net->acc_words; net->acc_words += 4 * net->dbn[i].acc_block(); }
   net->oAcc = A.take(net->acc_words * 8);
+  net->oTickets = A.take((int64_t)GI_IGEMM_TICKETS * 4);
   { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
   net->gp_slot = n_slots;                      // one private activation set for the gradient penalty
   net->slot_base = A.take(S.size * (n_slots + 1));
@@ -483,6 +486,7 @@ extern "C" int gi_net_bind(gi_net* net, float* params, float* grads, float* buff
   net->params = params; net->grads = grads; net->buffers = buffers; net->ws = (char*)workspace;
   net->bound = true;
   if (net->acc_words > 0) GI_HIP(hipMemsetAsync(net->shared(net->oAcc), 0, (size_t)net->acc_words * 8, net->ctx->stream));
+  if (net->oTickets >= 0) GI_HIP(hipMemsetAsync(net->shared(net->oTickets), 0, (size_t)GI_IGEMM_TICKETS * 4, net->ctx->stream));
   return GI_OK;
 }
 
@@ -698,6 +702,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   a.partials = stats ? (float*)net->shared(net->oPart) : nullptr;
   a.ws = net->split_bytes > 0 ? (float*)net->shared(net->oSplit) : nullptr;
   a.ws_bytes = net->split_bytes;
+  a.tickets = net->oTickets >= 0 ? (unsigned*)net->shared(net->oTickets) : nullptr;
   a.n = n; a.Hs = Hs; a.Ws = Ws;
   a.cin = cin; a.ldin = ldin; a.coffin = coffin;
   a.cout = cout; a.ldout = ldout; a.coffout = coffout;

@@ -30,6 +30,14 @@ CONV_CASES = [
     (7, 72, 72, 64, 512, False),     # igemm3 with a ragged last M tile (M = 9072) and non-power-of-two maps
     (8, 128, 128, 128, 64, False),   # igemm3, 64-column variant
     (8, 128, 128, 64, 512, False),   # igemm3, 256x256 two-stage variant (>= 256 such tiles)
+    # use_ws = 2: scratch for one tile per split -> the split-K fix-up inside the GEMM kernel (last arriver per tile)
+    (2, 64, 64, 64, 128, 2),         # M = 2048, one N tile
+    (2, 32, 32, 128, 256, 2),        # M = 512
+    (2, 16, 16, 256, 512, 2),        # M = 128: 128 x 64 tiles
+    (3, 8, 8, 512, 512, 2),          # M = 48, ragged
+    (5, 2, 2, 512, 512, 2),          # 1x1 output
+    (32, 16, 16, 512, 512, 2),       # the generator's d5 at the headline configuration (M = 2048, K = 8192)
+    (4, 32, 32, 64, 64, 2),          # 64 output channels: 256 x 64 tiles
 ]
 
 
@@ -44,6 +52,8 @@ def test_conv_s2_forward(code, case):
     xd = nhwc_dev(x, code)
     out = torch.full((n, H // 2, W // 2, ca), float("nan"), dtype=tdt(code), device="cuda")
     ws = torch.zeros(n * (H // 2) * (W // 2) * ca, dtype=torch.float32, device="cuda") if use_ws else None
+    if use_ws == 2:
+        ws = torch.full((8 << 20,), float("nan"), dtype=torch.float32, device="cuda")
     B.check(B.lib().gi_conv_s2_forward(B.get_ctx(), code, B.ptr(xd), B.ptr(packed), B.ptr(out), n, H, W, cb, cb, ca, ca,
                                        0, 0, B.ptr(ws), ws.numel() * 4 if use_ws else 0))
     torch.cuda.synchronize()
@@ -83,6 +93,14 @@ CONVT_CASES = [
     (3, 40, 40, 128, 256, False),   # igemm3, ragged M (4800), two N tiles
     (8, 32, 32, 128, 64, False),    # igemm3, 64-column variant (the generator's u2 shape family)
     (16, 32, 32, 128, 256, False),  # igemm3, 256x256 two-stage variant
+    # use_ws = 2: split-K fix-up inside the GEMM kernel
+    (2, 1, 1, 512, 512, 2),
+    (2, 2, 2, 1024, 512, 2),
+    (2, 4, 4, 1024, 512, 2),
+    (2, 8, 8, 1024, 256, 2),
+    (2, 16, 16, 512, 128, 2),
+    (2, 32, 32, 256, 64, 2),        # 64 output channels: 256 x 64 tiles
+    (32, 4, 4, 1024, 512, 2),       # the generator's u6 at the headline configuration
 ]
 
 
@@ -97,6 +115,8 @@ def test_convT_s2_forward(code, case):
     xd = nhwc_dev(x, code)
     out = torch.full((n, 2 * H, 2 * W, cb), float("nan"), dtype=tdt(code), device="cuda")
     ws = torch.zeros(n * 4 * H * W * cb, dtype=torch.float32, device="cuda") if use_ws else None
+    if use_ws == 2:
+        ws = torch.full((8 << 20,), float("nan"), dtype=torch.float32, device="cuda")
     B.check(B.lib().gi_convT_s2_forward(B.get_ctx(), code, B.ptr(xd), B.ptr(phase), B.ptr(out), n, H, W, ca, ca, cb, cb,
                                         0, 0, B.ptr(ws), ws.numel() * 4 if use_ws else 0))
     torch.cuda.synchronize()
