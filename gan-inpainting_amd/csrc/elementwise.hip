@@ -532,6 +532,80 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   }
 }
 
+// Small tensors (the U-Net's innermost levels: <= 512 pixels by default, the kernel serves up to 2048): reduce and apply in ONE launch. A workgroup owns a 16-byte
+// channel chunk and all pixels, every thread holds its <= 8 chunks of dz and x in registers: sums of dz and dz * xhat (fp32
+// per thread, double across the block, fixed order: reproducible), coefficients, dx. The two-launch form costs 13 + 14 us
+// per layer there, almost all of it launch and accumulator round trips (12 us in this form). Beyond ~512 pixels the
+// channel-chunk-per-workgroup layout loses: a workgroup uses 16 bytes of every 128-byte line it touches (28 us at 2048 pixels).
+template <typename T, int NIT>   // NIT = pixels / 256 rounded up: every thread keeps its NIT chunks (dz, x) in registers between the sweeps
+__global__ void __launch_bounds__(256) act_bn_bwd_small_kernel(BwdP p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  __shared__ double sh[8];
+  __shared__ float coef[3 * 8];
+  const int cc = blockIdx.x;
+  float mu[EPC], iv[EPC], sc[EPC], shf[EPC], s[EPC], sx[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    mu[e] = p.mean[cc * EPC + e]; iv[e] = p.inv[cc * EPC + e];
+    sc[e] = p.scale ? p.scale[cc * EPC + e] : 0.f; shf[e] = p.scale ? p.shift[cc * EPC + e] : 0.f;
+    s[e] = sx[e] = 0.f;
+  }
+  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
+  float xr[NIT][EPC], dzr[NIT][EPC];
+  DzIn<T, EPC> in[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {    // all loads first
+    const int64_t pix = threadIdx.x + it * 256;
+    if (pix < p.pixels) {
+      load_vec<T, EPC>(p.x, pix * p.c + cc * EPC, xr[it]);
+      load_dz<T, EPC>(p, pix, cc * EPC, need_y && !p.scale, in[it]);
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t pix = threadIdx.x + it * 256;
+    if (pix < p.pixels) {
+      if (p.scale || !need_y) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) in[it].y[e] = p.scale ? fmaf(xr[it][e], sc[e], shf[e]) : 1.f;
+      }
+      finish_dz<T, EPC>(p, in[it], in[it].y, dzr[it]);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { s[e] += dzr[it][e]; sx[e] = fmaf(dzr[it][e], (xr[it][e] - mu[e]) * iv[e], sx[e]); }
+    }
+  }
+  __shared__ float tot[2 * 8];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    double a = s[e], b = sx[e];
+    block_sum2(a, b, sh);
+    if (threadIdx.x == 0) { tot[e] = (float)a; tot[8 + e] = (float)b; }
+  }
+  __syncthreads();
+  if (threadIdx.x < EPC) {     // one lane per channel: the parameter-gradient updates overlap instead of queueing behind one lane
+    const int e = threadIdx.x, ch = cc * EPC + e;
+    const float s1 = tot[e], s2 = tot[8 + e];
+    const float ive = p.inv[ch], mue = p.mean[ch];
+    const float a1 = p.gamma[ch] * ive;
+    const float a2 = -a1 * ive * s2 * p.invM;
+    coef[e] = a1; coef[8 + e] = a2; coef[16 + e] = -a1 * s1 * p.invM - a2 * mue;
+    if (p.dbeta) p.dbeta[ch] += s1 * p.inv_loss_scale;
+    if (p.dgamma) p.dgamma[ch] += s2 * p.inv_loss_scale;
+  }
+  if (blockIdx.x == 0 && p.zero_next) zero_words64(p.zero_next, p.zero_words);
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t pix = threadIdx.x + it * 256;
+    if (pix < p.pixels) {
+      float o[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) o[e] = fmaf(coef[e], dzr[it][e], fmaf(coef[8 + e], xr[it][e], coef[16 + e]));
+      store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, o);
+    }
+  }
+}
+
 // ---- InstanceNorm2d(affine=False, track_running_stats=False), get_norm_layer('instance') (networks.py:38-40) -------------
 // Statistics per (image, channel) over the H*W pixels, eps 1e-5, the same in train and eval mode; no parameters. One
 // workgroup owns (image, 16-byte channel chunk): a first sweep over the image's pixels sums x and x^2 (fp32 per thread,
@@ -1195,6 +1269,20 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   const int grid2 = nblocks(a.pixels * Q, 4);
   p.acc = nullptr; p.acc_reps = a.acc_reps > 0 ? a.acc_reps : 1; p.dgamma = a.dgamma; p.dbeta = a.dbeta; p.inv_loss_scale = a.inv_loss_scale; p.invM = 1.f / (float)p.pg;
   p.zero_next = nullptr; p.zero_words = 0;
+  static int small_max = -1;   // GI_BN_BWD_SMALL: largest pixel count served by the one-launch kernel (0: off; tools: A/B)
+  if (small_max < 0) { const char* e = getenv("GI_BN_BWD_SMALL"); small_max = e ? atoi(e) : 512; if (small_max > 2048) small_max = 2048; }
+  if (a.has_bn && !a.eval_bn && groups == 1 && a.pixels <= small_max) {
+    p.zero_next = a.acc ? a.zero_next : nullptr; p.zero_words = a.acc ? a.zero_words : 0;   // (keeps the accumulator ping-pong of net.hip consistent)
+    const int nit = (int)((a.pixels + 255) / 256);
+#define GI_SMALL(T) do { if (nit <= 1) hipLaunchKernelGGL((act_bn_bwd_small_kernel<T, 1>), dim3(Q), dim3(256), 0, st, p); \
+      else if (nit <= 2) hipLaunchKernelGGL((act_bn_bwd_small_kernel<T, 2>), dim3(Q), dim3(256), 0, st, p); \
+      else if (nit <= 4) hipLaunchKernelGGL((act_bn_bwd_small_kernel<T, 4>), dim3(Q), dim3(256), 0, st, p); \
+      else hipLaunchKernelGGL((act_bn_bwd_small_kernel<T, 8>), dim3(Q), dim3(256), 0, st, p); } while (0)
+    if (dtype == GI_F16) GI_SMALL(half_t); else GI_SMALL(float);
+#undef GI_SMALL
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   if (a.has_bn && a.acc) {
     // exact accumulators: reduce pass (train mode only) + apply pass, no sums launch in between
     const int grid3 = nblocks(a.pixels * Q, 8);

@@ -14,6 +14,11 @@
 // a transposing read (consecutive for S, stride 2 for the halo) then touch eight distinct chunks.
 // Pixel ranges are split over workgroups as in wgrad.hip: partial tiles to scratch + fixed-order reduction, or
 // direct / atomic accumulation.
+// NKY = 2 (default): a workgroup owns the taps ky and ky + 2 (same row parity): the halo grows from 4 to 5 rows (rows of
+// 36 pixels so that the second tap set sits at a constant LDS distance, XOR 64 in the swizzle), each wave multiplies its
+// S fragments with both tap sets (64 x 128 per wave, 128 accumulator registers). 38 KiB of loads per 128 x 512 x 64 MAC
+// step instead of 33 KiB per 128 x 256 x 64: the kernel is bound by L2 -> LDS traffic (553 MB per launch on the critic's
+// layers at 64 images, 4.9 TB/s), which this cuts to 312 MB.
 #include <stdlib.h>
 
 #include "common.h"
@@ -56,8 +61,11 @@ __device__ __forceinline__ h8_t relu8(h8_t v) {
   return __builtin_bit_cast(h8_t, h);
 }
 
-// grid.x = (ca/128) * (cb/64) * 4 (ky) ; grid.y = splits
-__global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
+// grid.x = (ca/128) * (cb/64) * (4 / NKY) ; grid.y = splits
+template <int NKY>
+__global__ void __launch_bounds__(512, NKY == 1 ? 2 : 1) wgrad2_kernel(WP2 p) {
+  constexpr int HST = NKY == 2 ? 36 : 34;    // halo row stride in pixels
+  constexpr int HROWS = NKY == 2 ? 5 : 4;
   constexpr int S_BYTES = 2 * 64 * 128;      // two 64-channel segments x 64 pixels x 128 B
   constexpr int L_ROWS = 192, L_BYTES = L_ROWS * 128;   // 4 x 34 = 136 halo rows used, 24 pieces of 8 rows
   constexpr int STAGE = S_BYTES + L_BYTES;   // 40 KiB
@@ -70,7 +78,7 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
 
   const int nbt = p.cb >> 6;
   int bx = blockIdx.x;
-  const int ky = bx & 3; bx >>= 2;
+  const int ky = bx & (4 / NKY - 1); bx /= (4 / NKY);   // NKY = 2: taps ky and ky + 2
   const int b0 = (bx % nbt) * 64, a0 = (bx / nbt) * 128;
   const int ks = blockIdx.y;
   const int t0 = ks * p.tiles_per_split, t1 = min(p.ntile, t0 + p.tiles_per_split);
@@ -94,7 +102,7 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
 #pragma unroll
   for (int j = 0; j < LJ; ++j) {
     const int hrow = (wave * LJ + j) * 8 + lrow;         // 0..191
-    const int hr = hrow / 34, hx = hrow - hr * 34;
+    const int hr = hrow / HST, hx = hrow - hr * HST;
     l_hr[j] = hr; l_hx[j] = hx;
     l_off[j] = ((int64_t)(2 * hr * WL + hx) * p.ldL + p.coffL + b0) * 2 + lchunk * 16;
   }
@@ -118,7 +126,7 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
     } else {
       constexpr int jl = j - SJ;
       const int Y = Y0 + 2 * l_hr[jl], X = X0 + l_hx[jl];
-      const bool ok = l_hr[jl] < 4 && Y >= 0 && Y < HL && X >= 0 && X < WL;
+      const bool ok = l_hr[jl] < HROWS && l_hx[jl] < 34 && Y >= 0 && Y < HL && X >= 0 && X < WL;
       glds16w(ok ? lbase + l_off[jl] : p.zero + lchunk * 16, dst + S_BYTES + (wave * LJ + jl) * 1024);
     }
   };
@@ -140,7 +148,7 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
       const int k = ksx * 32 + 8 * g + 4 * h + q;        // pixel of the tile
       const int srow = wa * 64 + k;                      // S row: segment wa (channels wa*64 ..), pixel k
       const int ry = k >> 4, rx = k & 15;
-      const int lrw = ry * 34 + 2 * rx + kx;             // halo row of tap kx
+      const int lrw = ry * HST + 2 * rx + kx;            // halo row of tap kx
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int chunk = t * 2 + (pp >> 1);             // 16 channels of tile t start at byte t*32; this lane's 4 at + pp*8
@@ -149,11 +157,13 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
       }
     }
 
-  f4_t acc[4][4];
+  f4_t acc[NKY][4][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int s2 = 0; s2 < NKY; ++s2)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[s2][i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
   const int nt_tiles = t1 - t0;
   if (nt_tiles > 0) {
@@ -172,30 +182,36 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
       if (more) tile_bases(t0 + i + 2);
 #pragma unroll
       for (int ksx = 0; ksx < 2; ++ksx) {
-        h8_t af[4], bf[4];
+        h8_t af[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          af[t] = tr16x2(sb + aoff[ksx][0][t], sb + aoff[ksx][1][t]);
-          bf[t] = tr16x2(sb + boff[ksx][0][t], sb + boff[ksx][1][t]);
-        }
+        for (int t = 0; t < 4; ++t) af[t] = tr16x2(sb + aoff[ksx][0][t], sb + aoff[ksx][1][t]);
         if (p.relu_S) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) af[t] = relu8(af[t]);
         }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int s2 = 0; s2 < NKY; ++s2) {
+          h8_t bf[4];
+          // tap ky + 2 of pixel row ry is halo row ry + 1: 36 LDS rows further, i.e. (row & 7) ^ 4 in the swizzle
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-            // the five pieces of the next-but-one tile, one every six MFMAs
-            const int idx = ksx * 16 + mt * 4 + nt;
-            if (more) {
-              static_for<SJ + LJ>([&](auto Q) {
-                constexpr int qq = decltype(Q)::value;
-                if (idx == 3 + 6 * qq) issue_piece(st2, Q);
-              });
+          for (int t = 0; t < 4; ++t)
+            bf[t] = s2 ? tr16x2(sb + (boff[ksx][0][t] ^ 64) + HST * 128, sb + (boff[ksx][1][t] ^ 64) + HST * 128)
+                       : tr16x2(sb + boff[ksx][0][t], sb + boff[ksx][1][t]);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              acc[s2][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[s2][mt][nt], 0, 0, 0);
+              // the five pieces of the next-but-one tile, spread over the step's MFMAs
+              const int idx = (ksx * NKY + s2) * 16 + mt * 4 + nt;
+              if (more) {
+                static_for<SJ + LJ>([&](auto Q) {
+                  constexpr int qq = decltype(Q)::value;
+                  if (idx == NKY * (3 + 6 * qq)) issue_piece(st2, Q);
+                });
+              }
             }
-          }
+        }
       }
       ++stage;
       if (stage == 3) stage = 0;
@@ -204,21 +220,24 @@ __global__ void __launch_bounds__(512, 2) wgrad2_kernel(WP2 p) {
 
   // ---- epilogue: acc[mt][nt][r] = dW[a0 + wa*64 + mt*16 + (lane>>4)*4 + r][(ky*4+kx)*cb + b0 + nt*16 + (lane&15)]
   const int64_t ldw = (int64_t)16 * p.cb;
-  const int colb = (ky * 4 + kx) * p.cb + b0 + (lane & 15);
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int s2 = 0; s2 < NKY; ++s2) {
+    const int colb = ((ky + 2 * s2) * 4 + kx) * p.cb + b0 + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = a0 + wa * 64 + mt * 16 + (lane >> 4) * 4 + r;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int64_t o = (int64_t)row * ldw + colb + nt * 16;
-        const float v = acc[mt][nt][r] * p.scale;
-        if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
-        else if (p.direct) p.dW[o] += v;
-        else atomicAdd(p.dW + o, v);
+      for (int r = 0; r < 4; ++r) {
+        const int row = a0 + wa * 64 + mt * 16 + (lane >> 4) * 4 + r;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const int64_t o = (int64_t)row * ldw + colb + nt * 16;
+          const float v = acc[s2][mt][nt][r] * p.scale;
+          if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
+          else if (p.direct) p.dW[o] += v;
+          else atomicAdd(p.dW + o, v);
+        }
       }
-    }
+  }
 }
 
 // dW[i] += sum_k part[k][i] in a fixed order (as in wgrad.hip)
@@ -242,9 +261,15 @@ __global__ void __launch_bounds__(256) wgrad2_reduce_kernel(const float* __restr
   }
 }
 
+int wgrad2_nky() {   // GI_WGRAD2_NKY=1: one ky tap row per workgroup (tools: A/B)
+  static int nky = -1;
+  if (nky < 0) { const char* e = getenv("GI_WGRAD2_NKY"); nky = (e && atoi(e) == 1) ? 1 : 2; }
+  return nky;
+}
+
 int wgrad2_split(int n, int Hs, int Ws, int ca, int cb, int* tiles_per_split) {
   const int ntile = n * (Hs / 4) * (Ws / 16);
-  const int blocks = (ca / 128) * (cb / 64) * 4;
+  const int blocks = (ca / 128) * (cb / 64) * (4 / wgrad2_nky());
   int split = (256 + blocks - 1) / blocks;             // one 8-wave workgroup per CU
   if (split > ntile / 8) split = ntile / 8;
   if (split < 1) split = 1;
@@ -287,9 +312,15 @@ int op_wgrad2(hipStream_t st, const WgradArgs& a) {
   if (split > 1 && a.scratch && a.scratch_bytes >= (int64_t)split * out_floats * 4) p.part = a.scratch;
   constexpr int LDS = 3 * (2 * 64 * 128 + 192 * 128);
   static bool attr = false;
-  if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr = true; }
-  const dim3 grid((a.ca / 128) * (a.cb / 64) * 4, split);
-  hipLaunchKernelGGL(wgrad2_kernel, grid, dim3(512), LDS, st, p);
+  if (!attr) {
+    GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr = true;
+  }
+  const int nky = wgrad2_nky();
+  const dim3 grid((a.ca / 128) * (a.cb / 64) * (4 / nky), split);
+  if (nky == 2) hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(512), LDS, st, p);
+  else hipLaunchKernelGGL(wgrad2_kernel<1>, grid, dim3(512), LDS, st, p);
   GI_LAUNCH_CHECK();
   if (p.part) {
     const int64_t c4 = out_floats / 4;

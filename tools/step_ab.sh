@@ -1,16 +1,16 @@
 #!/bin/bash
 # Kernel chain of one WGAN batch WITH a generator update on one stream (256x256, bs=32, fp16) under rocprofv3.
-# usage: tools/step_ab.sh <tag>   (through gpurun) -> gpurun_out/step_<tag>/chain.txt + per-kernel-class summary
+# usage: tools/step_ab.sh <tag> [gen|critic]   (through gpurun) -> gpurun_out/step_<tag>/chain.txt + per-kernel-class summary
 set -o pipefail
 TAG=${1:-x}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/step_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/step_chain.py 4 > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
+rocprofv3 --kernel-trace --output-format csv -d $OUT -- python3 $R/tools/step_chain.py 4 ${2:-gen} > $OUT/run.log 2>&1 || { tail -5 $OUT/run.log; exit 1; }
 CSV=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python3 $R/tools/chain_table.py $CSV mask_apply > $OUT/chain.txt
-tail -1 $OUT/chain.txt; grep "batch with" $OUT/run.log
+tail -1 $OUT/chain.txt; grep "^batch " $OUT/run.log
 python3 - $OUT/chain.txt <<'PY'
 import re,sys,collections
 agg=collections.defaultdict(lambda:[0,0.0])
