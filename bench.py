@@ -83,8 +83,7 @@ def cpu_baseline():
     """The oracle's WGAN schedule (oracle/torch_ref.wgan_step, fp32) on the host cores at the GPU workload's own batch,
     bs=32 at 256x256: critic-only batches and one batch with a generator update, combined 4:1 like the GPU cadence. A bs=32
     batch takes several seconds on the box's host cores, so the sample is 1 warm-up + 2 critic-only + 1 generator-update
-    batch (stated in `sample`); a second figure restricts torch to 8 threads (the reference's own
-    CPU-runnable setting) on bs=8."""
+    batch (stated in `sample`), repeated at 8 threads, 32 and all host threads."""
     import numpy as np
     from oracle import params as op
     from oracle import torch_ref as orc
@@ -108,19 +107,24 @@ def cpu_baseline():
             t.append((time.perf_counter() - t0) / reps)
         return n / (((G_EVERY - 1) * t[0] + t[1]) / G_EVERY), t
 
+    # the oracle is torch-CPU code: its throughput peaks well below the box's core count (measured on the 128-core GPU host:
+    # 8 threads beat 128 by 4x at this size), so the same sample runs at 8, 32 and all threads and the best is the baseline
     threads = torch.get_num_threads()
-    v, t = run(BS, 1, 2, 1)
-    out = dict(value=v, unit="images/sec", cores=threads, kind="port",
+    sweep = {}
+    try:
+        for nt in sorted({min(8, threads), min(32, threads), threads}):
+            torch.set_num_threads(nt)
+            v, t = run(BS, 1, 2, 1)
+            sweep[nt] = (v, t)
+    finally:
+        torch.set_num_threads(threads)
+    best = max(sweep, key=lambda k: sweep[k][0])
+    v, t = sweep[best]
+    out = dict(value=v, unit="images/sec", cores=best, kind="port",
                sample=f"oracle/torch_ref.wgan_step fp32, bs={BS} at {H}x{W}: 1 warm-up + 2 critic-only batches ({t[0]:.2f} s each) "
-                      f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1 (reduced from 10 + 3 batches to keep the default run short)")
-    if threads > 8:
-        torch.set_num_threads(8)
-        try:
-            v8, t8 = run(8, 0, 1, 1)
-            out["threads8"] = dict(value=v8, unit="images/sec", cores=8,
-                                   sample=f"same, torch.set_num_threads(8), bs=8: 1 critic-only batch ({t8[0]:.2f} s) + 1 batch with G update ({t8[1]:.2f} s)")
-        finally:
-            torch.set_num_threads(threads)
+                      f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1 (reduced from 10 + 3 batches to keep the default run short); "
+                      f"torch threads swept, best shown",
+               sweep={str(k): round(sweep[k][0], 3) for k in sorted(sweep)})
     return out
 
 
@@ -235,6 +239,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preheat", type=int, default=400, help="untimed steps before the W warm-up steps (clock ramp of a cold GPU)")
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512", "config5_512", "dual_d_256"],
                     help="ssim_256 = the per-batch SSIM metric of experiment1_global_local_D.py:209 at 256x256 bs=32 (SURVEY 8f rank 2); wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
@@ -317,7 +322,10 @@ def main():
         torch.cuda.synchronize()
 
     it = 0
-    for _ in range(args.warmup):
+    # A cold MI355X (first process on an idle box) runs the first second or so at reduced clocks: measured 3.39 ms/step for
+    # the first process against 2.50 ms/step for the same binary started right after it. The same untimed steps as the W
+    # warm-up ones, a fixed number of them (all ranks issue the same collectives), bring the card to its steady state first.
+    for _ in range(args.preheat + args.warmup):
         g, m = batches[it % len(batches)]
         step_fn(g, m, it % G_EVERY == G_EVERY - 1, it)
         it += 1
