@@ -24,6 +24,7 @@ PROTOTYPES = {
     "gi_unet_create": (_i, [_vp, _i, _i, _f, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "gi_unet_create_ex": (_i, [_vp, _i, _i, _i, _f, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "gi_unet_create_norm": (_i, [_vp, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "gi_unet_create_padded": (_i, [_vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "gi_patchgan_create": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(_vp)]),
     "gi_net_destroy": (_i, [_vp]),
     "gi_net_tensor_count": (_i, [_vp]),

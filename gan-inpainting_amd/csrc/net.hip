@@ -167,13 +167,17 @@ int64_t part_rows(int64_t pixels) { return max64(pixels / 64 + 8, 1100); }
 // =================================================================================================
 // creation
 // =================================================================================================
-extern "C" int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_c, int norm_kind, float dropout_p, int H, int W,
-                                   int max_n, int dtype, int n_slots, gi_net** out) {
+extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch1, int out_c, int norm_kind, float dropout_p, int H, int W,
+                                     int max_n, int dtype, int n_slots, gi_net** out) {
   GI_REQUIRE(out, "unet_create: null argument");  // ctx may be null: inventory-only handle
   GI_REQUIRE(norm_kind >= 0 && norm_kind <= 2, "unet_create: norm_kind=%d (0 batch, 1 instance, 2 none)", norm_kind);
+  GI_REQUIRE(ch1 == 0 || (ch1 >= ngf && ch1 % 64 == 0), "unet_create: ch1=%d must be 0 or a multiple of 64 >= ngf", ch1);
   GI_REQUIRE(dtype == GI_F16 || dtype == GI_F32, "unet_create: dtype=%d", dtype);
   GI_REQUIRE(num_downs >= 5 && num_downs <= 9, "unet_create: num_downs=%d (supported 5..9)", num_downs);
-  if (ctx) GI_REQUIRE(ngf % 64 == 0 && ngf >= 64, "unet_create: ngf=%d must be a multiple of 64", ngf);
+  // the GEMM kernels take channel counts that are multiples of 64: every level must qualify. ngf = 32 does from level 2 on
+  // (64, 128, 256, ...); its level 1 is then computed ch1 = 64 channels wide with the upper half zero (gi_unet_create_padded)
+  if (ctx) GI_REQUIRE(ngf >= 32 && (2 * ngf) % 64 == 0 && ((ch1 ? ch1 : ngf) % 64 == 0),
+                      "unet_create: ngf=%d ch1=%d: every level needs a multiple of 64 channels (ngf a multiple of 64, or of 32 with ch1)", ngf, ch1);
   else GI_REQUIRE(ngf % 8 == 0 && ngf >= 8, "unet_create: ngf=%d must be a multiple of 8 (inventory-only handle)", ngf);
   GI_REQUIRE(out_c >= 1 && out_c <= 64, "unet_create: out_c=%d (1..64)", out_c);
   GI_REQUIRE(gi_is_pow2(H) && gi_is_pow2(W) && (H >> num_downs) >= 1 && (W >> num_downs) >= 1,
@@ -190,7 +194,7 @@ extern "C" int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_
   for (int k = 1; k <= nd; ++k) {
     int m = 1 << (k - 1);
     if (m > 8) m = 8;
-    net->ch[k] = ngf * m;
+    net->ch[k] = (k == 1 && ch1) ? ch1 : ngf * m;
     net->Hk[k] = H >> k;
     net->Wk[k] = W >> k;
   }
@@ -330,6 +334,11 @@ extern "C" int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
   return GI_OK;
+}
+
+extern "C" int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_c, int norm_kind, float dropout_p, int H, int W,
+                                   int max_n, int dtype, int n_slots, gi_net** out) {
+  return gi_unet_create_padded(ctx, num_downs, ngf, 0, out_c, norm_kind, dropout_p, H, W, max_n, dtype, n_slots, out);
 }
 
 extern "C" int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float dropout_p, int H, int W, int max_n,

@@ -390,6 +390,8 @@ class UnetGenerator(HipNet):
             return EmbeddedUnetGenerator(input_nc, output_nc, num_downs, ngf, *args, **kw)
         return super().__new__(cls)
 
+    _ch1 = 0     # physical width of level 1 (0: ngf); set by _PaddedUnetGenerator
+
     def __init__(self, input_nc=1, output_nc=1, num_downs=7, ngf=64, norm_layer=nn.BatchNorm2d, use_dropout=False,
                  use_sigmoid_output=False, dtype=None):
         super().__init__(dtype)
@@ -405,8 +407,8 @@ class UnetGenerator(HipNet):
         lib = B.lib()
         h = C.c_void_p()
         size0 = 1 << max(num_downs, 7)
-        B.check(lib.gi_unet_create_norm(None, num_downs, ngf, output_nc, self.norm_kind, self.dropout_p, size0, size0, 1, self._dtype, 1,
-                                        C.byref(h)))
+        B.check(lib.gi_unet_create_padded(None, num_downs, ngf, self._ch1, output_nc, self.norm_kind, self.dropout_p, size0, size0, 1,
+                                          self._dtype, 1, C.byref(h)))
         self._build_tree(self._inventory(h), lib.gi_net_param_floats(h), lib.gi_net_buffer_floats(h))
         lib.gi_net_destroy(h)
         self.reset_parameters()
@@ -446,8 +448,8 @@ class UnetGenerator(HipNet):
 
     def _create_handle(self, ctx, H, W, max_n):
         h = C.c_void_p()
-        B.check(B.lib().gi_unet_create_norm(ctx, self.num_downs, self.ngf, self.output_nc, self.norm_kind, self.dropout_p, H, W, max_n,
-                                            self._dtype, self.n_slots, C.byref(h)))
+        B.check(B.lib().gi_unet_create_padded(ctx, self.num_downs, self.ngf, self._ch1, self.output_nc, self.norm_kind, self.dropout_p, H, W,
+                                              max_n, self._dtype, self.n_slots, C.byref(h)))
         if getattr(self, "_drop_seed", None) is not None:      # a seed chosen before the handle existed
             B.check(B.lib().gi_net_set_dropout_seed(h, self._drop_seed))
         return h
@@ -496,15 +498,23 @@ class UnetGenerator(HipNet):
         self._pending_masks = dict(masks)
 
 
+class _PaddedUnetGenerator(UnetGenerator):
+    """UnetGenerator(ngf=32) on the device: level 1 is 64 channels wide (upper 32 zero), every other level has its true
+    width (64, 128, 256, ...): gi_unet_create_padded. The tensors that touch level 1 have the padded shapes."""
+    _ch1 = 64
+
+
 class EmbeddedUnetGenerator(nn.Module):
     """UnetGenerator whose width is not a multiple of 64 (the reference's face-parsing network has ngf=32,
-    train.py:171-172), run on the ngf'=64*ceil(ngf/64) kernels by zero-embedding: every channel axis is padded
-    with zero weights, BatchNorm of the padded channels has weight = bias = running_mean = 0 and
-    running_var = 1, and the two halves of a skip concatenation are embedded separately. Padded channels carry
-    exact zeros through convolutions, BatchNorm, LeakyReLU/ReLU and their gradients, so outputs and input
-    gradients equal the narrow network's (tests/test_segnet_gpu.py); the cost is (ngf'/ngf)^2 x the FLOPs -
-    native narrow kernels are the next step. state_dict()/load_state_dict() speak the NARROW shapes and the
-    reference's key names."""
+    train.py:171-172) on kernels whose channel counts are multiples of 64, by zero-embedding: padded channel axes get zero
+    weights, BatchNorm of the padded channels has weight = bias = running_mean = 0 and running_var = 1, and the two halves
+    of a skip concatenation are embedded separately. Padded channels carry exact zeros through convolutions, BatchNorm,
+    LeakyReLU/ReLU and their gradients, so outputs and input gradients equal the narrow network's
+    (tests/test_segnet_gpu.py).
+      * ngf = 32: only level 1 (32 channels) is below the granularity - that level alone is padded to 64, levels 2..7 run
+        at their true widths 64, 128, 256, ... (gi_unet_create_padded): 1.15x the narrow network's FLOPs;
+      * other widths: every level is widened to ngf' = 64*ceil(ngf/64) ((ngf'/ngf)^2 x the FLOPs).
+    state_dict()/load_state_dict() speak the NARROW shapes and the reference's key names."""
 
     def __init__(self, input_nc=1, output_nc=1, num_downs=7, ngf=32, norm_layer=nn.BatchNorm2d, use_dropout=False,
                  use_sigmoid_output=False, dtype=None):
@@ -522,23 +532,26 @@ class EmbeddedUnetGenerator(nn.Module):
         lib.gi_net_destroy(h)
         # draw the narrow network's initial weights exactly like the reference constructor, then embed
         probe = _NarrowInit(self._narrow, num_downs)
-        self.phys = UnetGenerator(input_nc, output_nc, num_downs, self.ngf_phys, norm_layer, use_dropout, use_sigmoid_output, dtype)
+        if ngf == 32:     # only level 1 is narrower than the kernels' 64-channel granularity: pad that level alone (1.15x the FLOPs, not 4x)
+            self.phys = _PaddedUnetGenerator(input_nc, output_nc, num_downs, ngf, norm_layer, use_dropout, use_sigmoid_output, dtype)
+        else:
+            self.phys = UnetGenerator(input_nc, output_nc, num_downs, self.ngf_phys, norm_layer, use_dropout, use_sigmoid_output, dtype)
+        self._phys_shapes = {k: tuple(v.shape) for k, v in self.phys.state_dict().items()}
         self.load_state_dict(probe.state, strict=True)
 
     # channel index maps narrow -> physical per tensor axis
     def _axis_maps(self, name, shape):
-        ch = lambda k: self.ngf * min(2 ** (k - 1), 8)          # noqa: E731  channels of level k (narrow)
-        r = self.ngf_phys // self.ngf
+        pshape = self._phys_shapes[name]                        # the physical tensor: each axis at least as long
         def plain(c):
             return torch.arange(c)
-        def halves(c):                                          # [skip | decoder] concat of two c/2 blocks
+        def halves(c, cphys):                                   # [skip | decoder] concat of two c/2 blocks (physical: cphys/2 each)
             h = c // 2
-            return torch.cat([torch.arange(h), r * h + torch.arange(h)])
+            return torch.cat([torch.arange(h), cphys // 2 + torch.arange(h)])
         is_up_conv = name.endswith(".weight") and len(shape) == 4 and name in self._up_names()
         maps = []
         for ax, c in enumerate(shape[:2] if len(shape) == 4 else shape):
             if len(shape) == 4 and is_up_conv and ax == 0 and name != self._up_names()[-1]:
-                maps.append(halves(c))                          # ConvTranspose2d in-channels = concat (all but the innermost)
+                maps.append(halves(c, pshape[ax]))              # ConvTranspose2d in-channels = concat (all but the innermost)
             else:
                 maps.append(plain(c))
         return maps

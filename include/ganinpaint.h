@@ -73,6 +73,13 @@ int gi_unet_create_ex(gi_ctx* ctx, int num_downs, int ngf, int out_c, float drop
  * unfused building blocks (no inference folding, no fused head). */
 int gi_unet_create_norm(gi_ctx* ctx, int num_downs, int ngf, int out_c, int norm_kind, float dropout_p, int H,
                         int W, int max_n, int dtype, int n_slots, gi_net** out);
+/* The same with level 1 (the outermost block's ngf channels) computed ch1 channels wide, ch1 a multiple of 64 >= ngf
+ * (0: ngf): the inventory then reports [ch1, 1, 4, 4], [2 ngf, ch1, 4, 4], ... for the tensors that touch level 1; a
+ * caller holding a narrower network (UnetGenerator(1, 4, 7, ngf=32), train.py:171-172) zero-fills the extra rows /
+ * columns - zero channels stay zero through BatchNorm (beta 0) and the activations -, every other level runs at its
+ * true width. */
+int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch1, int out_c, int norm_kind, float dropout_p,
+                          int H, int W, int max_n, int dtype, int n_slots, gi_net** out);
 /* PatchGANDiscriminator(c=1, sigmoid): Linear(25,1) generalised to ((H/16-3)*(W/16-3),1). */
 int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots,
                        gi_net** out);
