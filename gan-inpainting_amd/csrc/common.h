@@ -114,6 +114,16 @@ struct IgemmArgs {
   // tile t adds to replica t mod stat_reps). stat_pg > 0: the GEMM rows (small-grid pixels) are two consecutive BatchNorm
   // populations of stat_pg rows each (a multiple of 256), rows >= stat_pg add to group 1. Takes precedence over `partials`.
   unsigned long long* stat_acc; int stat_pg; int stat_reps;
+  // optional fused BatchNorm-backward reduction (input-gradient GEMMs whose result g is the gradient w.r.t. the output of
+  // BatchNorm + LeakyReLU(bwd_slope) of a layer with the raw convolution output bwd_x, laid out like out with ld = bwd_ldx):
+  // every tile adds sum dz and sum dz * xhat, dz = g * (fma(x, scale, shift) > 0 ? 1 : slope), xhat = (x - mean) * inv, to the
+  // accumulator block bwd_acc (quantities 0 / 1, stat_acc.h; replicas / populations as stat_reps / stat_pg, here counted in
+  // OUTPUT pixels). Kernels that implement it set bwd_applied = 1: the caller then skips the reduce pass of op_act_bn_bwd.
+  const void* bwd_x; int bwd_ldx;
+  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
+  float bwd_slope;
+  unsigned long long* bwd_acc; int bwd_reps; int64_t bwd_pg;
+  int bwd_applied;
   int stat_used;   // (returned) 1: the statistics went to stat_acc; 0: to `partials` (split-K layers: their finish pass
                    // has few rows per block, the partial rows + finalize launch are cheaper there than 4 atomics per channel)
 };
@@ -211,6 +221,7 @@ struct ActBnBwdArgs {
   // non-null (has_bn): exact accumulator block (stat_acc.h, zeroed, acc_reps replicas): the reduce pass adds into it and the
   // apply pass derives its coefficients itself - two launches instead of three; the apply pass then clears zero_next.
   unsigned long long* acc; int acc_reps; unsigned long long* zero_next; int zero_words;
+  int reduce_done;                    // 1: the sums are already in acc (IgemmArgs::bwd_acc, added by the producing GEMM's epilogue)
 };
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a);
 int op_bwd_rows_per_block(int64_t pixels);

@@ -1271,7 +1271,7 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   p.zero_next = nullptr; p.zero_words = 0;
   static int small_max = -1;   // GI_BN_BWD_SMALL: largest pixel count served by the one-launch kernel (0: off; tools: A/B)
   if (small_max < 0) { const char* e = getenv("GI_BN_BWD_SMALL"); small_max = e ? atoi(e) : 512; if (small_max > 2048) small_max = 2048; }
-  if (a.has_bn && !a.eval_bn && groups == 1 && a.pixels <= small_max) {
+  if (a.has_bn && !a.eval_bn && groups == 1 && a.pixels <= small_max && !a.reduce_done) {
     p.zero_next = a.acc ? a.zero_next : nullptr; p.zero_words = a.acc ? a.zero_words : 0;   // (keeps the accumulator ping-pong of net.hip consistent)
     const int nit = (int)((a.pixels + 255) / 256);
 #define GI_SMALL(T) do { if (nit <= 1) hipLaunchKernelGGL((act_bn_bwd_small_kernel<T, 1>), dim3(Q), dim3(256), 0, st, p); \
@@ -1291,9 +1291,11 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
       GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
                  (long long)p.pg, p.rows_per_block);
       p.acc = a.acc;
-      if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks * groups), dim3(256), 0, st, p);
-      else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
-      GI_LAUNCH_CHECK();
+      if (!a.reduce_done) {
+        if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks * groups), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
+        GI_LAUNCH_CHECK();
+      }
       p.zero_next = a.zero_next; p.zero_words = a.zero_words;
     } else {
       p.dgamma = nullptr; p.dbeta = nullptr;

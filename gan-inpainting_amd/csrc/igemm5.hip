@@ -47,6 +47,11 @@ struct KP5 {
   int ntiles;
   const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
   const char* add; int ldadd, coffadd;
+  // fused BatchNorm-backward reduction (IgemmArgs::bwd_*)
+  const char* bwd_x; int bwd_ldx;
+  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
+  float bwd_slope;
+  unsigned long long* bwd_acc; int bwd_reps; int bwd_pg_tiles;   // bwd_pg_tiles: M tiles per BatchNorm population (0: one population)
 };
 
 __device__ __forceinline__ float act5(float v, int act) {
@@ -150,12 +155,35 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
   }
   constexpr int CPRO = BN / 8;
   const int oc = tid % CPRO;
+  // fused BatchNorm-backward reduction: this thread's 8 channels are fixed (oc), its rows vary
+  const bool bwd = !DUAL && p.bwd_acc != nullptr;
+  float bsc[8], bsh[8], bmu[8], biv[8], bs[8], bsx[8];
+  if (bwd) {
+    const int go = (p.bwd_pg_tiles > 0 && mt_idx >= p.bwd_pg_tiles) ? p.bwd_stride : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = go + n0 + oc * 8 + e;
+      bsc[e] = p.bwd_scale[ch]; bsh[e] = p.bwd_shift[ch]; bmu[e] = p.bwd_mean[ch]; biv[e] = p.bwd_inv[ch];
+      bs[e] = bsx[e] = 0.f;
+    }
+  }
 #pragma unroll 1
   for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
     const int64_t opx = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
     const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
     const int64_t o = opx * p.ldout + p.coffout + och;
     u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+    if (bwd) {
+      const h8_t xv = *(const h8_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
+      const h8_t gv = __builtin_bit_cast(h8_t, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xf = (float)xv[e];
+        const float dz = (float)gv[e] * (fmaf(xf, bsc[e], bsh[e]) > 0.f ? 1.f : p.bwd_slope);
+        bs[e] += dz;
+        bsx[e] = fmaf(dz, (xf - bmu[e]) * biv[e], bsx[e]);
+      }
+    }
     if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
       const h8_t m = *(const h8_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
       h8_t hv = __builtin_bit_cast(h8_t, v);
@@ -174,6 +202,30 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
       v = __builtin_bit_cast(u4_t, hv);
     }
     *(u4_t*)(p.out + o * 2) = v;
+  }
+  if (bwd) {
+    // lanes oc, oc + 16, oc + 32, oc + 48 of a wave hold the same channels (CPRO = 16): fold them, then the 8 waves through LDS
+    static_assert(DUAL || CPRO == 16 || CPRO == 8, "CPRO");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int off = CPRO; off < 64; off <<= 1) { bs[e] += __shfl_xor(bs[e], off); bsx[e] += __shfl_xor(bsx[e], off); }
+    }
+    __syncthreads();      // the staged tile has been read by every thread
+    float* fold = (float*)smem;   // [8 waves][BN][2]
+    if (lane < CPRO) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { fold[((tid >> 6) * BN + oc * 8 + e) * 2] = bs[e]; fold[((tid >> 6) * BN + oc * 8 + e) * 2 + 1] = bsx[e]; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { s += fold[(w * BN + tid) * 2]; q += fold[(w * BN + tid) * 2 + 1]; }
+      const int grp = (p.bwd_pg_tiles > 0 && mt_idx >= p.bwd_pg_tiles) ? 1 : 0, rep = (mt_idx + (MODE == 1 ? ph : 0)) & (p.bwd_reps - 1);
+      gi_stat_add(p.bwd_acc, p.cout, rep, grp, 0, n0 + tid, s);
+      gi_stat_add(p.bwd_acc, p.cout, rep, grp, 1, n0 + tid, q);
+    }
   }
 }
 
@@ -713,6 +765,17 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
   kp.mask = (const char*)a.mask; kp.ldmask = a.ldmask; kp.coffmask = a.coffmask; kp.mask_slope = a.mask_slope;
   kp.add = a.mask ? (const char*)a.add : nullptr; kp.ldadd = a.ldadd; kp.coffadd = a.coffadd;
+  kp.bwd_acc = nullptr;
+  if (a.bwd_acc && mode != 2 && a.cout % 128 == 0 && BN == 128) {   // (the dual-px / 64-column tiles do not take it)
+    const int64_t px_per_tile = 256 * (mode == 1 ? 4 : 1);          // output pixels per M tile over all phases
+    GI_REQUIRE(a.bwd_ldx % 8 == 0 && out_px * a.bwd_ldx < (1ll << 31) && (a.bwd_pg == 0 || a.bwd_pg % px_per_tile == 0) && a.coffout == 0,
+               "igemm5: fused BatchNorm-backward reduction: layout");
+    kp.bwd_x = (const char*)a.bwd_x; kp.bwd_ldx = a.bwd_ldx;
+    kp.bwd_scale = a.bwd_scale; kp.bwd_shift = a.bwd_shift; kp.bwd_mean = a.bwd_mean; kp.bwd_inv = a.bwd_inv; kp.bwd_stride = a.bwd_stride;
+    kp.bwd_slope = a.bwd_slope; kp.bwd_acc = a.bwd_acc; kp.bwd_reps = a.bwd_reps > 0 ? a.bwd_reps : 1;
+    kp.bwd_pg_tiles = a.bwd_pg > 0 ? (int)(a.bwd_pg / px_per_tile) : 0;
+    a.bwd_applied = 1;
+  }
   if (a.mask) {
     GI_REQUIRE(a.ldmask % 8 == 0 && a.coffmask % 8 == 0 && out_px * a.ldmask < (1ll << 31), "igemm5: mask layout");
     GI_REQUIRE(!a.add || (a.ldadd % 8 == 0 && a.coffadd % 8 == 0 && out_px * a.ldadd < (1ll << 31)), "igemm5: add layout");

@@ -43,6 +43,18 @@ struct BN {
   int64_t acc_block() const { return gi_stat_block_words(c, GI_STAT_MAXREP); }
 };
 
+// BatchNorm-backward reduction fused into the GEMM that produces the gradient (IgemmArgs::bwd_*): fixed BEFORE that GEMM
+// runs (the accumulator ping-pong state moves here), consumed by act_bn_bwd, which then launches only its apply pass - or
+// both passes on the same accumulator block when the kernel that ran did not take the fusion (`applied` false).
+struct BwdFuse {
+  bool planned = false, applied = false;
+  unsigned long long* acc = nullptr; unsigned long long* zero_next = nullptr;
+  int zero_words = 0, reps_gemm = 1, reps_reduce = 1, groups = 1;
+  const void* x = nullptr; int ldx = 0;
+  const float* scale = nullptr; const float* shift = nullptr; const float* mean = nullptr; const float* inv = nullptr;
+  int stride = 0; float slope = 1.f; int64_t pg = 0;
+};
+
 struct Arena {
   int64_t size = 0;
   int64_t take(int64_t bytes) {
@@ -113,6 +125,7 @@ struct gi_net {
   // consuming passes. GI_BN_ACC=0 restores partial rows + finalize / sums launches.
   int64_t oAcc = -1, acc_words = 0;
   int use_acc = 1;
+  std::vector<BwdFuse> bwd_pending;  // per BatchNorm id: a reduction planned / done by the producing GEMM, waiting for act_bn_bwd
   int64_t oTickets = -1;             // split-K fix-up counters (IgemmArgs::tickets): zero at bind, zero after every launch
   // gradient-penalty scratch (patchgan): stacked 2n tensors, see patchgan_gradient_penalty
   int64_t oA2[5] = {-1, -1, -1, -1, -1}, oG2[5] = {-1, -1, -1, -1, -1}, oTX[5] = {-1, -1, -1, -1, -1};
@@ -330,6 +343,7 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
   net->slot_fused_u2.assign(n_slots, 0);
   net->slot_inference.assign(n_slots, 0);
   net->eval_gen.assign(n_slots, std::vector<uint64_t>(nbn, 0));
+  net->bwd_pending.assign(nbn, BwdFuse());
   { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }   // 0: materialise the last decoder level (tools: A/B)
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
@@ -439,6 +453,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   int64_t stat_floats = 0;
   for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 2 * 4 * net->dbn[i].c; net->dbn[i].id = i - 2; }   // x2: BN groups
   net->eval_gen.assign(n_slots + 1, std::vector<uint64_t>(3, 0));
+  net->bwd_pending.assign(3, BwdFuse());
   net->oStats = S.take(stat_floats * 4);
   net->slot_bytes = S.size;
   for (int i = 2; i <= 4; ++i) { net->dbn[i].acc_off = net->acc_words; net->acc_words += 4 * net->dbn[i].acc_block(); }
@@ -696,14 +711,49 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
   return GI_OK;
 }
 
+// pixels: rows of the BatchNorm'd tensor; gemm_tiles: workgroups of the producing GEMM that will add (tiles x phases)
+BwdFuse bwd_fuse_plan(gi_net* net, int slot, const BN& bn, const void* x, int64_t pixels, int64_t gemm_tiles, float slope) {
+  BwdFuse f;
+  static int on = -1;   // GI_BN_BWD_FUSE=0: reduce pass as a separate launch (tools: A/B)
+  if (on < 0) { const char* e = getenv("GI_BN_BWD_FUSE"); on = e ? atoi(e) : 1; }
+  const int g = net->kind == 1 ? net->bn_groups : 1;
+  if (!on || !net->use_acc || bn.acc_off < 0 || net->bwd_eval || net->dtype != GI_F16) return f;
+  const int64_t pg = pixels / g;
+  if (g == 2) {   // the same condition under which act_bn_bwd reduces both populations in one launch
+    const int rpb = op_bwd_rows_per_block(pg);
+    if (pixels % 2 != 0 || pg % rpb != 0 || (2 * (pg / rpb)) * 2 * bn.c > net->part_floats) return f;
+  }
+  const int64_t blocks = (pg + op_bwd_rows_per_block(pg) - 1) / op_bwd_rows_per_block(pg);
+  unsigned long long* base = (unsigned long long*)net->shared(net->oAcc) + bn.acc_off + 2 * bn.acc_block();
+  f.planned = true;
+  f.groups = g;
+  f.acc = base + bn.bwd_par * bn.acc_block();
+  f.reps_gemm = stat_reps_for(gemm_tiles);
+  f.reps_reduce = stat_reps_for(blocks);
+  const int other = 2 + (bn.bwd_par ^ 1);
+  f.zero_words = (int)gi_stat_block_words(bn.c, bn.dirty[other]);
+  f.zero_next = f.zero_words > 0 ? base + (bn.bwd_par ^ 1) * bn.acc_block() : nullptr;
+  bn.dirty[other] = 0;
+  bn.dirty[2 + bn.bwd_par] = f.reps_gemm > f.reps_reduce ? f.reps_gemm : f.reps_reduce;
+  bn.bwd_par ^= 1;
+  BNPtrs p0 = bn_ptrs(net, slot, bn, 0);
+  f.x = x; f.ldx = bn.c; f.scale = p0.scale; f.shift = p0.shift; f.mean = p0.mean; f.inv = p0.inv; f.stride = 4 * bn.c;
+  f.slope = slope; f.pg = g == 2 ? pg : 0;
+  return f;
+}
+
 // mask / ldmask / mask_slope / mask_applied: IgemmArgs::mask (activation backward fused into an input-gradient GEMM)
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
-          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr) {
+          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr, BwdFuse* bf = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; a.stat_reps = sp->reps; }
+  if (bf && bf->planned) {
+    a.bwd_x = bf->x; a.bwd_ldx = bf->ldx; a.bwd_scale = bf->scale; a.bwd_shift = bf->shift; a.bwd_mean = bf->mean; a.bwd_inv = bf->inv;
+    a.bwd_stride = bf->stride; a.bwd_slope = bf->slope; a.bwd_acc = bf->acc; a.bwd_reps = bf->reps_gemm; a.bwd_pg = bf->pg;
+  }
   a.relu_cend = relu_cend;
   a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
   a.add = add; a.ldadd = ldadd; a.coffadd = 0;
@@ -718,6 +768,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   a.relu_in = relu_in; a.act_out = act_out;
   GI_TRY(op_igemm(net->ctx->stream, net->dtype, phase, a));
   if (mask_applied) *mask_applied = a.mask_applied;
+  if (bf && bf->planned) bf->applied = a.bwd_applied != 0;
   if (sp && sp->use && !a.stat_used) sp->use = false;
   if (ntiles) *ntiles = a.ntiles_out;
   if (stats) GI_REQUIRE((int64_t)a.ntiles_out * 2 * cout <= net->part_floats, "internal: partials buffer too small");
@@ -737,7 +788,7 @@ int wgrad(gi_net* net, const void* S, int ca, int ldS, int coffS, int relu_S, co
 
 int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, const void* g2, int ldg2, int coffg2,
                const void* y, int ldy, int coffy, const void* x, void* dx, int64_t pixels, int c, int act, float drop_scale,
-               const BN* bn, int need_wgrad) {
+               const BN* bn, int need_wgrad, const BwdFuse* pre = nullptr) {
   int g = (net->kind == 1 && bn) ? net->bn_groups : 1;   // BatchNorm groups: reductions per group
   int64_t pg = pixels / g;
   const int64_t T = (int64_t)net->tsz();
@@ -767,7 +818,13 @@ int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, cons
     a.inv_loss_scale = 1.f / net->loss_scale;
     a.partials = (float*)net->shared(net->oPart);
     a.sums = (float*)net->shared(net->oSums);
-    if (bn && net->use_acc && bn->acc_off >= 0 && (merged || g == 1)) {   // exact accumulators: no sums launch (stat_acc.h)
+    if (pre && pre->planned) {   // the accumulator block was chosen before the producing GEMM ran (bwd_fuse_plan)
+      GI_REQUIRE(bn && (merged || g == 1), "internal: fused BatchNorm-backward plan without the one-launch reduction");
+      a.acc = pre->acc;
+      a.acc_reps = pre->reps_gemm > pre->reps_reduce ? pre->reps_gemm : pre->reps_reduce;
+      a.zero_next = pre->zero_next; a.zero_words = pre->zero_words;
+      a.reduce_done = pre->applied ? 1 : 0;
+    } else if (bn && net->use_acc && bn->acc_off >= 0 && (merged || g == 1)) {   // exact accumulators: no sums launch (stat_acc.h)
       unsigned long long* base = (unsigned long long*)net->shared(net->oAcc) + bn->acc_off + 2 * bn->acc_block();
       a.acc = base + bn->bwd_par * bn->acc_block();
       if (!net->bwd_eval) {   // (a running-statistics backward adds nothing: the block stays clean)
@@ -1377,22 +1434,38 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
     hb.scale4 = p.scale; hb.shift4 = p.shift; hb.n_per_group = n / net->bn_groups; hb.gstride = 4 * 512;
   }
   hb.n = n; hb.Hh = net->Hh; hb.Wh = net->Wh; hb.c = 512; hb.sigmoid = net->sigmoid; hb.loss_scale = LS;
-  if (phase != 2) GI_TRY(op_head_backward(st, dt, hb));
+  if (phase != 2) {
+    // a reduction planned by an earlier, abandoned backward (phase 1 without its phase 2) left sums in its accumulator block
+    for (int i = 2; i <= 4; ++i) {
+      BwdFuse& pend = net->bwd_pending[net->dbn[i].id];
+      if (pend.planned) GI_HIP(hipMemsetAsync(pend.acc, 0, (size_t)net->dbn[i].acc_block() * 8, st));
+      pend = BwdFuse();
+    }
+    GI_TRY(op_head_backward(st, dt, hb));
+  }
   int lrelu1_done = 0;
   for (int i = 4; i >= 2; --i) {
     if (i == 4 ? phase == 2 : phase == 1) continue;
     const Conv& c = net->dconv[i];
     const int Hs = H >> i, Ws = W >> i;
     const int64_t pix = (int64_t)n * Hs * Ws;
+    BwdFuse& pend = net->bwd_pending[net->dbn[i].id];
     GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[i]), c.ca, 0, nullptr, 0, 0, net->slot(s, net->oA[i]), c.ca, 0, net->slot(s, net->oRd[i]),
-                      D, pix, c.ca, GI_ACT_LRELU, 1.f, &net->dbn[i], need_wgrad));
+                      D, pix, c.ca, GI_ACT_LRELU, 1.f, &net->dbn[i], need_wgrad, pend.planned ? &pend : nullptr));
+    pend = BwdFuse();
     if (need_wgrad)
       GI_TRY(wgrad(net, D, c.ca, c.ca, 0, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, net->grads + c.w_off));
     // conv1 has no BatchNorm: its LeakyReLU backward rides in the epilogue of conv2's input-gradient GEMM when the
     // kernel supports it (same arithmetic, one 3-tensor HBM pass less)
     const bool fuse1 = (i == 2);
+    // the gradient this GEMM produces enters BatchNorm + LeakyReLU of layer i - 1: its reduction rides in the GEMM's epilogue
+    BwdFuse* pbf = nullptr;
+    if (i >= 3) {
+      pbf = &net->bwd_pending[net->dbn[i - 1].id];
+      *pbf = bwd_fuse_plan(net, s, net->dbn[i - 1], net->slot(s, net->oRd[i - 1]), pix * 4, pix / 256 * 4, 0.2f);
+    }
     GI_TRY(igemm(net, 1, D, c.ca, c.ca, 0, phase_ptr(net, c), net->shared(net->ogA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, 0, GI_ACT_NONE, false,
-                 nullptr, 0, fuse1 ? net->slot(s, net->oA[1]) : nullptr, 64, 0.2f, fuse1 ? &lrelu1_done : nullptr));
+                 nullptr, 0, fuse1 ? net->slot(s, net->oA[1]) : nullptr, 64, 0.2f, fuse1 ? &lrelu1_done : nullptr, nullptr, 0, nullptr, nullptr, pbf));
   }
   if (phase == 1) return GI_OK;
   const int64_t pix = (int64_t)n * (H / 2) * (W / 2);
