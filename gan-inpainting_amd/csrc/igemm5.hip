@@ -167,7 +167,7 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
       bs[e] = bsx[e] = 0.f;
     }
   }
-#pragma unroll 1
+#pragma unroll 4
   for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
     const int64_t opx = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
     const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
