@@ -167,14 +167,30 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
       bs[e] = bsx[e] = 0.f;
     }
   }
-#pragma unroll 4
-  for (int r = tid / CPRO; r < BM; r += 512 / CPRO) {
-    const int64_t opx = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
-    const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
+  // A thread copies NR rows (one 16-byte chunk each). With a fused mask / add / BatchNorm reduction every row also needs global
+  // loads; issued row by row behind the previous row's store they run one latency at a time (the pointers may alias for the
+  // compiler) - 150 us for the critic's conv2 input gradient, whose epilogue moves 268 MB. All loads of the NR rows go first.
+  constexpr int NR = BM / (512 / CPRO);
+  int opxs[NR];
+  u4_t mk[NR], ad[NR], xs[NR];
+  const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int r = tid / CPRO + k * (512 / CPRO);
+    opxs[k] = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
+    const int64_t opx = opxs[k];
+    if (p.mask) mk[k] = *(const u4_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
+    if (p.mask && p.add) ad[k] = *(const u4_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
+    if (bwd) xs[k] = *(const u4_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
+  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int r = tid / CPRO + k * (512 / CPRO);
+    const int64_t opx = opxs[k];
     const int64_t o = opx * p.ldout + p.coffout + och;
     u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
     if (bwd) {
-      const h8_t xv = *(const h8_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
+      const h8_t xv = __builtin_bit_cast(h8_t, xs[k]);
       const h8_t gv = __builtin_bit_cast(h8_t, v);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -185,10 +201,10 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
       }
     }
     if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
-      const h8_t m = *(const h8_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
+      const h8_t m = __builtin_bit_cast(h8_t, mk[k]);
       h8_t hv = __builtin_bit_cast(h8_t, v);
       if (p.add) {
-        const h8_t a8 = *(const h8_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
+        const h8_t a8 = __builtin_bit_cast(h8_t, ad[k]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const bool pos = (float)m[e] > 0.f;
