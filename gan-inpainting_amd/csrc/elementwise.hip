@@ -1120,6 +1120,58 @@ __global__ void __launch_bounds__(256) pack_batch_kernel(PackJobs P) {
   }
 }
 
+// The same on 64 x 64 tiles with four values per lane (layers whose channel counts are multiples of 64, i.e. every layer of the
+// generator and the critic but the single-channel ones): 128-byte rows on both fp16 copies instead of 64-byte ones, a quarter of
+// the workgroups.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_batch64_kernel(PackJobs P) {
+  __shared__ float tile[64][65];
+  int jb = 0;
+  while (jb + 1 < P.n && (int)blockIdx.x >= P.j[jb + 1].tile0) ++jb;
+  const float* w = P.j[jb].w;
+  T* packed = (T*)P.j[jb].packed;
+  T* wph = (T*)P.j[jb].phase;
+  const int ca = P.j[jb].ca, cb = P.j[jb].cb, tiles_a = ca / 64, tiles_b = cb / 64;
+  int t = (int)blockIdx.x - P.j[jb].tile0;
+  const int a0 = (t % tiles_a) * 64;
+  t /= tiles_a;
+  const int b0 = (t % tiles_b) * 64, k16 = t / tiles_b;   // k16 = ph*4 + tap
+  const int ph = k16 >> 2, tp = k16 & 3;
+  const int ky = 1 - (ph >> 1) + 2 * (tp >> 1), kx = 1 - (ph & 1) + 2 * (tp & 1);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // 16 x 16, four consecutive values per lane
+  const float* sc = P.j[jb].scale;
+  const int on_b = P.j[jb].scale_on_b;
+  for (int r = ty; r < 64; r += 16) {
+    const int a = a0 + r, b = b0 + tx * 4;
+    const int64_t idx = ((int64_t)a * 16 + ky * 4 + kx) * cb + b;
+    f4_t v = *(const f4_t*)(w + idx);
+    if (sc) {
+      if (on_b) v *= *(const f4_t*)(sc + b);
+      else v *= sc[a];
+    }
+    if (packed) {
+      T o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (T)v[e];
+      if constexpr (sizeof(T) == 2) *(uint2*)(packed + idx) = *(const uint2*)o;
+      else *(f4_t*)(packed + idx) = *(const f4_t*)o;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[r][tx * 4 + e] = v[e];
+  }
+  __syncthreads();
+  if (!wph) return;
+  for (int r = ty; r < 64; r += 16) {
+    const int b = b0 + r, a = a0 + tx * 4;
+    T o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (T)tile[tx * 4 + e][r];
+    T* dst = wph + (((int64_t)ph * cb + b) * 4 + tp) * ca + a;
+    if constexpr (sizeof(T) == 2) *(uint2*)dst = *(const uint2*)o;
+    else *(f4_t*)dst = *(const f4_t*)o;
+  }
+}
+
 __global__ void __launch_bounds__(256) dropout_fill_kernel(uint8_t* mask, int64_t count, uint64_t seed, uint32_t thresh) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
     mask[i] = dropout_keep(seed, i, thresh);
@@ -1389,12 +1441,18 @@ int op_pack_weights(hipStream_t st, int dtype, const float* w, int ca, int cb, v
 int op_pack_weights_batch(hipStream_t st, int dtype, PackJobs& P) {
   if (P.n <= 0) return GI_OK;
   GI_REQUIRE(P.n <= 16, "pack_weights_batch: %d layers", P.n);
+  bool all64 = true;
+  for (int i = 0; i < P.n; ++i) all64 = all64 && P.j[i].ca % 64 == 0 && P.j[i].cb % 64 == 0;
+  const int ts = all64 ? 64 : 32;
   int tiles = 0;
   for (int i = 0; i < P.n; ++i) {
     P.j[i].tile0 = tiles;
-    tiles += ((P.j[i].ca + 31) / 32) * ((P.j[i].cb + 31) / 32) * 16;
+    tiles += ((P.j[i].ca + ts - 1) / ts) * ((P.j[i].cb + ts - 1) / ts) * 16;
   }
-  if (dtype == GI_F16) hipLaunchKernelGGL(pack_batch_kernel<half_t>, dim3(tiles), dim3(256), 0, st, P);
+  if (all64) {
+    if (dtype == GI_F16) hipLaunchKernelGGL(pack_batch64_kernel<half_t>, dim3(tiles), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(pack_batch64_kernel<float>, dim3(tiles), dim3(256), 0, st, P);
+  } else if (dtype == GI_F16) hipLaunchKernelGGL(pack_batch_kernel<half_t>, dim3(tiles), dim3(256), 0, st, P);
   else hipLaunchKernelGGL(pack_batch_kernel<float>, dim3(tiles), dim3(256), 0, st, P);
   GI_LAUNCH_CHECK();
   return GI_OK;
