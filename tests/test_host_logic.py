@@ -138,3 +138,31 @@ def test_norm_layer_argument_forms():
     assert torch.equal(a["model.model.1.model.3.model.3.model.3.model.1.weight"], inner_down.weight.detach())
     assert torch.equal(a["model.model.1.model.3.model.3.model.3.model.1.bias"], inner_down.bias.detach())
     assert torch.equal(a["model.model.1.model.3.model.3.model.3.model.3.bias"], inner_up.bias.detach())
+
+
+def test_padded_level1_inventory():
+    """gi_unet_create_padded (inventory-only handle): ngf = 32 with level 1 computed 64 channels wide - the tensors that touch
+    level 1 report the padded shapes, every other tensor the narrow network's (UnetGenerator(1, 4, 7, ngf=32), train.py:171-172)."""
+    import ctypes as C
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import backend as B
+    from gan_inpainting_amd.lib.models import networks
+    net = networks.UnetGenerator(1, 4, 7, ngf=32, use_dropout="False")
+    assert isinstance(net, networks.EmbeddedUnetGenerator) and isinstance(net.phys, networks._PaddedUnetGenerator)
+    phys = {k: tuple(v.shape) for k, v in net.phys.state_dict().items()}
+    narrow = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert phys["model.model.0.weight"] == (64, 1, 4, 4) and narrow["model.model.0.weight"] == (32, 1, 4, 4)
+    assert phys["model.model.1.model.1.weight"] == (64, 64, 4, 4) and narrow["model.model.1.model.1.weight"] == (64, 32, 4, 4)
+    assert phys["model.model.3.weight"] == (128, 4, 4, 4) and narrow["model.model.3.weight"] == (64, 4, 4, 4)
+    differ = sorted(k for k in narrow if phys[k] != narrow[k])
+    assert differ == sorted(["model.model.0.weight", "model.model.1.model.1.weight", "model.model.1.model.5.weight", "model.model.1.model.6.weight",
+                             "model.model.1.model.6.bias", "model.model.1.model.6.running_mean", "model.model.1.model.6.running_var",
+                             "model.model.3.weight"]), differ
+    # a narrow state_dict round-trips through the padded network
+    sd = {k: torch.randn(v.shape) if v.dtype.is_floating_point else v for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    back = net.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(back[k].cpu(), v), k
+    h = C.c_void_p()
+    assert B.lib().gi_unet_create_padded(None, 7, 32, 48, 4, 0, 0.0, 128, 128, 1, B.GI_F16, 1, C.byref(h)) != 0   # ch1 must be a multiple of 64

@@ -282,6 +282,31 @@ def test_patchgan_vs_oracle(dtype, cfg):
         assert fx["out_sig"].shape[1] == 1
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_unet_forward_and_input_gradient_are_reproducible(dtype):
+    """Split-K layers reduce inside the GEMM kernel: whichever workgroup arrives last adds the splits in split order, and the
+    BatchNorm statistics go through exact integer accumulators - so the forward output, the running statistics and the input
+    gradient repeat BIT FOR BIT from run to run (igemm7 / the generic kernel's fix-up, stat_acc.h). (Parameter gradients of the
+    layers whose weight-gradient kernel uses fp32 atomics are not part of this statement.)"""
+    nd, N, HW = 7, 3, 128
+    P = op.make_unet_params(777, num_downs=nd)
+    ground, mask = op.synth_batch(778, N, HW, HW)
+    runs = []
+    for _ in range(3):
+        net = make_unet(P, nd, dtype)
+        net.set_dropout_seed(5)
+        x = torch.from_numpy(ground * (1 - mask)).cuda().requires_grad_(True)
+        y = net(x)
+        y.sum().backward()
+        stats = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k}
+        runs.append((y.detach().cpu().clone(), x.grad.detach().cpu().clone(), stats))
+    for r in runs[1:]:
+        assert torch.equal(runs[0][0], r[0]), "forward output differs between runs"
+        assert torch.equal(runs[0][1], r[1]), "input gradient differs between runs"
+        for k in runs[0][2]:
+            assert torch.equal(runs[0][2][k], r[2][k]), k
+
+
 @pytest.mark.parametrize("cfg", [(64, 5), (256, 4), (512, 1)])
 def test_patchgan_head_gradients_are_reproducible(cfg):
     """fp16 head kernels (csrc/c1.hip: head_fwd512 / head_bwd512 / head_wsum512): the weight-gradient partials are
