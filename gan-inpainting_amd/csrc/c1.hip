@@ -318,6 +318,149 @@ __global__ void __launch_bounds__(256) c1_col2im_kernel(const half_t* __restrict
   }
 }
 
+// ---- transposed conv to a FEW channels (the frozen face-parsing network's head: 4 classes) -------------------------------
+// The same two steps with OC output channels: col[p][o*16 + tap] = sum_c relu?(X[p][c]) * w[c][tap][o] - a 16*OC-row GEMM, OC MFMA
+// row tiles per 32-channel step on the same B fragments - and the overlap-add per channel. 2*P*c*16*OC FLOP instead of the
+// 2*4*P*(4c)*64 of the general kernels on weights padded to 64 output channels (16x less for OC = 4).
+template <int KS, int OC>   // KS = c / 32
+__global__ void __launch_bounds__(256) c1_col_mc_kernel(const char* X, const float* __restrict__ w, half_t* col, int64_t P, int ldx,
+                                                        int coffx, int relu_in) {
+  const int lane = threadIdx.x & 63;
+  const int tapr = lane & 15, kq = lane >> 4;
+  h8_t af[OC][KS];
+#pragma unroll
+  for (int o = 0; o < OC; ++o)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[o][ks][j] = (half_t)w[((ks * 32 + kq * 8 + j) * 16 + tapr) * OC + o];
+  const int64_t ngroups = (P + 15) / 16;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    const int64_t pix = g * 16 + tapr;
+    const bool live = pix < P;
+    h8_t bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
+      if (relu_in) bf[ks] = __builtin_elementwise_max(bf[ks], zero);
+    }
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+      f4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[o][ks], bf[ks], acc, 0, 0, 0);
+      if (live) {
+        h4_t v = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+        *(h4_t*)(col + pix * (16 * OC) + o * 16 + kq * 4) = v;   // taps 4kq..4kq+3 of channel o
+      }
+    }
+  }
+}
+
+// overlap-add per channel into (n, OC, H, W) fp32, bias + tanh (post = 1)
+template <int OC>
+__global__ void __launch_bounds__(256) c1_col2im_mc_kernel(const half_t* __restrict__ col, const float* __restrict__ bias, float* img,
+                                                           float* img2, int n, int Hs, int Ws, int post) {
+  const int64_t total = (int64_t)n * Hs * Ws * OC;
+  const int H = 2 * Hs, W = 2 * Ws;
+  for (int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x; id < total; id += (int64_t)gridDim.x * 256) {
+    const int o = (int)(id % OC);            // (channel fastest: the OC lanes of a pixel read one 32*OC-byte col row)
+    const int64_t pix = id / OC;
+    const int i = (int)(pix % Ws);
+    const int64_t t = pix / Ws;
+    const int j = (int)(t % Hs);
+    const int nn = (int)(t / Hs);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int sy = j + dy, sx = i + dx;
+        if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) continue;
+        const half_t* cp = col + ((((int64_t)nn * Hs + sy) * Ws + sx) * OC + o) * 16;
+        const h8_t c0 = *(const h8_t*)cp, c1 = *(const h8_t*)(cp + 8);
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int ty = py - dy, tx = px - dx;
+            if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+            const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+            acc[py * 2 + px] += tap < 8 ? (float)c0[tap & 7] : (float)c1[tap & 7];
+          }
+      }
+    const float b = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float v0 = acc[py * 2] + b, v1 = acc[py * 2 + 1] + b;
+      if (post == 1) { v0 = tanhf(v0); v1 = tanhf(v1); }
+      const int64_t oo = (((int64_t)nn * OC + o) * H + 2 * j + py) * W + 2 * i;
+      *(float2*)(img + oo) = make_float2(v0, v1);
+      if (img2) *(float2*)(img2 + oo) = make_float2(v0, v1);
+    }
+  }
+}
+
+// input gradient of that head: out[p][c] = sum_{o,tap} G[o][p's tap] * w[c][tap][o], G the (n, OC, H, W) fp32 gradient: the gather of
+// c1_gather_mfma_kernel with K = 16*OC (OC = 4: two full 32-wide MFMA steps, k = o*16 + tap)
+template <int MTC>   // c / 16; OC = 4
+__global__ void __launch_bounds__(256) c1_gather_mc4_kernel(const float* __restrict__ img, const float* __restrict__ w, char* out, int n, int Hs,
+                                                            int Ws, int ldout, int coffout) {
+  constexpr int OC = 4;
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  // A[row lr of tile mt][k = 32 s + 8 kq + j] = w[ch][tap = 8 (kq & 1) + j][o = 2 s + (kq >> 1)], ch as in c1_gather_mfma_kernel
+  h8_t af[MTC][2];
+#pragma unroll
+  for (int mt = 0; mt < MTC; ++mt) {
+    const int ch = (mt >> 2) * 64 + (lr >> 2) * 16 + (mt & 3) * 4 + (lr & 3);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) af[mt][s2][j] = (half_t)w[(ch * 16 + (kq & 1) * 8 + j) * OC + 2 * s2 + (kq >> 1)];
+  }
+  const int H = 2 * Hs, W = 2 * Ws;
+  const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
+  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+  for (int64_t g = wave; g < ngroups; g += nwaves) {
+    const int64_t p0 = g * 16;
+    const int x = (int)(p0 % Ws) + lr;
+    const int64_t rowi = p0 / Ws;
+    const int y = (int)(rowi % Hs);
+    const int nn = (int)(rowi / Hs);
+    h8_t bf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const float* ip = img + ((int64_t)nn * OC + 2 * s2 + (kq >> 1)) * H * W;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int iy = 2 * y - 1 + 2 * (kq & 1) + (j >> 2), ix = 2 * x - 1 + (j & 3);
+        bf[s2][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (half_t)ip[(int64_t)iy * W + ix] : (half_t)0.f;
+      }
+    }
+    const int64_t pix = p0 + lr;
+    char* dst = out + ((pix * ldout + coffout) << 1);
+#pragma unroll
+    for (int mq = 0; mq < MTC / 4; ++mq) {
+      h8_t o[2];
+#pragma unroll
+      for (int m4 = 0; m4 < 4; ++m4) {
+        f4_t acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mq * 4 + m4][0], bf[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mq * 4 + m4][1], bf[1], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[m4 >> 1][(m4 & 1) * 4 + r] = (half_t)acc[r];
+      }
+      *(h8_t*)(dst + ((mq * 64 + kq * 16) << 1)) = o[0];
+      *(h8_t*)(dst + ((mq * 64 + kq * 16 + 8) << 1)) = o[1];
+    }
+  }
+}
+
 // ---- scatter (transposed conv to one channel), one lane group per small-resolution pixel ------
 // The 2x2 output quad (2j..2j+1, 2i..2i+1) reads the 3x3 neighbourhood of (j,i):
 //   out(2j+py, 2i+px) = sum_{ty,tx} X[j+py-ty][i+px-tx] . w[:, (1-py+2ty)*4 + (1-px+2tx)]
@@ -1261,5 +1404,29 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
       hipLaunchKernelGGL(head_wgrad_kernel<float>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
     GI_LAUNCH_CHECK();
   }
+  return GI_OK;
+}
+
+// The 4-channel head of a narrow generator (fp16, c = 128 input channels): forward (col + col2im, bias + tanh) and input gradient.
+bool op_c1_head4_ok(int dtype, int c, int out_c, int Ws, int ldx, int coffx) {
+  return dtype == GI_F16 && c == 128 && out_c == 4 && Ws % 16 == 0 && ldx % 8 == 0 && coffx % 8 == 0;
+}
+int64_t op_c1_head4_col_bytes(int n, int Hs, int Ws) { return (int64_t)n * Hs * Ws * 16 * 4 * 2; }
+int op_c1_head4_forward(hipStream_t st, const void* X, const float* w, const float* bias, float* out, float* out2, int n, int Hs, int Ws, int ldx,
+                        int coffx, int relu_in, void* col_scratch) {
+  const int64_t P = (int64_t)n * Hs * Ws;
+  hipLaunchKernelGGL((c1_col_mc_kernel<4, 4>), dim3(grid_for((P + 15) / 16, 4, 256 * 8)), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P,
+                     ldx, coffx, relu_in);
+  GI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(c1_col2im_mc_kernel<4>, dim3(grid_for(P * 4, 256, 256 * 8)), dim3(256), 0, st, (const half_t*)col_scratch, bias, out, out2, n, Hs,
+                     Ws, 1);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int op_c1_head4_dgrad(hipStream_t st, const float* g, const float* w, void* out, int n, int Hs, int Ws, int ldout, int coffout) {
+  GI_REQUIRE(Ws % 16 == 0 && ldout % 8 == 0 && coffout % 8 == 0, "c1_head4_dgrad: layout");
+  const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
+  hipLaunchKernelGGL(c1_gather_mc4_kernel<8>, dim3(grid_for(ngroups, 4, 256 * 8)), dim3(256), 0, st, g, w, (char*)out, n, Hs, Ws, ldout, coffout);
+  GI_LAUNCH_CHECK();
   return GI_OK;
 }

@@ -156,6 +156,13 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
 // Fused producer for the upper half of a c1 kernel's input channels: relu(fma(x2, scale, shift)) of a dense raw tensor
 // (the BatchNorm + ReLU of the last decoder level), instead of reading that half from X.
 struct C1Affine { const void* x2; int ld2; const float* scale; const float* shift; };
+// the 4-channel head of a narrow generator (UnetGenerator(1, 4, 7, ngf=32), fp16, 128 input channels): col GEMM with 64 rows + overlap-add
+// with bias and tanh into (n,4,2Hs,2Ws) fp32 (out2: a second copy, may be null); input gradient of the head from the (n,4,2Hs,2Ws) gradient
+bool op_c1_head4_ok(int dtype, int c, int out_c, int Ws, int ldx, int coffx);
+int64_t op_c1_head4_col_bytes(int n, int Hs, int Ws);
+int op_c1_head4_forward(hipStream_t st, const void* X, const float* w, const float* bias, float* out, float* out2, int n, int Hs, int Ws, int ldx,
+                        int coffx, int relu_in, void* col_scratch);
+int op_c1_head4_dgrad(hipStream_t st, const float* g, const float* w, void* out, int n, int Hs, int Ws, int ldout, int coffout);
 bool op_c1_affine_ok(int dtype, int c, int Ws, int ldx, int coffx);
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img,
                   int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale,

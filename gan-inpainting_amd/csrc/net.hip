@@ -294,7 +294,7 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
     net->oUp1Phase = A.take(cnt * T);
     net->oU1 = A.take(N * H * W * 64 * T);
   }
-  net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2);
+  net->oCol = A.take(N * (H / 2) * (W / 2) * 16 * 2 * (out_c == 4 ? 4 : 1));   // (x4: the 4-channel head's col buffer)
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
   net->oSums = A.take(8 * maxc * 4);   // [8][c]: sums + apply coefficients
@@ -952,8 +952,11 @@ int unet_forward_inference(gi_net* net, int s, const float* x, float* y, int n) 
                          net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y));
     return GI_OK;
   }
-  void* U1 = net->shared(net->oU1);
   const int c1 = 2 * net->ch[1], H = net->H, W = net->W;
+  if (op_c1_head4_ok(dt, c1, net->out_c, net->Wk[1], c1, 0))   // the face-parsing network's head: 64-row col GEMM + overlap-add
+    return op_c1_head4_forward(st, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, y, n, net->Hk[1], net->Wk[1], c1,
+                               0, 1, net->shared(net->oCol));
+  void* U1 = net->shared(net->oU1);
   GI_TRY(igemm(net, 1, C(1), c1, c1, 0, net->shared(net->oUp1Phase), U1, 64, 64, 0, n, net->Hk[1], net->Wk[1], 1, GI_ACT_NONE, false, nullptr,
                net->ch[1]));
   const int64_t total = (int64_t)n * net->out_c * H * W;
@@ -1069,8 +1072,11 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   } else {
     // u1 with out_c channels: the same sub-pixel GEMM as the other up-convolutions on weights zero-padded to 64
     // output channels, then bias + tanh of the first out_c channels into the (n,out_c,H,W) fp32 result
-    void* U1 = net->shared(net->oU1);
     const int c1 = 2 * net->ch[1];
+    if (op_c1_head4_ok(dt, c1, net->out_c, net->Wk[1], c1, 0))   // the face-parsing network's head: 64-row col GEMM + overlap-add
+      return op_c1_head4_forward(st, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, y, n, net->Hk[1], net->Wk[1], c1,
+                                 0, 1, net->shared(net->oCol));
+    void* U1 = net->shared(net->oU1);
     GI_TRY(igemm(net, 1, C(1), c1, c1, 0, net->shared(net->oUp1Phase), U1, 64, 64, 0, n, net->Hk[1], net->Wk[1], 1, GI_ACT_NONE, false,
                  nullptr, net->ch[1]));
     const int64_t total = (int64_t)n * net->out_c * H * W;
@@ -1126,6 +1132,8 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   }
   if (net->out_c == 1) {
     GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
+  } else if (op_c1_head4_ok(dt, c1, net->out_c, net->Wk[1], c1, 0)) {
+    GI_TRY(op_c1_head4_dgrad(st, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, 0));
   } else {
     void* U1 = net->shared(net->oU1);
     if (dt == GI_F16) hipLaunchKernelGGL(pad_dy_kernel<half_t>, dim3(grid1d(npx * 64)), dim3(256), 0, st, G0, (half_t*)U1, n, net->out_c, H * W);
@@ -1250,8 +1258,11 @@ int unet_forward_plain(gi_net* net, int s, const float* x, float* y, int n) {
   if (net->out_c == 1)
     return op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1], net->Wk[1],
                          2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y);
-  void* U1 = net->shared(net->oU1);
   const int c1 = 2 * net->ch[1];
+  if (op_c1_head4_ok(dt, c1, net->out_c, net->Wk[1], c1, 0))   // the face-parsing network's head: 64-row col GEMM + overlap-add
+    return op_c1_head4_forward(st, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, y, n, net->Hk[1], net->Wk[1], c1,
+                               0, 1, net->shared(net->oCol));
+  void* U1 = net->shared(net->oU1);
   GI_TRY(igemm(net, 1, C(1), c1, c1, 0, net->shared(net->oUp1Phase), U1, 64, 64, 0, n, net->Hk[1], net->Wk[1], 1, GI_ACT_NONE, false, nullptr,
                net->ch[1]));
   const int64_t total = (int64_t)n * net->out_c * H * W;
@@ -1304,6 +1315,8 @@ int unet_backward_plain(gi_net* net, int s, const float* dy, float* dx, int need
     }
     if (net->out_c == 1) {
       GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
+    } else if (op_c1_head4_ok(dt, c1, net->out_c, net->Wk[1], c1, 0)) {
+      GI_TRY(op_c1_head4_dgrad(st, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, 0));
     } else {
       void* U1 = net->shared(net->oU1);
       if (dt == GI_F16) hipLaunchKernelGGL(pad_dy_kernel<half_t>, dim3(grid1d(npx * 64)), dim3(256), 0, st, G0, (half_t*)U1, n, net->out_c, H * W);
