@@ -426,22 +426,33 @@ __global__ void __launch_bounds__(256) c1_gather_mc4_kernel(const float* __restr
   const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  for (int64_t g = wave; g < ngroups; g += nwaves) {
+  auto load_b = [&](int64_t g, float (&bv)[2][8]) {
     const int64_t p0 = g * 16;
     const int x = (int)(p0 % Ws) + lr;
     const int64_t rowi = p0 / Ws;
     const int y = (int)(rowi % Hs);
     const int nn = (int)(rowi / Hs);
-    h8_t bf[2];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       const float* ip = img + ((int64_t)nn * OC + 2 * s2 + (kq >> 1)) * H * W;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int iy = 2 * y - 1 + 2 * (kq & 1) + (j >> 2), ix = 2 * x - 1 + (j & 3);
-        bf[s2][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? (half_t)ip[(int64_t)iy * W + ix] : (half_t)0.f;
+        bv[s2][j] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ip[(int64_t)iy * W + ix] : 0.f;
       }
     }
+  };
+  float bv[2][8], bn[2][8];
+  int64_t g = wave;
+  if (g < ngroups) load_b(g, bv);
+  for (; g < ngroups; g += nwaves) {
+    if (g + nwaves < ngroups) load_b(g + nwaves, bn);     // the next group's 16 loads are in flight during this group's MFMAs and stores
+    const int64_t p0 = g * 16;
+    h8_t bf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bf[s2][j] = (half_t)bv[s2][j];
     const int64_t pix = p0 + lr;
     char* dst = out + ((pix * ldout + coffout) << 1);
 #pragma unroll
@@ -458,6 +469,10 @@ __global__ void __launch_bounds__(256) c1_gather_mc4_kernel(const float* __restr
       *(h8_t*)(dst + ((mq * 64 + kq * 16) << 1)) = o[0];
       *(h8_t*)(dst + ((mq * 64 + kq * 16 + 8) << 1)) = o[1];
     }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[s2][j] = bn[s2][j];
   }
 }
 
