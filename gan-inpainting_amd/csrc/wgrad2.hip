@@ -266,8 +266,14 @@ __device__ __forceinline__ void blds16w(rsrc4_t r4, unsigned voff, int soff, cha
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" : : "s"(lds), "v"(voff), "s"(r4), "s"(soff) : "memory", "m0");
 }
 
+// LGTW: the pixel tile is 64 / TW rows x TW = 2^LGTW pixels: 4 x 16 (small grids at least 16 wide) or 8 x 8 (8 x 8 maps: the generator's
+// level 5 at 256 x 256)
+template <int LGTW>
 __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
-  constexpr int HST = 36, HROWS = 5;
+  constexpr int TW = 1 << LGTW, TH = 64 / TW;
+  constexpr int HW = 2 * TW + 2;                   // halo pixels per row
+  constexpr int HST = HW + 2, HROWS = TH + 1;      // row stride 36 / 20: a multiple of 4 that is not one of 8 (second tap set: XOR 64)
+  static_assert(HST % 8 == 4 && (HROWS - 1) * HST + HW <= 192, "halo layout");
   constexpr int S_STAGE = 2 * 64 * 128;            // 16 KiB: two 64-channel segments x 64 pixels
   constexpr int L_STAGE = 192 * 128;               // 24 KiB: 5 x 36 halo rows used
   constexpr int L_BASE = 3 * S_STAGE;
@@ -285,8 +291,8 @@ __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
   const int ks = blockIdx.y;
   const int t0 = ks * p.tiles_per_split, t1 = min(p.ntile, t0 + p.tiles_per_split);
   const int HL = 2 * p.Hs, WL = 2 * p.Ws;
-  const int txs = p.Ws >> 4, tys = p.Hs >> 2;
-  const int lg_txs = p.lgWs - 4, lg_tys = p.lgHs - 2;
+  const int txs = p.Ws >> LGTW, tys = p.Hs / TH;
+  const int lg_txs = p.lgWs - LGTW, lg_tys = p.lgHs - (6 - LGTW);
 
   const rsrc4_t rsS = make_rsrc4(p.S, (unsigned)((int64_t)p.n * p.Hs * p.Ws * p.ldS * 2));
   const rsrc4_t rsL = make_rsrc4(p.L, (unsigned)((int64_t)p.n * HL * WL * p.ldL * 2));
@@ -299,14 +305,14 @@ __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
   for (int j = 0; j < SJ; ++j) {
     const int ps = wave * SJ + j;
     const int seg = ps >> 3, k = (ps & 7) * 8 + lrow;
-    const int ry = k >> 4, rx = k & 15;
+    const int ry = k >> LGTW, rx = k & (TW - 1);
     s_voff[j] = ((ry * p.Ws + rx) * p.ldS + p.coffS + a0 + seg * 64) * 2 + lchunk * 16;
   }
 #pragma unroll
   for (int j = 0; j < LJ; ++j) {
     const int hrow = (wave * LJ + j) * 8 + lrow;
     const int hr = hrow / HST, hx = hrow - hr * HST;
-    l_hr[j] = (hr < HROWS && hx < 34) ? hr : 1 << 20;     // rows of the buffer no tap reads: always zero-filled
+    l_hr[j] = (hr < HROWS && hx < HW) ? hr : 1 << 20;     // rows of the buffer no tap reads: always zero-filled
     l_hx[j] = hx;
     l_voff[j] = ((2 * hr * WL + hx) * p.ldL + p.coffL + b0) * 2 + lchunk * 16;
   }
@@ -316,7 +322,7 @@ __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
     constexpr int stage = decltype(STG)::value, j = decltype(PIECE)::value;
     const bool live = t < t1;
     const int xb = t & (txs - 1), yb = (t >> lg_txs) & (tys - 1), nn = t >> (lg_txs + lg_tys);
-    const int y0 = yb * 4, x0 = xb * 16;
+    const int y0 = yb * TH, x0 = xb * TW;
     if constexpr (j < SJ) {
       const int sb = live ? ((nn * p.Hs + y0) * p.Ws + x0) * p.ldS * 2 : 0;   // wave-uniform
       blds16w(rsS, live ? (unsigned)s_voff[j] : OOB, sb, smem + stage * S_STAGE + (wave * SJ + j) * 1024);
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
     for (int h = 0; h < 2; ++h) {
       const int k = ksx * 32 + 8 * g + 4 * h + q;
       const int srow = wa * 64 + k;
-      const int ry = k >> 4, rx = k & 15;
+      const int ry = k >> LGTW, rx = k & (TW - 1);
       const int lrw = ry * HST + 2 * rx + kx;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -700,7 +706,7 @@ int wgrad2_nky() {   // GI_WGRAD2_NKY=1: one ky tap row per workgroup (tools: A/
 }
 
 int wgrad2_split(int n, int Hs, int Ws, int ca, int cb, int* tiles_per_split) {
-  const int ntile = n * (Hs / 4) * (Ws / 16);
+  const int ntile = n * Hs * Ws / 64;      // 4 x 16 or 8 x 8 pixel tiles
   const int blocks = (ca / 128) * (cb / 64) * (4 / wgrad2_nky());
   int split = (256 + blocks - 1) / blocks;             // one 8-wave workgroup per CU
   if (split > ntile / 8) split = ntile / 8;
@@ -710,6 +716,10 @@ int wgrad2_split(int n, int Hs, int Ws, int ca, int cb, int* tiles_per_split) {
   return (ntile + tps - 1) / tps;
 }
 
+// 8 x 8 pixel tiles (small grids 8 wide): served by wgrad3 only
+bool wgrad3_square_ok(int n, int Hs, int Ws, int ca, int cb) {
+  return ca % 128 == 0 && cb % 64 == 0 && gi_is_pow2(Hs) && Ws == 8 && Hs >= 8 && n >= 1;
+}
 bool wgrad2_ok(int n, int Hs, int Ws, int ca, int cb) {
   return ca % 128 == 0 && cb % 64 == 0 && gi_is_pow2(Hs) && gi_is_pow2(Ws) && Ws >= 16 && Hs >= 4 && n >= 1;
 }
@@ -717,14 +727,15 @@ bool wgrad2_ok(int n, int Hs, int Ws, int ca, int cb) {
 }  // namespace
 
 int64_t op_wgrad2_scratch_bytes(int n, int Hs, int Ws, int ca, int cb) {
-  if (!wgrad2_ok(n, Hs, Ws, ca, cb)) return 0;
+  if (!wgrad2_ok(n, Hs, Ws, ca, cb) && !wgrad3_square_ok(n, Hs, Ws, ca, cb)) return 0;
   const int split = wgrad2_split(n, Hs, Ws, ca, cb, nullptr);
   return split > 1 ? (int64_t)split * ca * 16 * cb * 4 : 0;
 }
 
 // fp16 only. GI_ERR_UNSUPPORTED: shape not served (the caller uses wgrad.hip).
 int op_wgrad2(hipStream_t st, const WgradArgs& a) {
-  if (!wgrad2_ok(a.n, a.Hs, a.Ws, a.ca, a.cb)) return GI_ERR_UNSUPPORTED;
+  const bool square = !wgrad2_ok(a.n, a.Hs, a.Ws, a.ca, a.cb) && wgrad3_square_ok(a.n, a.Hs, a.Ws, a.ca, a.cb);
+  if (!wgrad2_ok(a.n, a.Hs, a.Ws, a.ca, a.cb) && !square) return GI_ERR_UNSUPPORTED;
   if (a.ldS % 8 != 0 || a.coffS % 8 != 0 || a.ldL % 8 != 0 || a.coffL % 8 != 0) return GI_ERR_UNSUPPORTED;
   if ((int64_t)a.n * a.Hs * a.Ws * a.ldS >= (1ll << 31) || (int64_t)a.n * 4 * a.Hs * a.Ws * a.ldL >= (1ll << 31)) return GI_ERR_UNSUPPORTED;
   int dev = 0;
@@ -736,7 +747,7 @@ int op_wgrad2(hipStream_t st, const WgradArgs& a) {
   p.n = a.n; p.Hs = a.Hs; p.Ws = a.Ws; p.lgWs = gi_ilog2(a.Ws); p.lgHs = gi_ilog2(a.Hs);
   p.ca = a.ca; p.ldS = a.ldS; p.coffS = a.coffS; p.cb = a.cb; p.ldL = a.ldL; p.coffL = a.coffL;
   p.relu_S = a.relu_S; p.scale = a.scale;
-  p.ntile = a.n * (a.Hs / 4) * (a.Ws / 16);
+  p.ntile = a.n * a.Hs * a.Ws / 64;
   const int split = wgrad2_split(a.n, a.Hs, a.Ws, a.ca, a.cb, &p.tiles_per_split);
   const int64_t out_floats = (int64_t)a.ca * 16 * a.cb;
   p.part = nullptr;
@@ -754,7 +765,8 @@ int op_wgrad2(hipStream_t st, const WgradArgs& a) {
   static int pipe = -1;   // GI_WGRAD3=0: the unpipelined two-ky kernel (tools: A/B)
   if (pipe < 0) {
     const char* e = getenv("GI_WGRAD3"); pipe = e ? atoi(e) : 1;
-    GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
   // wgrad3 addresses both tensors with 32-bit byte offsets (buffer descriptors; 2^31 marks out-of-range)
   const bool small32 = (int64_t)a.n * a.Hs * a.Ws * a.ldS * 2 < (1ll << 31) && (int64_t)a.n * 4 * a.Hs * a.Ws * a.ldL * 2 < (1ll << 31);
@@ -763,8 +775,12 @@ int op_wgrad2(hipStream_t st, const WgradArgs& a) {
     const char* e = getenv("GI_WGRAD4"); four = e ? atoi(e) : 0;
     GI_HIP(hipFuncSetAttribute((const void*)wgrad4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
   }
-  if (nky == 2 && four && small32) hipLaunchKernelGGL(wgrad4_kernel, grid, dim3(256), LDS, st, p);
-  else if (nky == 2 && pipe && small32) hipLaunchKernelGGL(wgrad3_kernel, grid, dim3(512), LDS, st, p);
+  if (square) {   // 8 x 8 maps: wgrad3 only, and only where the partial-tile pass stays small (u5: 42.7 + 23.2 us against 86.7 us
+    // for wgrad.hip; with four splits - d5 - the 67 MB of partial tiles cost more than the faster K loop gains: 48.7 against 45.2)
+    if (!(nky == 2 && pipe && small32) || split > 2) return GI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(wgrad3_kernel<3>, grid, dim3(512), LDS, st, p);
+  } else if (nky == 2 && four && small32) hipLaunchKernelGGL(wgrad4_kernel, grid, dim3(256), LDS, st, p);
+  else if (nky == 2 && pipe && small32) hipLaunchKernelGGL(wgrad3_kernel<4>, grid, dim3(512), LDS, st, p);
   else if (nky == 2) hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(512), LDS, st, p);
   else hipLaunchKernelGGL(wgrad2_kernel<1>, grid, dim3(512), LDS, st, p);
   GI_LAUNCH_CHECK();
