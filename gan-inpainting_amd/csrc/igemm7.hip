@@ -372,7 +372,7 @@ const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
 int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   if (mode != 0 && mode != 1) return GI_ERR_UNSUPPORTED;
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.force_splitk != 0) return GI_ERR_UNSUPPORTED;
-  static int use7 = -1, max_split = 16;   // GI_IGEMM7=0: igemm.hip serves these layers; GI_IGEMM7_MAXSPLIT (tools: A/B)
+  static int use7 = -1, max_split = 8;    // (measured: d7 20.6 us with 16 splits, 18.6 us with 8: the last arriver's tail)   // GI_IGEMM7=0: igemm.hip serves these layers; GI_IGEMM7_MAXSPLIT (tools: A/B)
   if (use7 < 0) {
     const char* e = getenv("GI_IGEMM7"); use7 = e ? atoi(e) : 1;
     e = getenv("GI_IGEMM7_MAXSPLIT"); if (e && atoi(e) >= 1) max_split = atoi(e);
@@ -392,7 +392,7 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   const int Ktot = (mode == 1 ? 4 : 16) * a.cin, nk = Ktot / 64;
   int splitk = (256 + tiles - 1) / tiles;
   if (splitk > max_split) splitk = max_split;
-  if (splitk > nk / 4) splitk = nk / 4;
+  if (splitk > nk / 8) splitk = nk / 8;   // at least 8 K tiles per split (u7: 21.7 us with 4 tiles per split, 17.9 us with 8)
   if (splitk < 1) splitk = 1;
   int kps = (nk + splitk - 1) / splitk;
   splitk = (nk + kps - 1) / kps;
