@@ -7,6 +7,11 @@ compute with fp32 master weights, synthetic masked-image batches resident in HBM
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+With --gpus N > 1 and no WORLD_SIZE in the environment (a plain `python bench.py --gpus 8`) the process starts N rank
+processes itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU, RCCL through torch.distributed "nccl") BEFORE it
+touches the GPU, relays rank 0's JSON line and exits non-zero if any rank fails (launch_ranks). `n_gpus` in the line is the
+number of ranks that answered a 1-element SUM all-reduce, not the flag.
+
 Prints ONE JSON line on rank 0. Extra objects:
   roofline      dominant kernel (the fp16 MFMA implicit-GEMM transposed conv on the u3 shape), timed live
                 with HIP events on the kernel's stream: algorithmic FLOP / average launch time vs 2.5 PFLOP/s
@@ -44,6 +49,82 @@ def synth(n, seed, device):
         x0 = int(torch.randint(0, W - w + 1, (1,), generator=g))
         mask[i, 0, y0:y0 + h, x0:x0 + w] = 1.0
     return ground.to(device), mask.to(device)
+
+
+def launch_ranks(n, argv):
+    """Start n fresh rank processes of this script (children never re-exec; this parent makes no GPU call), wait for them,
+    return the exit code: 0 only if every rank exited 0. Rank 0 writes to our stdout, the other ranks' stdout is dropped
+    (they print nothing by contract), stderr is shared. A rank that fails takes the others down (exact PIDs)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                print(f"bench.py: rank {procs.index(p)} exited with {c}; stopping the other ranks", file=sys.stderr)
+                for q in live:
+                    q.terminate()
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    return rc
+
+
+def ranks_alive(world, device):
+    """Number of ranks that take part in a collective: a 1-element SUM all-reduce (so a run that silently lost ranks cannot
+    report the --gpus flag as n_gpus)."""
+    if world == 1:
+        return 1
+    one = torch.ones(1, device=device, dtype=torch.float32)
+    torch.distributed.all_reduce(one, op=torch.distributed.ReduceOp.SUM)
+    return int(round(float(one.item())))
+
+
+def rehearsal_workload(args):
+    """Plumbing only, no kernels and NOT a measurement (tests/test_parallel_cpu.py, GI_DIST_BACKEND=gloo on a box without
+    a GPU): the launch, rendezvous, rank count, barrier / max-over-ranks timing and the one-line report of the real path."""
+    import gan_inpainting_amd  # noqa: F401
+    from gan_inpainting_amd import parallel
+    rank, world = parallel.init_from_env()
+    if os.environ.get("GI_BENCH_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    dev = torch.device("cpu")
+    alive = ranks_alive(world, dev)
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        torch.distributed.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal (no kernels)", "value": whole_job_rate(alive, BS, args.steps, dt), "unit": "images/sec",
+                          "n_gpus": alive, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none",
+                          "config": {"workload": "rehearsal of the multi-rank launch path; measures nothing"}}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def max_over_ranks(dt, world, device):
@@ -241,7 +322,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--preheat", type=int, default=400, help="untimed steps before the W warm-up steps (clock ramp of a cold GPU)")
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512", "config5_512", "dual_d_256"],
+    ap.add_argument("--workload", default="wgan_rmse_256", choices=["wgan_rmse_256", "wgan_gp_128", "ssim_256", "vgg_512", "config5_512", "dual_d_256", "rehearsal"],
                     help="ssim_256 = the per-batch SSIM metric of experiment1_global_local_D.py:209 at 256x256 bs=32 (SURVEY 8f rank 2); wgan_gp_128 = BASELINE configs[1]: wgan_l1 128x128 bs=16 fp32 with the gradient-penalty extension (not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
@@ -249,6 +330,11 @@ def main():
     ap.add_argument("--kernel-only", action="store_true")
     ap.add_argument("--kernel-iters", type=int, default=50)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.workload == "rehearsal":
+        return rehearsal_workload(args)
 
     import gan_inpainting_amd  # noqa: F401
     from gan_inpainting_amd import optim, parallel, trainer
@@ -270,6 +356,10 @@ def main():
     local = parallel.local_device()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    alive = ranks_alive(world, dev)
+    if alive != world:
+        print(f"bench.py: {alive} of {world} ranks answered the all-reduce", file=sys.stderr)
+        sys.exit(4)
 
     if args.workload == "ssim_256":
         print(json.dumps(ssim_workload(args, dev)))
@@ -344,7 +434,7 @@ def main():
         return
     if c5:   # secondary workload: plain line
         print(json.dumps({"metric": "training images/sec at 512x512 bs=8/GPU (wgan_perceptual_style_faceparsing)",
-                          "value": world * BS * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "value": alive * BS * args.steps / dt, "unit": "images/sec", "n_gpus": alive, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                           "config": {"workload": "wgan_perceptual_style_faceparsing 512x512 bs=8/GPU fp16 (BASELINE.json configs[4]): WGAN + "
@@ -353,7 +443,7 @@ def main():
         return
     if gp:   # secondary workload: plain line, no roofline / cpu legs
         print(json.dumps({"metric": "training images/sec at 128x128 bs=16/GPU (wgan_l1 + gradient penalty, fp32)",
-                          "value": world * BS * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                          "value": alive * BS * args.steps / dt, "unit": "images/sec", "n_gpus": alive, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "wgan_l1 128x128 bs=16 fp32 + WGAN-GP (BASELINE.json configs[1])"}, "losses": losses}))
@@ -408,9 +498,9 @@ def main():
     flop_batch = BS * ((F_G + 6 * F_D) + (2 * F_G + 2 * F_D) / G_EVERY)
     out = {
         "metric": "training images/sec at 256x256 bs=32/GPU",
-        "value": whole_job_rate(world, BS, args.steps, dt),
+        "value": whole_job_rate(alive, BS, args.steps, dt),
         "unit": "images/sec",
-        "n_gpus": world,
+        "n_gpus": alive,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,

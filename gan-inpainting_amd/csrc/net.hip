@@ -1623,6 +1623,76 @@ extern "C" int gi_net_forward(gi_net* net, int slot, const float* x, float* y, i
   return net->kind == 0 ? unet_forward(net, slot, x, y, n) : patchgan_forward(net, slot, x, y, n);
 }
 
+namespace {
+// saved activation (pixels x channels of an NHWC tensor, ld / coff) -> fp32 (n,c,hw). scale != null: src is the RAW
+// convolution output of a layer whose normalisation + activation a consumer applies on the fly (C1Affine / HeadArgs::scale4):
+// the same fma(x, scale, shift) and activation are applied here (image i of population i / n_per_group, vectors gstride apart)
+template <typename T>
+__global__ void __launch_bounds__(256) export_act_kernel(const T* __restrict__ src, int ld, int coff, float* __restrict__ out, int n, int c, int hw,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                         int n_per_group, int gstride) {
+  const int64_t total = (int64_t)n * c * hw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int p = (int)(i % hw);
+    const int64_t t = i / hw;
+    const int ch = (int)(t % c);
+    const int64_t img = t / c;
+    float v = (float)src[(img * hw + p) * ld + coff + ch];
+    if (scale) {
+      const int g = n_per_group > 0 ? (int)(img / n_per_group) : 0;
+      v = fmaf(v, scale[(int64_t)g * gstride + ch], shift[(int64_t)g * gstride + ch]);
+      v = act == GI_ACT_RELU ? fmaxf(v, 0.f) : (act == GI_ACT_LRELU ? (v > 0.f ? v : 0.2f * v) : v);
+      v = (float)(T)v;
+    }
+    out[i] = v;
+  }
+}
+}  // namespace
+
+extern "C" int gi_net_saved_activation(gi_net* net, int slot, int kind, int level, float* out_nchw, int64_t count) {
+  GI_REQUIRE(net && net->bound && out_nchw, "saved_activation: net not bound / null output");
+  GI_REQUIRE(slot >= 0 && slot < net->n_slots && net->slot_n[slot] > 0, "saved_activation: slot %d holds no forward", slot);
+  GI_REQUIRE(!(net->kind == 0 && net->slot_inference[slot]), "saved_activation: slot %d holds an inference forward (nothing saved)", slot);
+  const int n = net->slot_n[slot];
+  const void* src = nullptr;
+  int ld = 0, coff = 0, c = 0, hw = 0, act = GI_ACT_NONE, npg = 0, gstride = 0;
+  const float* scale = nullptr; const float* shift = nullptr;
+  if (net->kind == 0) {
+    const int nd = net->nd;
+    GI_REQUIRE((kind == 0 && level >= 1 && level <= nd) || (kind == 1 && level >= 1 && level <= nd - 1),
+               "saved_activation: generator kind=%d level=%d (kind 0: 1..%d, kind 1: 1..%d)", kind, level, nd, nd - 1);
+    c = net->ch[level]; hw = net->Hk[level] * net->Wk[level];
+    if (kind == 0 && level == nd) { src = net->slot(slot, net->oE); ld = c; }
+    else {
+      src = net->slot(slot, net->oC[level]); ld = 2 * c; coff = kind ? c : 0;
+      if (kind == 1 && level == 1 && net->slot_fused_u2[slot]) {   // never materialised: the head applies it on the fly
+        BNPtrs p = bn_ptrs(net, slot, net->unorm[2]);
+        src = net->slot(slot, net->oU[2]); ld = c; coff = 0; scale = p.scale; shift = p.shift; act = GI_ACT_RELU;
+      }
+    }
+  } else {
+    GI_REQUIRE(kind == 0 && level >= 1 && level <= 4, "saved_activation: discriminator kind=%d level=%d (kind 0, 1..4)", kind, level);
+    const int chans[5] = {1, 64, 128, 256, 512};
+    c = chans[level]; hw = (net->H >> level) * (net->W >> level); ld = c;
+    src = net->slot(slot, net->oA[level]);
+    if (level == 4 && net->slot_fused_u2[slot]) {
+      BNPtrs p = bn_ptrs(net, slot, net->dbn[4]);
+      src = net->slot(slot, net->oRd[4]); scale = p.scale; shift = p.shift; act = GI_ACT_LRELU;
+      npg = n / net->slot_groups[slot]; gstride = 4 * 512;
+    }
+  }
+  GI_REQUIRE(count == (int64_t)n * c * hw, "saved_activation: count %lld != n*c*h*w = %lld", (long long)count, (long long)n * c * hw);
+  hipStream_t st = net->ctx->stream;
+  if (net->dtype == GI_F16)
+    hipLaunchKernelGGL(export_act_kernel<half_t>, dim3(grid1d(count)), dim3(256), 0, st, (const half_t*)src, ld, coff, out_nchw, n, c, hw, scale, shift,
+                       act, npg, gstride);
+  else
+    hipLaunchKernelGGL(export_act_kernel<float>, dim3(grid1d(count)), dim3(256), 0, st, (const float*)src, ld, coff, out_nchw, n, c, hw, scale, shift,
+                       act, npg, gstride);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
 extern "C" int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad) {
   GI_REQUIRE(net && net->bound, "net_backward: net not bound");
   GI_REQUIRE(dy, "net_backward: dy is null");

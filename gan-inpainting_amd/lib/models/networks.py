@@ -344,6 +344,14 @@ class HipNet(nn.Module):
         B.check(B.lib().gi_net_backward(self._handle, slot, B.ptr(dy), B.ptr(dx), 1 if need_wgrad else 0))
         return dx
 
+    def saved_activation(self, kind, level, shape, slot=None):
+        """fp32 (N,C,h,w) copy of an activation the last forward saved for its backward (gi_net_saved_activation): its sign is
+        the side of the ReLU / LeakyReLU kink that forward took. Parity tests only."""
+        slot = self._last_slot if slot is None else slot
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        B.check(B.lib().gi_net_saved_activation(self._handle, slot, kind, level, B.ptr(out), out.numel()))
+        return out
+
     def forward(self, x):
         if torch.is_grad_enabled() and (self.training or x.requires_grad):
             return _NetFunction.apply(x, self._anchor, self)

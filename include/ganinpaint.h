@@ -116,6 +116,14 @@ int gi_net_dropout_mask(gi_net* net, int slot, int level, uint8_t* out_nchw, int
 /* impose external keep-masks (uint8 NCHW, device) for the next forward of slot; null clears */
 int gi_net_set_dropout_mask(gi_net* net, int slot, int level, const uint8_t* mask_nchw);
 
+/* Activations the forward held in `slot` saved for its backward, as fp32 (N,C,h,w): which side of every ReLU / LeakyReLU
+ * kink the forward took (parity tests hand these decisions to the oracle for units whose pre-activation is within fp32
+ * rounding distance of zero). Generator, level k = 1..num_downs: kind 0 = the skip a_k = LeakyReLU(norm(conv_k(.)))
+ * (networks.py:287; k = num_downs: ReLU of the innermost convolution, :299-305); kind 1 (k < num_downs) = the decoder half
+ * ReLU(dropout(norm(up_{k+1}(.)))) concatenated beside it (:289, :324). Discriminator, kind 0, level i = 1..4:
+ * LeakyReLU(BatchNorm(conv_i(.))) (:335-345). count = N*C*h*w. */
+int gi_net_saved_activation(gi_net* net, int slot, int kind, int level, float* out_nchw, int64_t count);
+
 /* forward: x (n,1,H,W) fp32 -> y: generator (n,1,H,W) fp32, discriminator (n,1) fp32 */
 int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n);
 /* backward of the forward held in `slot`: dy like y; dx like x or NULL; need_wgrad=0 is the

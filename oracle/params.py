@@ -60,6 +60,18 @@ def dropout_levels(num_downs):
     return list(range(5, num_downs))
 
 
+def synth_dropout_masks(seed, num_downs, N, H, W, ngf=64):
+    """Deterministic keep-masks {level: uint8 (N,C,h,w)} with keep probability 0.5 for the Dropout(0.5) levels: level k's
+    up path ends with ngf*min(2^(k-2), 8) channels at (H, W) >> (k-1). Imposed on both sides by the parity tests whose
+    seeds are chosen from the oracle alone (tools/pick_kink_safe_seeds.py)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k in dropout_levels(num_downs):
+        c = ngf * min(2 ** (k - 2), 8)
+        out[k] = (rng.random(size=(N, c, H >> (k - 1), W >> (k - 1)), dtype=np.float32) < 0.5).astype(np.uint8)
+    return out
+
+
 def _uniform(rng, shape, bound):
     return ((rng.random(size=shape, dtype=np.float32) * 2.0 - 1.0) * np.float32(bound)).astype(np.float32)
 

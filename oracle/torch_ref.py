@@ -58,7 +58,17 @@ def _norm(P, prefix, x, train, norm):
     return x
 
 
-def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None, norm="batch"):
+def _act(z, slope, flip=None):
+    """LeakyReLU(slope) / ReLU (slope 0). flip (bool tensor like z, tools/pick_kink_safe_seeds.py only): the units whose
+    kink decision is inverted - the value is continuous there (z is within rounding distance of 0), the derivative is
+    the other branch's. flip=None is the reference's own call."""
+    if flip is None:
+        return F.leaky_relu(z, slope) if slope else F.relu(z)
+    pos = (z > 0) ^ flip
+    return torch.where(pos, z, slope * z)
+
+
+def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None, norm="batch", taps=None, flips=None):
     """UnetGenerator.forward (networks.py:246-253) through the recursive
     UnetSkipConnectionBlock.forward (networks.py:320-324), unrolled.
 
@@ -70,36 +80,60 @@ def unet_forward(P, x, num_downs=7, train=True, dropout_masks=None, norm="batch"
         (networks.py:18-19, :313-314).
     dropout_masks: {level: keep-mask tensor (N,C,H,W) of 0/1}; required in train mode for
     those levels (the oracle never draws its own random numbers).
+    taps: optional dict; receives every tensor that feeds a LeakyReLU / ReLU kink, keyed 'd<k>' (input of level k+1's
+    downrelu = output of level k's down path) and 'u<k>' (level k's up-path output before dropout, one half of the next
+    uprelu's input; the other half is the skip, whose kinks are those of 'd<k-1>'), together with the keep-mask under
+    'u<k>.keep' where dropout follows (tools/pick_kink_safe_seeds.py). flips: {tap name: bool tensor}, see _act.
     """
+    flips = flips or {}
     keys = _p.unet_key_layout(num_downs)
     drops = _p.dropout_levels(num_downs)
     skips = {}
     h = F.conv2d(x, P[keys[0]["down"] + ".weight"], P.get(keys[0]["down"] + ".bias"), stride=2, padding=1)
     for k in range(2, num_downs + 1):
-        s = F.leaky_relu(h, 0.2)
+        if taps is not None:
+            taps[f"d{k - 1}"] = h
+        s = _act(h, 0.2, flips.get(f"d{k - 1}"))
         skips[k - 1] = s
         h = F.conv2d(s, P[keys[k - 1]["down"] + ".weight"], P.get(keys[k - 1]["down"] + ".bias"), stride=2, padding=1)
         if keys[k - 1]["dnorm"]:
             h = _norm(P, keys[k - 1]["dnorm"], h, train, norm)
     u = h
+    if taps is not None:
+        taps[f"d{num_downs}"] = h
     for k in range(num_downs, 0, -1):
-        inp = F.relu(u) if k == num_downs else F.relu(torch.cat([skips[k], u], 1))
+        if flips:   # the skip's ReLU decides like its LeakyReLU did (same sign); the decoder half has its own kinks
+            fu = flips.get(f"d{num_downs}") if k == num_downs else flips.get(f"u{k + 1}")
+            inp = _act(u, 0.0, fu) if k == num_downs else torch.cat([_act(skips[k], 0.0, flips.get(f"d{k}")), _act(u, 0.0, fu)], 1)
+        else:
+            inp = F.relu(u) if k == num_downs else F.relu(torch.cat([skips[k], u], 1))
         bias = P.get(keys[k - 1]["up"] + ".bias")
         u = F.conv_transpose2d(inp, P[keys[k - 1]["up"] + ".weight"], bias, stride=2, padding=1)
         if keys[k - 1]["unorm"]:
             u = _norm(P, keys[k - 1]["unorm"], u, train, norm)
+        if taps is not None and k > 1:
+            taps[f"u{k}"] = u
         if train and k in drops:
+            if taps is not None:
+                taps[f"u{k}.keep"] = dropout_masks[k]
             u = u * dropout_masks[k].to(u.dtype) * 2.0
     return torch.tanh(u)
 
 
-def patchgan_forward(P, x, sigmoid=True, train=True):
+def patchgan_forward(P, x, sigmoid=True, train=True, taps=None, flips=None):
     """PatchGANDiscriminator.forward (networks.py:335-363); Linear(25,1) generalised to
     Linear((H/16-3)*(W/16-3),1) for sizes other than 128x128."""
-    h = F.leaky_relu(F.conv2d(x, P["model.0.weight"], None, stride=2, padding=1), 0.2)
-    for conv, bn in ((2, 3), (5, 6), (8, 9)):
+    h = F.conv2d(x, P["model.0.weight"], None, stride=2, padding=1)
+    if taps is not None:   # the tensors that feed a LeakyReLU kink (tools/pick_kink_safe_seeds.py)
+        taps["c1"] = h
+    flips = flips or {}
+    h = _act(h, 0.2, flips.get("c1"))
+    for i, (conv, bn) in enumerate(((2, 3), (5, 6), (8, 9))):
         h = F.conv2d(h, P[f"model.{conv}.weight"], None, stride=2, padding=1)
-        h = F.leaky_relu(_bn(P, f"model.{bn}", h, train), 0.2)
+        h = _bn(P, f"model.{bn}", h, train)
+        if taps is not None:
+            taps[f"c{i + 2}"] = h
+        h = _act(h, 0.2, flips.get(f"c{i + 2}"))
     h = F.conv2d(h, P["model.11.weight"], None, stride=1, padding=0)
     h = h.reshape(h.shape[0], -1)
     h = F.linear(h, P["model.13.weight"], P["model.13.bias"])

@@ -59,18 +59,47 @@ def rel_l2(got, ref):
     return float((got - ref).norm() / (ref.norm() + 1e-30))
 
 
-def close_to_either(name, got, ref32, ref64, tol_max, tol_l2=None):
-    """The reference's fp32 CPU result is itself only an approximation: between its fp32 and an
-    fp64 evaluation of the same graph, LeakyReLU / ReLU kinks flip for activations within rounding
-    distance of zero and move individual gradient entries by 1e-3..1e-2 of the tensor's max (measured:
-    DESIGN.md 'parity metric'). A result is accepted when it lies within `tol_max` (max-norm,
-    relative to max|ref|) of EITHER evaluation; `tol_l2`, if given, additionally bounds the relative
-    L2 error against the fp64 evaluation (used for fp16 where kink flips are frequent)."""
-    if tol_l2 is not None:
-        l2 = rel_l2(got, ref64)
-        msg = f"{name}: relL2 vs fp64 oracle = {l2:.3e} (tol {tol_l2:.1e})"
-        print(msg)
-        return l2 <= tol_l2, msg
+def hip_decisions(net, case):
+    """{tap: bool (N,C,h,w) on the CPU}: which side of each ReLU / LeakyReLU kink the HIP forward took, read from the
+    activations it saved for its backward (gi_net_saved_activation) - the input of oracle.kink.kink_reference."""
+    from oracle import kink
+    return {name: (net.saved_activation(kind, level, shape) > 0).cpu() for name, (shape, kind, level) in kink.tap_shapes(case).items()}
+
+
+def check_grads_vs_kink_reference(what, net, case, dx, dtype, tol_max, tol_l2=None, skip=()):
+    """Every parameter gradient of `net` (and dx) against the fp64 oracle evaluated with the HIP forward's own kink
+    decisions on the units the oracle itself marks as undecidable (oracle/kink.py). fp32: max-norm <= tol_max * max|ref| per
+    tensor; fp16 (tol_l2 given): relative L2 <= tol_l2 per tensor. Asserts that no kink decision differs outside the band.
+    Returns the report."""
+    from oracle import kink
+    fp16 = dtype == "fp16"
+    y64, g64, dx64, rep = kink.kink_reference(case, hip_decisions(net, case), fp16=fp16)
+    print(f"{what}: {rep['units']} kink inputs, {rep['at_risk']} within the band, {rep['flipped']} decided by the HIP forward, "
+          f"{rep['outside']} disagreements outside the band (worst {rep['outside_worst']:.2f} band widths)")
+    assert rep["outside"] == 0, f"{what}: {rep['outside']} kink decisions differ from the oracle's outside the rounding band"
+    bad, worst = [], (0.0, "")
+    items = [(n, p.grad.detach().cpu()) for n, p in net.named_parameters() if n not in skip]
+    if dx is not None:
+        items.append(("dx", dx.detach().cpu()))
+    for name, g in items:
+        ref = dx64 if name == "dx" else g64[name]
+        if tol_l2 is not None:
+            err, tol = rel_l2(g, ref), tol_l2
+        else:
+            err, tol = float((g.double() - ref).abs().max() / (ref.abs().max() + 1e-300)), tol_max
+        if err > worst[0]:
+            worst = (err, name)
+        if not err <= tol:
+            bad.append(f"{what} grad {name}: {'relL2' if tol_l2 is not None else 'max-norm'} error {err:.3e} > {tol:.1e}")
+    print(f"{what}: worst gradient error {worst[0]:.3e} at {worst[1]}")
+    assert not bad, "\n".join(bad)
+    return rep, y64
+
+
+def close_to_either(name, got, ref32, ref64, tol_max):
+    """Gradient-penalty extension tests only (tests/test_gp_gpu.py: the penalty's own forward runs in a private activation
+    slot whose kink decisions are not exported, so oracle/kink.py cannot be applied there): accepted when within `tol_max`
+    (max-norm, relative to max|ref|) of the oracle's fp32 OR fp64 evaluation. The network parity tests do not use this."""
     ok32, m32 = report(name + " [vs fp32 oracle]", got, ref32, tol_max)
     if ok32:
         return True, m32

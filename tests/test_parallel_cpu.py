@@ -111,3 +111,30 @@ def test_bench_multi_rank_plumbing_world2_gloo():
     for rank, (rk, r, w, dt, rate, bsum) in enumerate(res):
         assert (rk, r, w) == (rank, rank, 2)
         assert dt == 1.5 and abs(rate - 2 * 32 * 10 / 1.5) < 1e-9 and bsum == 0.0
+
+
+def _run_bench(extra_env, *flags):
+    import json
+    import subprocess
+    env = dict(os.environ, GI_DIST_BACKEND="gloo", **extra_env)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_gpus_flag_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how the driver calls it) must produce 2 ranks by
+    itself: launch_ranks() -> two child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, rendezvous, the 1-element
+    all-reduce that counts the ranks, ONE JSON line from rank 0 with n_gpus = 2 (the rehearsal workload runs no kernels)."""
+    rc, lines, err = _run_bench({}, "--gpus", "2", "--workload", "rehearsal", "--steps", "3", "--warmup", "1")
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["steps"] == 3
+    # rank r sleeps (r + 1) ms per step: the reported time is the slowest rank's
+    assert lines[0]["ms_per_step"] >= 2.0
+
+
+def test_bench_exits_nonzero_when_a_rank_fails():
+    rc, lines, err = _run_bench({"GI_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--workload", "rehearsal", "--steps", "2", "--warmup", "0")
+    assert rc != 0 and not lines and "rank 1 exited" in err
