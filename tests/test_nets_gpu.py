@@ -22,8 +22,11 @@ TOL_OUT = {"fp32": 1e-4, "fp16": 2e-2}
 # pre-activation lies within the oracle's own rounding band of zero, the side of the kink the HIP forward took.
 # fp32: max-norm per tensor. fp16: relative L2 per tensor (fp16 storage of activations and gradients; the kink decisions
 # of the fp16 forward are the HIP forward's wherever |z| < 2e-2 max|z|, so what remains is rounding of VALUES).
-TOL_GRAD = {"fp32": 1e-3, "fp16": None}
-TOL_GRAD_L2 = {"fp32": None, "fp16": 5e-2}
+# Measured on MI355X (round 3, all cases of this file and tests/test_norms_gpu.py): fp32 worst 1.6e-5 with 0..10 units decided
+# by the HIP forward out of 0.5..31 M; fp16 worst relative L2 1.7e-2. The bounds: 1e-4 (ten times tighter than north_star's
+# 1e-3) and 3e-2.
+TOL_GRAD = {"fp32": 1e-4, "fp16": None}
+TOL_GRAD_L2 = {"fp32": None, "fp16": 3e-2}
 TOL_ABSMEAN = {"fp32": 1e-3, "fp16": 6e-2}   # per-tensor mean|grad| against the numbers recorded from the reference
 
 
