@@ -18,6 +18,9 @@ _vp, _i, _i64, _f, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 PROTOTYPES = {
     "gi_last_error": (C.c_char_p, []),
     "gi_version": (_i, []),
+    "gi_set_option": (_i, [C.c_char_p, _i]),
+    "gi_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
+    "gi_debug_last_kernel": (C.c_char_p, []),
     "gi_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "gi_ctx_destroy": (_i, [_vp]),
     "gi_ctx_sync": (_i, [_vp]),
@@ -100,6 +103,10 @@ PROTOTYPES = {
     "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_convT_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),
     "gi_wgrad_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f]),
+    "gi_conv_s2_forward_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "gi_convT_s2_forward_ex": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "gi_stat_acc_words": (_i64, [_i]),
+    "gi_stat_acc_read": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gi_pack_weights": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "gi_convert": (_i, [_vp, _i, _vp, _vp, _i64]),
     "gi_convert_back": (_i, [_vp, _i, _vp, _vp, _i64]),
@@ -108,6 +115,19 @@ PROTOTYPES = {
 
 _lib = None
 _lock = threading.Lock()
+
+
+class IgemmEx(C.Structure):
+    """gi_igemm_ex (include/ganinpaint.h): the fused epilogues of the single-layer _ex entry points."""
+    _fields_ = [("relu_cend", _i),
+                ("mask", _vp), ("ldmask", _i), ("mask_slope", _f),
+                ("add", _vp), ("ldadd", _i),
+                ("stat_acc", _vp), ("stat_reps", _i), ("stat_pg", _i),
+                ("partials", _vp),
+                ("bwd_x", _vp), ("bwd_ldx", _i),
+                ("bwd_scale", _vp), ("bwd_shift", _vp), ("bwd_mean", _vp), ("bwd_inv", _vp), ("bwd_stride", _i),
+                ("bwd_slope", _f), ("bwd_acc", _vp), ("bwd_reps", _i), ("bwd_pg", _i64),
+                ("mask_applied", _i), ("bwd_applied", _i), ("stat_used", _i), ("ntiles_out", _i)]
 
 
 class BackendError(RuntimeError):
@@ -173,3 +193,19 @@ def dtype_code(dtype):
 
 def torch_dtype(code):
     return torch.float16 if code == GI_F16 else torch.float32
+
+
+def set_option(name, value):
+    """Process-wide kernel-path option (include/ganinpaint.h lists them); value < 0 restores the default."""
+    check(lib().gi_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int()
+    check(lib().gi_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+def last_kernel():
+    """Name of the GEMM / weight-gradient kernel launched most recently (gi_debug_last_kernel)."""
+    return (lib().gi_debug_last_kernel() or b"").decode()

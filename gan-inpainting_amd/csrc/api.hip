@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "stat_acc.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -14,7 +15,48 @@ void gi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+namespace {
+struct OptDesc { const char* name; int dflt; int value; int state; };   // state 0: unread, 1: from default / environment, 2: set by the caller
+OptDesc g_opts[GI_OPT_COUNT] = {
+  {"GI_IGEMM5", 7, 0, 0}, {"GI_IGEMM6", 1, 0, 0}, {"GI_IGEMM7", 1, 0, 0}, {"GI_IGEMM_FIXUP", 1, 0, 0}, {"GI_IGEMM_VARIANT", 3, 0, 0},
+  {"GI_BN_ACC", 1, 0, 0}, {"GI_FUSE_HEAD", 1, 0, 0}, {"GI_HEAD_FAST", 1, 0, 0}, {"GI_BN_BWD_FUSE", 1, 0, 0}, {"GI_BN_BWD_SMALL", 512, 0, 0},
+  {"GI_WGRAD2", 1, 0, 0}, {"GI_WGRAD3", 1, 0, 0},
+};
+const char* g_last_kernel = "";
+}  // namespace
+
+int gi_opt(int id) {
+  OptDesc& o = g_opts[id];
+  if (o.state == 0) {
+    const char* e = getenv(o.name);
+    o.value = e ? atoi(e) : o.dflt;
+    o.state = 1;
+  }
+  return o.value;
+}
+void gi_note_kernel(const char* name) { g_last_kernel = name; }
+
 extern "C" {
+
+int gi_set_option(const char* name, int value) {
+  GI_REQUIRE(name, "set_option: null name");
+  for (int i = 0; i < GI_OPT_COUNT; ++i)
+    if (strcmp(name, g_opts[i].name) == 0) {
+      if (value < 0) g_opts[i].state = 0;      // back to the environment / default
+      else { g_opts[i].value = value; g_opts[i].state = 2; }
+      return GI_OK;
+    }
+  gi_set_error("set_option: unknown option '%s'", name);
+  return GI_ERR_INVALID;
+}
+int gi_get_option(const char* name, int* value) {
+  GI_REQUIRE(name && value, "get_option: null argument");
+  for (int i = 0; i < GI_OPT_COUNT; ++i)
+    if (strcmp(name, g_opts[i].name) == 0) { *value = gi_opt(i); return GI_OK; }
+  gi_set_error("get_option: unknown option '%s'", name);
+  return GI_ERR_INVALID;
+}
+const char* gi_debug_last_kernel(void) { return g_last_kernel; }
 
 const char* gi_last_error(void) { return g_err; }
 int gi_version(void) { return 100; }
@@ -83,6 +125,74 @@ int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_ph
   return op_igemm(ctx->stream, dtype, 1, a);
 }
 
+// the same two layers with the optional fused epilogues of IgemmArgs (what the networks pass; include/ganinpaint.h: gi_igemm_ex)
+static void apply_ex(IgemmArgs& a, const gi_igemm_ex* ex) {
+  if (!ex) return;
+  a.relu_cend = ex->relu_cend;
+  a.mask = ex->mask; a.ldmask = ex->ldmask; a.mask_slope = ex->mask_slope;
+  a.add = ex->add; a.ldadd = ex->ldadd;
+  a.stat_acc = ex->stat_acc; a.stat_reps = ex->stat_reps; a.stat_pg = ex->stat_pg;
+  a.partials = ex->partials;
+  a.bwd_x = ex->bwd_x; a.bwd_ldx = ex->bwd_ldx; a.bwd_scale = ex->bwd_scale; a.bwd_shift = ex->bwd_shift; a.bwd_mean = ex->bwd_mean;
+  a.bwd_inv = ex->bwd_inv; a.bwd_stride = ex->bwd_stride; a.bwd_slope = ex->bwd_slope; a.bwd_acc = ex->bwd_acc; a.bwd_reps = ex->bwd_reps;
+  a.bwd_pg = ex->bwd_pg;
+}
+static void return_ex(const IgemmArgs& a, gi_igemm_ex* ex) {
+  if (!ex) return;
+  ex->mask_applied = a.mask_applied; ex->bwd_applied = a.bwd_applied; ex->stat_used = a.stat_used; ex->ntiles_out = a.ntiles_out;
+}
+
+int gi_conv_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out, int n, int H, int W, int cb, int ldin,
+                          int ca, int ldout, int relu_in, int act_out, float* ws, int64_t ws_bytes, gi_igemm_ex* ex) {
+  GI_REQUIRE(ctx && in && w_packed && out, "conv_s2_forward_ex: null pointer");
+  GI_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv_s2_forward_ex: H=%d W=%d must be even", H, W);
+  IgemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.w = w_packed; a.out = out; a.ws = ws; a.ws_bytes = ws_bytes;
+  a.tickets = ws ? ctx_tickets(ctx) : nullptr;
+  a.n = n; a.Hs = H / 2; a.Ws = W / 2;
+  a.cin = cb; a.ldin = ldin; a.cout = ca; a.ldout = ldout;
+  a.relu_in = relu_in; a.act_out = act_out;
+  apply_ex(a, ex);
+  const int rc = op_igemm(ctx->stream, dtype, 0, a);
+  return_ex(a, ex);
+  return rc;
+}
+
+int gi_convT_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w_phase, void* out, int n, int H, int W, int ca, int ldin,
+                           int cb, int ldout, int relu_in, int act_out, float* ws, int64_t ws_bytes, gi_igemm_ex* ex) {
+  GI_REQUIRE(ctx && in && w_phase && out, "convT_s2_forward_ex: null pointer");
+  IgemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.w = w_phase; a.out = out; a.ws = ws; a.ws_bytes = ws_bytes;
+  a.tickets = ws ? ctx_tickets(ctx) : nullptr;
+  a.n = n; a.Hs = H; a.Ws = W;
+  a.cin = ca; a.ldin = ldin; a.cout = cb; a.ldout = ldout;
+  a.relu_in = relu_in; a.act_out = act_out;
+  apply_ex(a, ex);
+  const int rc = op_igemm(ctx->stream, dtype, 1, a);
+  return_ex(a, ex);
+  return rc;
+}
+
+int64_t gi_stat_acc_words(int c) { return gi_stat_block_words(c, GI_STAT_MAXREP); }
+
+namespace {
+__global__ void __launch_bounds__(256) stat_acc_read_kernel(const unsigned long long* acc, int c, int reps, int group, double* out) {
+  for (int ch = blockIdx.x * 256 + threadIdx.x; ch < c; ch += gridDim.x * 256) {
+    out[ch] = gi_stat_read(acc, c, reps, group, 0, ch);
+    out[c + ch] = gi_stat_read(acc, c, reps, group, 1, ch);
+  }
+}
+}  // namespace
+
+int gi_stat_acc_read(gi_ctx* ctx, const unsigned long long* acc, int c, int reps, int group, double* out_dev) {
+  GI_REQUIRE(ctx && acc && out_dev && c > 0 && reps >= 1 && reps <= GI_STAT_MAXREP && (group == 0 || group == 1), "stat_acc_read: bad argument");
+  hipLaunchKernelGGL(stat_acc_read_kernel, dim3((c + 255) / 256), dim3(256), 0, ctx->stream, acc, c, reps, group, out_dev);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
 int gi_wgrad_s2(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW, int n, int Hs, int Ws, int ca, int ldS, int cb, int ldL,
                 int relu_S, float scale) {
   GI_REQUIRE(ctx && S && L && dW, "wgrad_s2: null pointer");
@@ -129,8 +239,7 @@ int gi_time_convT_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_phase
   hipEvent_t e0, e1;
   GI_HIP(hipEventCreate(&e0));
   GI_HIP(hipEventCreate(&e1));
-  const char* er = getenv("GI_TIME_RELU");     // tools: 0 times the variant without the fused input ReLU (input-gradient use)
-  const int relu = er ? atoi(er) : 1;
+  const int relu = gi_tune("GI_TIME_RELU", 1);   // (ablation build: 0 times the variant without the fused input ReLU)
   // warm-up
   GI_TRY(gi_convT_s2_forward(ctx, dtype, in, w_phase, out, n, H, W, ca, ldin, cb, ldout, relu, GI_ACT_NONE, nullptr, 0));
   GI_HIP(hipEventRecord(e0, ctx->stream));

@@ -1188,11 +1188,7 @@ __global__ void __launch_bounds__(256) head_wsum512_kernel(const float* __restri
 }
 
 // row bands per image for the backward: ~256 workgroups, at least 32 pixels each
-static bool head_fast() {   // GI_HEAD_FAST=0: the generic kernels (tools: A/B)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("GI_HEAD_FAST"); v = e ? atoi(e) : 1; }
-  return v != 0;
-}
+static bool head_fast() { return gi_opt(GI_OPT_HEAD_FAST) != 0; }   // GI_HEAD_FAST=0: the generic kernels
 static int head_bands(int n, int npx) {
   int bands = 1;
   while (n * bands < 256 && npx / (bands * 2) >= 32) bands *= 2;

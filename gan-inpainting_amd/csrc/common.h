@@ -19,6 +19,24 @@ typedef float f16_t __attribute__((ext_vector_type(16)));
 
 void gi_set_error(const char* fmt, ...);
 
+// Run-time path options (api.hip): the value set through gi_set_option(), else the environment variable of the same name (read
+// once per process), else the default. include/ganinpaint.h documents each; tests/test_options_gpu.py runs every alternative.
+enum gi_opt_id {
+  GI_OPT_IGEMM5 = 0, GI_OPT_IGEMM6, GI_OPT_IGEMM7, GI_OPT_IGEMM_FIXUP, GI_OPT_IGEMM_VARIANT, GI_OPT_BN_ACC, GI_OPT_FUSE_HEAD,
+  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_COUNT
+};
+int gi_opt(int id);
+// name of the GEMM / weight-gradient kernel a dispatcher has just launched (gi_debug_last_kernel: tests assert which kernel
+// served a shape)
+void gi_note_kernel(const char* name);
+// tuning constants: fixed in the shipped library, read from the environment only by the ablation build (build.sh -DGI_ABLATION)
+#ifdef GI_ABLATION
+#include <stdlib.h>
+static inline int gi_tune(const char* env, int dflt) { const char* e = getenv(env); return e ? atoi(e) : dflt; }
+#else
+#define gi_tune(env, dflt) (dflt)
+#endif
+
 // compile-time unrolled loop: f(std::integral_constant<int, i>) for i in [0, N). Register arrays
 // indexed through it never fall back to scratch memory.
 template <int N, typename F>

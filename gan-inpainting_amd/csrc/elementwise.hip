@@ -1321,8 +1321,8 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   const int grid2 = nblocks(a.pixels * Q, 4);
   p.acc = nullptr; p.acc_reps = a.acc_reps > 0 ? a.acc_reps : 1; p.dgamma = a.dgamma; p.dbeta = a.dbeta; p.inv_loss_scale = a.inv_loss_scale; p.invM = 1.f / (float)p.pg;
   p.zero_next = nullptr; p.zero_words = 0;
-  static int small_max = -1;   // GI_BN_BWD_SMALL: largest pixel count served by the one-launch kernel (0: off; tools: A/B)
-  if (small_max < 0) { const char* e = getenv("GI_BN_BWD_SMALL"); small_max = e ? atoi(e) : 512; if (small_max > 2048) small_max = 2048; }
+  int small_max = gi_opt(GI_OPT_BN_BWD_SMALL);   // GI_BN_BWD_SMALL: largest pixel count served by the one-launch kernel (0: off)
+  if (small_max > 2048) small_max = 2048;
   if (a.has_bn && !a.eval_bn && groups == 1 && a.pixels <= small_max && !a.reduce_done) {
     p.zero_next = a.acc ? a.zero_next : nullptr; p.zero_words = a.acc ? a.zero_words : 0;   // (keeps the accumulator ping-pong of net.hip consistent)
     const int nit = (int)((a.pixels + 255) / 256);

@@ -540,11 +540,9 @@ int run(hipStream_t st, IgemmArgs& a) {
   int splitk = 1;
   // in-kernel fix-up: the last arriver reads splits x tile bytes on ONE CU (~100 GB/s), so the split count is capped
   // and very small M gets 128 x 64 tiles instead (twice the workgroups for the same tail)
-  static int fix = -1, fix_max = 8;   // GI_IGEMM_FIXUP=0: finish-kernel path; GI_IGEMM_FIX_MAXSPLIT (tools: A/B)
-  if (fix < 0) {
-    const char* e = getenv("GI_IGEMM_FIXUP"); fix = e ? atoi(e) : 1;
-    e = getenv("GI_IGEMM_FIX_MAXSPLIT"); if (e && atoi(e) > 1) fix_max = atoi(e);
-  }
+  const int fix = gi_opt(GI_OPT_IGEMM_FIXUP);   // GI_IGEMM_FIXUP=0: finish-kernel path
+  int fix_max = gi_tune("GI_IGEMM_FIX_MAXSPLIT", 8);
+  if (fix_max < 2) fix_max = 8;
   bool fixup = fix && a.tickets && a.ws && a.force_splitk == 0 && tiles < 256 && kp.nk >= 8;
   bool half_n = false;
   if (fixup) {
@@ -561,8 +559,7 @@ int run(hipStream_t st, IgemmArgs& a) {
   if (fixup) {
   } else if (a.force_splitk > 0) splitk = a.force_splitk;
   else if (tiles < 256 && kp.nk >= 8) {   // fewer workgroups than CUs: split the reduction
-    static int target = -1;   // workgroups to aim for (GI_IGEMM_SPLIT_BLOCKS: tools only)
-    if (target < 0) { const char* e = getenv("GI_IGEMM_SPLIT_BLOCKS"); target = e ? atoi(e) : 384; }
+    const int target = gi_tune("GI_IGEMM_SPLIT_BLOCKS", 384);   // workgroups to aim for
     splitk = (target + tiles - 1) / tiles;
     if (splitk > kp.nk / 4) splitk = kp.nk / 4;
     if (splitk > 64) splitk = 64;
@@ -588,6 +585,8 @@ int run(hipStream_t st, IgemmArgs& a) {
   if (half_n) GI_TRY((launch_cfg<T, PHASE, 128, 64, 2, 2>(st, kp, grid)));
   else if (wide) GI_TRY((launch_cfg<T, PHASE, 128, 128, 2, 2>(st, kp, grid)));
   else GI_TRY((launch_cfg<T, PHASE, 256, 64, 4, 1>(st, kp, grid)));
+  gi_note_kernel(std::is_same<T, float>::value ? (fixup ? "igemm<f32,fixup>" : (splitk > 1 ? "igemm<f32,splitk>" : "igemm<f32>"))
+                                               : (fixup ? "igemm<f16,fixup>" : (splitk > 1 ? "igemm<f16,splitk>" : "igemm<f16>")));
   a.ntiles_out = mt * phases;
   if (splitk > 1 && !fixup) {
     const int RL = 256 / (a.cout / 4) > 0 ? 256 / (a.cout / 4) : 1;   // row lanes per block
@@ -612,9 +611,8 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a);   // igemm3.hip: 256xBN t
 int op_igemm7(hipStream_t st, int mode, IgemmArgs& a);   // igemm7.hip: 128xBN tiles, 4-stage ring, split-K with in-kernel fix-up
 
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a) {
-  // GI_IGEMM_VARIANT (tools / A-B timing only): 3 = LDS-DMA kernel (default), 1 = register-staged kernel only
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("GI_IGEMM_VARIANT"); variant = e ? atoi(e) : 3; }
+  // GI_IGEMM_VARIANT: 3 = LDS-DMA kernels (default), 1 = the register-staged kernel of this file only (what fp32 always runs)
+  const int variant = gi_opt(GI_OPT_IGEMM_VARIANT);
   if (dtype == GI_F16 && a.force_splitk == 0 && variant >= 3) {
     int rc = op_igemm3(st, phase_mode, a);
     if (rc != GI_ERR_UNSUPPORTED) return rc;

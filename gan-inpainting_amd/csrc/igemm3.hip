@@ -380,8 +380,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a);   // igemm5.hip: halo-res
 // returns GI_ERR_UNSUPPORTED when the shape is not served by this kernel (caller falls back)
 int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.cin > 2048) return GI_ERR_UNSUPPORTED;
-  static int use5 = -1;   // GI_IGEMM5: bit 0 / 1 / 2 = halo-resident kernel for mode 1 / 0 / 2 (tools: A/B; default all)
-  if (use5 < 0) { const char* e = getenv("GI_IGEMM5"); use5 = e ? atoi(e) : 7; }
+  const int use5 = gi_opt(GI_OPT_IGEMM5);   // GI_IGEMM5: bit 0 / 1 / 2 = halo-resident kernel for mode 1 / 0 / 2 (default all)
   if ((mode == 1 && (use5 & 1)) || (mode == 0 && (use5 & 2)) || (mode == 2 && (use5 & 4))) {
     const int rc = op_igemm5(st, mode, a);
     if (rc != GI_ERR_UNSUPPORTED) return rc;
@@ -393,8 +392,7 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
     const int tiles = ((M + 255) / 256) * (a.cout / BN) * nph;
     if (tiles < 128) return GI_ERR_UNSUPPORTED;
     // 128..255 tiles leave CUs idle (one 8-wave workgroup per CU): 64-wide N tiles double the workgroups
-    static int narrow = -1;   // GI_IGEMM3_NARROW=0 keeps 128-wide tiles (tools: A/B)
-    if (narrow < 0) { const char* e = getenv("GI_IGEMM3_NARROW"); narrow = e ? atoi(e) : 1; }
+    const int narrow = gi_tune("GI_IGEMM3_NARROW", 1);
     if (narrow && BN == 128 && tiles < 256) BN = 64;
   }
   int dev = 0;
@@ -473,6 +471,7 @@ int op_igemm3(hipStream_t st, int mode, IgemmArgs& a) {
     case 4: hipLaunchKernelGGL((igemm3_kernel<1, 64, 8>), g, b, LDS, st, kp); break;
     default: hipLaunchKernelGGL((igemm3_kernel<2, 64, 8>), g, b, LDS, st, kp); break;
   }
+  { static const char* nm[6] = {"igemm3<0,128>", "igemm3<1,128>", "igemm3<2,128>", "igemm3<0,64>", "igemm3<1,64>", "igemm3<2,64>"}; gi_note_kernel(nm[vi]); }
   GI_LAUNCH_CHECK();
   a.ntiles_out = kp.mtiles * nph;
   return GI_OK;

@@ -771,8 +771,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   if (mode != 2 && mtiles * (a.cout / BN) * nph < 128) return GI_ERR_UNSUPPORTED;
   if (mode == 0 && BN == 128 && mtiles * (a.cout / BN) < 256) {
     // 128..255 workgroups on 256 CUs (generator d4 at 256x256, bs=32): 64-wide N tiles double them
-    static int narrow = -1;   // GI_IGEMM5_NARROW=0 keeps 128-wide tiles (tools: A/B)
-    if (narrow < 0) { const char* e = getenv("GI_IGEMM5_NARROW"); narrow = e ? atoi(e) : 1; }
+    const int narrow = gi_tune("GI_IGEMM5_NARROW", 1);
     if (narrow) BN = 64;
   }
   const bool dual = mode == 1 && BN == 64;     // 64-channel N tiles: both px phases per workgroup (MODE 3)
@@ -826,8 +825,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   static bool attr[6] = {false, false, false, false, false, false};
   const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
                        (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
-  static int use6 = -1;   // GI_IGEMM6=0: the first-generation halo kernels (tools: A/B)
-  if (use6 < 0) { const char* e = getenv("GI_IGEMM6"); use6 = e ? atoi(e) : 1; }
+  const int use6 = gi_opt(GI_OPT_IGEMM6);   // GI_IGEMM6=0: the first-generation halo kernels (also the fallback beyond 2^31-byte tensors)
   if (use6 && mode != 2 && in_px * a.ldin * 2 < (1ll << 31) && (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) &&
       !(mode == 0 && a.relu_in)) {
     const int lds6 = 2 * 320 * 128 + 4 * BNk * 128;
@@ -855,14 +853,14 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
       } }
 #endif
     switch (v6) {
-      case 0: GI_K6(0, 128, false); break;
-      case 2: GI_K6(1, 128, false); break;
-      case 3: GI_K6(1, 128, true); break;
-      case 4: GI_K6(0, 64, false); break;
-      case 6: GI_K6(1, 64, false); break;
-      case 7: GI_K6(1, 64, true); break;
-      case 8: GI_K6(3, 128, false); break;
-      default: GI_K6(3, 128, true); break;
+      case 0: GI_K6(0, 128, false); gi_note_kernel("igemm6<0,128>"); break;
+      case 2: GI_K6(1, 128, false); gi_note_kernel("igemm6<1,128>"); break;
+      case 3: GI_K6(1, 128, true); gi_note_kernel("igemm6<1,128,relu>"); break;
+      case 4: GI_K6(0, 64, false); gi_note_kernel("igemm6<0,64>"); break;
+      case 6: GI_K6(1, 64, false); gi_note_kernel("igemm6<1,64>"); break;
+      case 7: GI_K6(1, 64, true); gi_note_kernel("igemm6<1,64,relu>"); break;
+      case 8: GI_K6(3, 128, false); gi_note_kernel("igemm6<3,128>"); break;
+      default: GI_K6(3, 128, true); gi_note_kernel("igemm6<3,128,relu>"); break;
     }
 #undef GI_K6
     GI_LAUNCH_CHECK();
@@ -873,6 +871,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
     static bool attr_dual = false;
     if (!attr_dual) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<3, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_dual = true; }
     hipLaunchKernelGGL((igemm5_kernel<3, 128>), dim3(grid), dim3(512), LDS, st, kp);
+    gi_note_kernel("igemm5<3,128>");
     GI_LAUNCH_CHECK();
     a.ntiles_out = mtiles * nph;
     return GI_OK;
@@ -887,6 +886,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
     case 4: hipLaunchKernelGGL((igemm5_kernel<1, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
     default: hipLaunchKernelGGL((igemm5_kernel<2, 64>), dim3(grid), dim3(512), LDS, st, kp); break;
   }
+  { static const char* nm[6] = {"igemm5<0,128>", "igemm5<1,128>", "igemm5<2,128>", "igemm5<0,64>", "igemm5<1,64>", "igemm5<2,64>"}; gi_note_kernel(nm[vi]); }
   GI_LAUNCH_CHECK();
   a.ntiles_out = mtiles * nph;
   return GI_OK;

@@ -372,19 +372,15 @@ const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
 int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   if (mode != 0 && mode != 1) return GI_ERR_UNSUPPORTED;
   if (a.cin % 64 != 0 || a.cout % 64 != 0 || a.force_splitk != 0) return GI_ERR_UNSUPPORTED;
-  static int use7 = -1, max_split = 8;    // (measured: d7 20.6 us with 16 splits, 18.6 us with 8: the last arriver's tail)   // GI_IGEMM7=0: igemm.hip serves these layers; GI_IGEMM7_MAXSPLIT (tools: A/B)
-  if (use7 < 0) {
-    const char* e = getenv("GI_IGEMM7"); use7 = e ? atoi(e) : 1;
-    e = getenv("GI_IGEMM7_MAXSPLIT"); if (e && atoi(e) >= 1) max_split = atoi(e);
-  }
-  if (!use7) return GI_ERR_UNSUPPORTED;
+  if (!gi_opt(GI_OPT_IGEMM7)) return GI_ERR_UNSUPPORTED;   // GI_IGEMM7=0: igemm.hip serves these layers
+  int max_split = gi_tune("GI_IGEMM7_MAXSPLIT", 8);   // (measured: d7 20.6 us with 16 splits, 18.6 us with 8: the last arriver's tail)
+  if (max_split < 1) max_split = 8;
   const int M = a.n * a.Hs * a.Ws;
   const int nph = mode == 1 ? 4 : 1;
   const int mtiles = (M + 127) / 128;
   int BN = (a.cout % 128 == 0 && mtiles * (a.cout / 128) * nph >= 64) ? 128 : 64;
-  {   // GI_IGEMM7_BN (tools: A/B): force the N tile
-    static int force_bn = -1;
-    if (force_bn < 0) { const char* e = getenv("GI_IGEMM7_BN"); force_bn = e ? atoi(e) : 0; }
+  {   // GI_IGEMM7_BN (ablation build): force the N tile
+    const int force_bn = gi_tune("GI_IGEMM7_BN", 0);
     if (force_bn == 64 || (force_bn == 128 && a.cout % 128 == 0)) BN = force_bn;
   }
   const int ntiles = a.cout / BN;
@@ -434,6 +430,7 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
     case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
     default: hipLaunchKernelGGL((igemm7_kernel<1, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
   }
+  { static const char* nm[4] = {"igemm7<0,128>", "igemm7<1,128>", "igemm7<0,64>", "igemm7<1,64>"}; gi_note_kernel(nm[vi]); }
   GI_LAUNCH_CHECK();
   a.ntiles_out = mtiles * nph;
   return GI_OK;

@@ -337,14 +337,14 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
       if (b->c && norm_kind == 0) { b->acc_off = net->acc_words; net->acc_words += 4 * b->acc_block(); }
   net->oAcc = A.take(net->acc_words * 8);
   net->oTickets = A.take((int64_t)GI_IGEMM_TICKETS * 4);
-  { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
+  net->use_acc = gi_opt(GI_OPT_BN_ACC);   // GI_BN_ACC=0: partial rows + finalize / sums launches
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
   net->slot_fused_u2.assign(n_slots, 0);
   net->slot_inference.assign(n_slots, 0);
   net->eval_gen.assign(n_slots, std::vector<uint64_t>(nbn, 0));
   net->bwd_pending.assign(nbn, BwdFuse());
-  { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }   // 0: materialise the last decoder level (tools: A/B)
+  net->fuse_head = gi_opt(GI_OPT_FUSE_HEAD);   // GI_FUSE_HEAD=0: materialise the last decoder level
   net->ext_mask.assign(n_slots, std::vector<const uint8_t*>(nd + 1, nullptr));
   *out = net;
   return GI_OK;
@@ -459,13 +459,13 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   for (int i = 2; i <= 4; ++i) { net->dbn[i].acc_off = net->acc_words; net->acc_words += 4 * net->dbn[i].acc_block(); }
   net->oAcc = A.take(net->acc_words * 8);
   net->oTickets = A.take((int64_t)GI_IGEMM_TICKETS * 4);
-  { const char* e = getenv("GI_BN_ACC"); net->use_acc = e ? atoi(e) : 1; }
+  net->use_acc = gi_opt(GI_OPT_BN_ACC);   // GI_BN_ACC=0: partial rows + finalize / sums launches
   net->gp_slot = n_slots;                      // one private activation set for the gradient penalty
   net->slot_base = A.take(S.size * (n_slots + 1));
   net->slot_n.assign(n_slots + 1, 0);
   net->slot_train.assign(n_slots + 1, 0);
   net->slot_fused_u2.assign(n_slots + 1, 0);
-  { const char* e = getenv("GI_FUSE_HEAD"); net->fuse_head = e ? atoi(e) : 1; }
+  net->fuse_head = gi_opt(GI_OPT_FUSE_HEAD);
   net->slot_groups.assign(n_slots + 1, 1);
   *out = net;
   return GI_OK;
@@ -714,8 +714,7 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
 // pixels: rows of the BatchNorm'd tensor; gemm_tiles: workgroups of the producing GEMM that will add (tiles x phases)
 BwdFuse bwd_fuse_plan(gi_net* net, int slot, const BN& bn, const void* x, int64_t pixels, int64_t gemm_tiles, float slope) {
   BwdFuse f;
-  static int on = -1;   // GI_BN_BWD_FUSE=0: reduce pass as a separate launch (tools: A/B)
-  if (on < 0) { const char* e = getenv("GI_BN_BWD_FUSE"); on = e ? atoi(e) : 1; }
+  const int on = gi_opt(GI_OPT_BN_BWD_FUSE);   // GI_BN_BWD_FUSE=0: reduce pass as a separate launch
   const int g = net->kind == 1 ? net->bn_groups : 1;
   if (!on || !net->use_acc || bn.acc_off < 0 || net->bwd_eval || net->dtype != GI_F16) return f;
   const int64_t pg = pixels / g;

@@ -8,7 +8,9 @@
 // commutes and never rounds, so the totals do not depend on the order the tiles finish in: results are
 // bit-reproducible, unlike fp32 atomics. Consumers convert back to double once.
 //   bit 63 of lo = "a non-finite or absurd value was added" -> the total reads NaN
-//   range: |value| < 2^43 per addend, up to 2^19 addends
+//   range: the hi word counts units of 2^-8, so a total must stay below 2^55 in magnitude (signed 64 bits); an addend is
+//   accepted below 2^40 (1.1e12: a 256-row tile of fp16's largest squares) and a replica receives at most 2^13 addends
+//   (tiles of a layer / replicas), i.e. |total| < 2^53; gi_stat_read returns NaN for a total beyond 2^54 all the same
 //
 // Layout of one accumulator block (structure of arrays): word[replica][group][w][c], w = {sum hi, sum lo, sumsq hi,
 // sumsq lo} (or any two quantities), group = BatchNorm population (0 / 1). The 64 lanes of one atomic wave
@@ -33,7 +35,7 @@ __device__ __forceinline__ unsigned long long* gi_stat_ptr(unsigned long long* b
 __device__ __forceinline__ void gi_stat_add(unsigned long long* base, int c, int rep, int group, int q, int ch, float s) {
   unsigned long long* hi = gi_stat_ptr(base, c, rep, group, 2 * q) + ch;
   unsigned long long* lo = hi + c;
-  if (!(fabsf(s) < 8.0e12f)) {     // inf, NaN, or beyond the fixed-point range
+  if (!(fabsf(s) < 1.0995116e12f)) {     // inf, NaN, or beyond the fixed-point range (2^40)
     atomicOr(lo, 0x8000000000000000ull);
     return;
   }
@@ -54,6 +56,7 @@ __device__ __forceinline__ double gi_stat_read(const unsigned long long* base, i
     lo += l & 0x7FFFFFFFFFFFFFFFull;
     bad |= l >> 63;
   }
-  if (bad) return __builtin_nan("");
-  return ((double)(long long)hi * 4294967296.0 + (double)lo) * 9.094947017729282e-13;   // * 2^-40
+  const long long h = (long long)hi;
+  if (bad || h > (1ll << 62) || h < -(1ll << 62)) return __builtin_nan("");   // (2^62 units of 2^-8 = 2^54)
+  return ((double)h * 4294967296.0 + (double)lo) * 9.094947017729282e-13;   // * 2^-40
 }

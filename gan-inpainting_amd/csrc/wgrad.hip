@@ -245,8 +245,7 @@ int wgrad_split(int dtype, int n, int Hs, int Ws, int ca, int cb, int* tiles_per
   const int P = n * Hs * Ws;
   const int tiles = (ca / 128) * (16 * cb / 128);
   const int ktiles = (P + BKP - 1) / BKP;
-  static int target = -1;   // workgroups to aim for (GI_WGRAD_BLOCKS: tools only)
-  if (target < 0) { const char* e = getenv("GI_WGRAD_BLOCKS"); target = e ? atoi(e) : 512; }   // 2 workgroups per CU in one wave; 1024 measured 10-28 % slower
+  const int target = gi_tune("GI_WGRAD_BLOCKS", 512);   // workgroups to aim for: 2 per CU in one wave; 1024 measured 10-28 % slower
   int split = (target + tiles - 1) / tiles;
   if (split > ktiles / 8) split = ktiles / 8;
   if (split < 1) split = 1;
@@ -289,6 +288,7 @@ int run(hipStream_t st, const WgradArgs& a) {
     attr_set = true;
   }
   hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), LDS, st, p);
+  gi_note_kernel(F16 ? "wgrad<f16>" : "wgrad<f32>");
   GI_LAUNCH_CHECK();
   if (p.part) {
     const int64_t c4 = out_floats / 4;
@@ -313,8 +313,7 @@ int64_t op_wgrad_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb)
 }
 
 int op_wgrad(hipStream_t st, int dtype, const WgradArgs& a) {
-  static int use2 = -1;   // GI_WGRAD2=0: always the register-staged kernel of this file (tools: A/B)
-  if (use2 < 0) { const char* e = getenv("GI_WGRAD2"); use2 = e ? atoi(e) : 1; }
+  const int use2 = gi_opt(GI_OPT_WGRAD2);   // GI_WGRAD2=0: always the register-staged kernel of this file
   if (dtype == GI_F16 && use2) {
     const int rc = op_wgrad2(st, a);
     if (rc != GI_ERR_UNSUPPORTED) return rc;

@@ -477,207 +477,6 @@ __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
   }
 }
 
-// wgrad4 (experiment, off by default: one wave per SIMD does not keep the matrix pipe fed - 90 us against wgrad3's 68 us):
-// the same 128 x 512 tile (taps ky, ky + 2; four kx; 64 L channels) on FOUR waves, one per SIMD, each owning one kx tap:
-// 128 S channels x (2 tap sets x 64 L channels) = 128 x 128 per wave, 256 accumulator registers (the unified register file gives a
-// single wave per SIMD 512). The eight-wave kernels are bound by the LDS: every transposing read (`ds_read_b64_tr_b16`, 8 cycles
-// of the LDS pipe) feeds 2.7 MFMAs there - the two S-halves re-read each B fragment, 768 reads per pixel tile and CU = 6100 cycles
-// against 6600 measured. Here a B fragment is read once and feeds 8 MFMAs, an A fragment 8: 256 reads per tile and CU (2048
-// cycles) beside 2048 cycles of MFMA per SIMD. Issue stream as wgrad3 (buffer-descriptor LDS-DMA, immediates for stage / tap
-// set, next tile's first fragments read during the last block).
-__global__ void __launch_bounds__(256, 1) wgrad4_kernel(WP2 p) {
-  constexpr int HST = 36, HROWS = 5;
-  constexpr int S_STAGE = 2 * 64 * 128;            // 16 KiB
-  constexpr int L_STAGE = 192 * 128;               // 24 KiB
-  constexpr int L_BASE = 3 * S_STAGE;
-  constexpr int SJ = 4, LJ = 6, NP = SJ + LJ;      // pieces per wave and tile
-  constexpr unsigned OOB = 0x80000000u;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kx = wave;
-  const int nbt = p.cb >> 6;
-  int bx = blockIdx.x;
-  const int ky = bx & 1; bx >>= 1;
-  const int b0 = (bx % nbt) * 64, a0 = (bx / nbt) * 128;
-  const int ks = blockIdx.y;
-  const int t0 = ks * p.tiles_per_split, t1 = min(p.ntile, t0 + p.tiles_per_split);
-  const int HL = 2 * p.Hs, WL = 2 * p.Ws;
-  const int txs = p.Ws >> 4, tys = p.Hs >> 2;
-  const int lg_txs = p.lgWs - 4, lg_tys = p.lgHs - 2;
-
-  const rsrc4_t rsS = make_rsrc4(p.S, (unsigned)((int64_t)p.n * p.Hs * p.Ws * p.ldS * 2));
-  const rsrc4_t rsL = make_rsrc4(p.L, (unsigned)((int64_t)p.n * HL * WL * p.ldL * 2));
-
-  const int lrow = lane >> 3;
-  const int lchunk = (lane & 7) ^ (lrow & 7);
-  int s_voff[SJ], l_voff[LJ], l_hr[LJ], l_hx[LJ];
-#pragma unroll
-  for (int j = 0; j < SJ; ++j) {
-    const int ps = wave * SJ + j;                  // 0..15: segment ps >> 3, pixel rows (ps & 7) * 8 ..
-    const int seg = ps >> 3, k = (ps & 7) * 8 + lrow;
-    const int ry = k >> 4, rx = k & 15;
-    s_voff[j] = ((ry * p.Ws + rx) * p.ldS + p.coffS + a0 + seg * 64) * 2 + lchunk * 16;
-  }
-#pragma unroll
-  for (int j = 0; j < LJ; ++j) {
-    const int hrow = (wave * LJ + j) * 8 + lrow;   // 0..191
-    const int hr = hrow / HST, hx = hrow - hr * HST;
-    l_hr[j] = (hr < HROWS && hx < 34) ? hr : 1 << 20;
-    l_hx[j] = hx;
-    l_voff[j] = ((2 * hr * WL + hx) * p.ldL + p.coffL + b0) * 2 + lchunk * 16;
-  }
-  auto issue_piece = [&](int t, auto STG, auto PIECE) {
-    constexpr int stage = decltype(STG)::value, j = decltype(PIECE)::value;
-    const bool live = t < t1;
-    const int xb = t & (txs - 1), yb = (t >> lg_txs) & (tys - 1), nn = t >> (lg_txs + lg_tys);
-    const int y0 = yb * 4, x0 = xb * 16;
-    if constexpr (j < SJ) {
-      const int sb = live ? ((nn * p.Hs + y0) * p.Ws + x0) * p.ldS * 2 : 0;
-      blds16w(rsS, live ? (unsigned)s_voff[j] : OOB, sb, smem + stage * S_STAGE + (wave * SJ + j) * 1024);
-    } else {
-      constexpr int jl = j - SJ;
-      const int Y0 = 2 * y0 - 1 + ky, X0 = 2 * x0 - 1;
-      const int Y = Y0 + 2 * l_hr[jl], X = X0 + l_hx[jl];
-      const bool ok = live && Y >= 0 && Y < HL && X >= 0 && X < WL;
-      const int lb = ((nn * HL + Y0) * WL + X0) * p.ldL * 2;
-      blds16w(rsL, ok ? (unsigned)(l_voff[jl] + lb) : OOB, 0, smem + L_BASE + stage * L_STAGE + (wave * LJ + jl) * 1024);
-    }
-  };
-
-  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
-  int aoff[2][2][4], boff[2][2][4];              // A: channel tile t of segment 0 (segment 1 = + 64 rows: an immediate)
-#pragma unroll
-  for (int ksx = 0; ksx < 2; ++ksx)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = ksx * 32 + 8 * g + 4 * h + q;
-      const int ry = k >> 4, rx = k & 15;
-      const int lrw = ry * HST + 2 * rx + kx;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int chunk = t * 2 + (pp >> 1);
-        aoff[ksx][h][t] = k * 128 + ((chunk ^ (k & 7)) << 4) + (pp & 1) * 8;
-        boff[ksx][h][t] = L_BASE + lrw * 128 + ((chunk ^ (lrw & 7)) << 4) + (pp & 1) * 8;
-      }
-    }
-  auto read_a = [&](auto STG, auto KSX, auto MT) -> h8_t {     // mt 0..7: segment mt >> 2, channel tile mt & 3
-    constexpr int stage = decltype(STG)::value, ksx = decltype(KSX)::value, mt = decltype(MT)::value;
-    constexpr int imm = stage * S_STAGE + (mt >> 2) * 64 * 128;
-    return tr16x2(smem + aoff[ksx][0][mt & 3] + imm, smem + aoff[ksx][1][mt & 3] + imm);
-  };
-  auto read_b = [&](auto STG, auto KSX, auto S2, auto NT) -> h8_t {
-    constexpr int stage = decltype(STG)::value, ksx = decltype(KSX)::value, s2 = decltype(S2)::value, nt = decltype(NT)::value;
-    if constexpr (s2 == 0) return tr16x2(smem + boff[ksx][0][nt] + stage * L_STAGE, smem + boff[ksx][1][nt] + stage * L_STAGE);
-    else return tr16x2(smem + (boff[ksx][0][nt] ^ 64) + stage * L_STAGE + HST * 128, smem + (boff[ksx][1][nt] ^ 64) + stage * L_STAGE + HST * 128);
-  };
-
-  f4_t acc[2][8][4];
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[s2][i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-  using I0 = std::integral_constant<int, 0>;
-  using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>;
-  typedef short s8_t __attribute__((ext_vector_type(8)));
-  const short rm = p.relu_S ? (short)0 : (short)-32768;
-  const s8_t rmin = {rm, rm, rm, rm, rm, rm, rm, rm};
-  auto relu_a = [&](h8_t& v) { v = __builtin_bit_cast(h8_t, __builtin_elementwise_max(__builtin_bit_cast(s8_t, v), rmin)); };
-
-  const int nt_tiles = t1 - t0;
-  h8_t af[8], bfA[4], bfB[4];
-  if (nt_tiles > 0) {
-    static_for<NP>([&](auto J) { issue_piece(t0, I0{}, J); });
-    static_for<NP>([&](auto J) { issue_piece(t0 + 1, I1{}, J); });
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    static_for<8>([&](auto MT) { af[decltype(MT)::value] = read_a(I0{}, I0{}, MT); });
-    static_for<4>([&](auto NT) { bfA[decltype(NT)::value] = read_b(I0{}, I0{}, I0{}, NT); });
-  }
-  // 128 MFMAs per tile in four blocks of 32 (k-half, tap set), row-major over (mt, nt). Pieces of tile i + 2 at MFMAs 4 + 9 q.
-  auto tile = [&](int i, auto STG, auto NXT, auto ISS) {
-    const int tnext2 = t0 + i + 2;
-    auto slot = [&](auto IDX) {
-      constexpr int idx = decltype(IDX)::value;
-      static_for<NP>([&](auto Q) {
-        constexpr int qq = decltype(Q)::value;
-        if constexpr (idx == 4 + 9 * qq) issue_piece(tnext2, ISS, Q);
-      });
-    };
-    // block 0: (k0, set 0) on af, bfA; reads bfB <- (k0, set 1)
-    static_for<32>([&](auto IDX) {
-      constexpr int idx = decltype(IDX)::value, mt = idx >> 2, nt = idx & 3;
-      if constexpr (nt == 0) relu_a(af[mt]);
-      acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bfA[nt], acc[0][mt][nt], 0, 0, 0);
-      if constexpr ((idx & 7) == 2) bfB[idx >> 3] = read_b(STG, I0{}, I1{}, std::integral_constant<int, (idx >> 3)>{});
-      slot(IDX);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // block 1: (k0, set 1) on af, bfB; reads bfA <- (k1, set 0); af[mt] <- k1 once its row of MFMAs has issued
-    static_for<32>([&](auto IDX) {
-      constexpr int idx = decltype(IDX)::value, mt = idx >> 2, nt = idx & 3;
-      acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bfB[nt], acc[1][mt][nt], 0, 0, 0);
-      if constexpr ((idx & 7) == 2) bfA[idx >> 3] = read_b(STG, I1{}, I0{}, std::integral_constant<int, (idx >> 3)>{});
-      if constexpr (nt == 3) af[mt] = read_a(STG, I1{}, std::integral_constant<int, mt>{});
-      slot(std::integral_constant<int, idx + 32>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // block 2: (k1, set 0) on af, bfA; reads bfB <- (k1, set 1)
-    static_for<32>([&](auto IDX) {
-      constexpr int idx = decltype(IDX)::value, mt = idx >> 2, nt = idx & 3;
-      if constexpr (nt == 0) relu_a(af[mt]);
-      acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bfA[nt], acc[0][mt][nt], 0, 0, 0);
-      if constexpr ((idx & 7) == 2) bfB[idx >> 3] = read_b(STG, I1{}, I1{}, std::integral_constant<int, (idx >> 3)>{});
-      slot(std::integral_constant<int, idx + 64>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    // the next tile (issued a whole step ago) must have landed in every wave's share: all but the 10 pieces of tile i + 2
-    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // block 3: (k1, set 1) on af, bfB; reads the NEXT tile's first fragments
-    static_for<32>([&](auto IDX) {
-      constexpr int idx = decltype(IDX)::value, mt = idx >> 2, nt = idx & 3;
-      acc[1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bfB[nt], acc[1][mt][nt], 0, 0, 0);
-      if constexpr ((idx & 7) == 2) bfA[idx >> 3] = read_b(NXT, I0{}, I0{}, std::integral_constant<int, (idx >> 3)>{});
-      if constexpr (nt == 3) af[mt] = read_a(NXT, I0{}, std::integral_constant<int, mt>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-  for (int i = 0; i < nt_tiles; i += 3) {
-    tile(i, I0{}, I1{}, I2{});
-    if (i + 1 < nt_tiles) tile(i + 1, I1{}, I2{}, I0{});
-    if (i + 2 < nt_tiles) tile(i + 2, I2{}, I0{}, I1{});
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-  const int64_t ldw = (int64_t)16 * p.cb;
-#pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const int colb = ((ky + 2 * s2) * 4 + kx) * p.cb + b0 + (lane & 15);
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = a0 + mt * 16 + (lane >> 4) * 4 + r;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int64_t o = (int64_t)row * ldw + colb + nt * 16;
-          const float v = acc[s2][mt][nt][r] * p.scale;
-          if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
-          else if (p.direct) p.dW[o] += v;
-          else atomicAdd(p.dW + o, v);
-        }
-      }
-  }
-}
-
 // dW[i] += sum_k part[k][i] in a fixed order (as in wgrad.hip)
 __global__ void __launch_bounds__(256) wgrad2_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int64_t count4, int split) {
   __shared__ f4_t red[3][64];
@@ -699,11 +498,7 @@ __global__ void __launch_bounds__(256) wgrad2_reduce_kernel(const float* __restr
   }
 }
 
-int wgrad2_nky() {   // GI_WGRAD2_NKY=1: one ky tap row per workgroup (tools: A/B)
-  static int nky = -1;
-  if (nky < 0) { const char* e = getenv("GI_WGRAD2_NKY"); nky = (e && atoi(e) == 1) ? 1 : 2; }
-  return nky;
-}
+constexpr int wgrad2_nky() { return 2; }   // ky tap rows per workgroup (the one-row form of round 1 moved 1.8x the bytes L2 -> LDS)
 
 int wgrad2_split(int n, int Hs, int Ws, int ca, int cb, int* tiles_per_split) {
   const int ntile = n * Hs * Ws / 64;      // 4 x 16 or 8 x 8 pixel tiles
@@ -756,33 +551,22 @@ int op_wgrad2(hipStream_t st, const WgradArgs& a) {
   constexpr int LDS = 3 * (2 * 64 * 128 + 192 * 128);
   static bool attr = false;
   if (!attr) {
-    GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr = true;
-  }
-  const int nky = wgrad2_nky();
-  const dim3 grid((a.ca / 128) * (a.cb / 64) * (4 / nky), split);
-  static int pipe = -1;   // GI_WGRAD3=0: the unpipelined two-ky kernel (tools: A/B)
-  if (pipe < 0) {
-    const char* e = getenv("GI_WGRAD3"); pipe = e ? atoi(e) : 1;
     GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    attr = true;
   }
+  const dim3 grid((a.ca / 128) * (a.cb / 64) * (4 / wgrad2_nky()), split);
+  const int pipe = gi_opt(GI_OPT_WGRAD3);   // GI_WGRAD3=0: the unpipelined two-ky kernel (also the fallback beyond 2^31-byte tensors)
   // wgrad3 addresses both tensors with 32-bit byte offsets (buffer descriptors; 2^31 marks out-of-range)
   const bool small32 = (int64_t)a.n * a.Hs * a.Ws * a.ldS * 2 < (1ll << 31) && (int64_t)a.n * 4 * a.Hs * a.Ws * a.ldL * 2 < (1ll << 31);
-  static int four = -1;   // GI_WGRAD4=1: the four-wave kernel (measured slower: 90 / 83 / 88 us against 68 / 69 / 73 us; tools: A/B)
-  if (four < 0) {
-    const char* e = getenv("GI_WGRAD4"); four = e ? atoi(e) : 0;
-    GI_HIP(hipFuncSetAttribute((const void*)wgrad4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-  }
   if (square) {   // 8 x 8 maps: wgrad3 only, and only where the partial-tile pass stays small (u5: 42.7 + 23.2 us against 86.7 us
     // for wgrad.hip; with four splits - d5 - the 67 MB of partial tiles cost more than the faster K loop gains: 48.7 against 45.2)
-    if (!(nky == 2 && pipe && small32) || split > 2) return GI_ERR_UNSUPPORTED;
+    if (!(pipe && small32) || split > 2) return GI_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(wgrad3_kernel<3>, grid, dim3(512), LDS, st, p);
-  } else if (nky == 2 && four && small32) hipLaunchKernelGGL(wgrad4_kernel, grid, dim3(256), LDS, st, p);
-  else if (nky == 2 && pipe && small32) hipLaunchKernelGGL(wgrad3_kernel<4>, grid, dim3(512), LDS, st, p);
-  else if (nky == 2) hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(512), LDS, st, p);
-  else hipLaunchKernelGGL(wgrad2_kernel<1>, grid, dim3(512), LDS, st, p);
+    gi_note_kernel("wgrad3<3>");
+  } else if (pipe && small32) { hipLaunchKernelGGL(wgrad3_kernel<4>, grid, dim3(512), LDS, st, p); gi_note_kernel("wgrad3<4>"); }
+  else { hipLaunchKernelGGL(wgrad2_kernel<2>, grid, dim3(512), LDS, st, p); gi_note_kernel("wgrad2<2>"); }
   GI_LAUNCH_CHECK();
   if (p.part) {
     const int64_t c4 = out_floats / 4;

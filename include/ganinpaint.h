@@ -47,6 +47,28 @@ typedef struct gi_net gi_net;
 const char* gi_last_error(void);
 int gi_version(void);
 
+/* ---- run-time options (process-wide): which kernel family serves a layer. Every shape is served under every setting
+ * (the alternatives are the fallbacks for shapes the default kernels do not take, e.g. tensors beyond 2^31 bytes); results
+ * agree to rounding (tests/test_options_gpu.py runs each). value < 0 restores the default, which is the environment
+ * variable of the same name if set (read once), else the number in brackets. Nothing here exists in the reference.
+ *   GI_IGEMM5 [7]         bit 0 / 1 / 2: halo-resident implicit GEMM for sub-pixel phases / 4x4-s2 gather / 3x3-s1 (else igemm3)
+ *   GI_IGEMM6 [1]         0: first-generation halo kernels (igemm5) instead of the buffer-descriptor LDS-DMA ones
+ *   GI_IGEMM7 [1]         0: small-M layers on the generic kernel (igemm.hip) instead of the four-stage ring kernel
+ *   GI_IGEMM_FIXUP [1]    0: split-K partial sums added by a finish launch instead of the last arriver inside the GEMM
+ *   GI_IGEMM_VARIANT [3]  1: fp16 layers on the register-staged generic kernel only
+ *   GI_BN_ACC [1]         0: BatchNorm statistics through partial rows + finalize launches (read at net creation)
+ *   GI_FUSE_HEAD [1]      0: last norm + activation in front of a network's head as a separate pass (read at net creation)
+ *   GI_HEAD_FAST [1]      0: PatchGAN head on the generic kernels
+ *   GI_BN_BWD_FUSE [1]    0: BatchNorm-backward reduction as its own launch instead of the producing GEMM's epilogue
+ *   GI_BN_BWD_SMALL [512] largest pixel count served by the one-launch BatchNorm backward (0: never)
+ *   GI_WGRAD2 [1]         0: weight gradients on the register-staged kernel (wgrad.hip) only
+ *   GI_WGRAD3 [1]         0: the unpipelined two-tap-row weight-gradient kernel instead of wgrad3 */
+int gi_set_option(const char* name, int value);
+int gi_get_option(const char* name, int* value);
+/* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.
+ * "igemm6<1,128,relu>", "igemm7<0,64>", "wgrad3<4>" (tests assert which kernel served a shape); "" before the first. */
+const char* gi_debug_last_kernel(void);
+
 /* ---- context ------------------------------------------------------------------------------ */
 int gi_ctx_create(int device_id, void* hip_stream, gi_ctx** out);
 int gi_ctx_destroy(gi_ctx* ctx);
@@ -313,6 +335,39 @@ int gi_conv_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_pac
 int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_phase, void* out,
                         int n, int H, int W, int ca, int ldin, int cb, int ldout, int relu_in,
                         int act_out, float* ws, int64_t ws_bytes);
+/* The same two layers with the fused epilogues the networks use (all optional, zero = absent; nothing here exists in the
+ * reference: these are the seams at which its separate BatchNorm / activation modules, networks.py:285-318, are folded into the
+ * GEMMs). Fields marked (returned) say whether the kernel that served the shape implemented the fusion; if not, the caller
+ * runs the separate pass. */
+typedef struct gi_igemm_ex {
+  int relu_cend;                 /* with relu_in: only input channels [0, relu_cend) need the ReLU (0 = all) */
+  /* activation backward on the result: out = (out + [mask > 0] * add) * (mask > 0 ? 1 : mask_slope); mask / add laid out
+   * like out with leading dimensions ldmask / ldadd (the LeakyReLU backward of a norm-free layer, networks.py:287) */
+  const void* mask; int ldmask; float mask_slope;
+  const void* add; int ldadd;
+  /* BatchNorm batch statistics of the result: every tile adds its column sum / sum of squares to the exact accumulator
+   * block stat_acc (gi_stat_acc_words(ca) zeroed 64-bit words; tile t -> replica t mod stat_reps, a power of two <= 4;
+   * stat_pg > 0: GEMM rows >= stat_pg belong to a second population). partials: per-tile rows instead, [tiles][2][c] */
+  unsigned long long* stat_acc; int stat_reps; int stat_pg;
+  float* partials;
+  /* BatchNorm-backward reduction of the layer whose output gradient this GEMM produces: with x = bwd_x (raw convolution
+   * output, ld bwd_ldx), dz = g * (fma(x, scale, shift) > 0 ? 1 : bwd_slope), xhat = (x - mean) * inv, every tile adds
+   * sum dz and sum dz * xhat to bwd_acc (layout as stat_acc; populations of bwd_pg output pixels, vectors bwd_stride apart) */
+  const void* bwd_x; int bwd_ldx;
+  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
+  float bwd_slope; unsigned long long* bwd_acc; int bwd_reps; int64_t bwd_pg;
+  int mask_applied, bwd_applied, stat_used, ntiles_out;   /* (returned) */
+} gi_igemm_ex;
+int gi_conv_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out,
+                          int n, int H, int W, int cb, int ldin, int ca, int ldout, int relu_in,
+                          int act_out, float* ws, int64_t ws_bytes, gi_igemm_ex* ex);
+int gi_convT_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w_phase, void* out,
+                           int n, int H, int W, int ca, int ldin, int cb, int ldout, int relu_in,
+                           int act_out, float* ws, int64_t ws_bytes, gi_igemm_ex* ex);
+/* exact accumulator blocks (csrc/stat_acc.h): words per block of c channels; totals of the two quantities of a population
+ * as doubles, out_dev[2][c] (device) */
+int64_t gi_stat_acc_words(int c);
+int gi_stat_acc_read(gi_ctx* ctx, const unsigned long long* acc, int c, int reps, int group, double* out_dev);
 /* dW[a][ky][kx][b] += scale * sum_{n,y,x} S[n,y,x,a] * L[n,2y-1+ky,2x-1+kx,b] */
 int gi_wgrad_s2(gi_ctx* ctx, int dtype, const void* S, const void* L, float* dW, int n, int Hs, int Ws,
                 int ca, int ldS, int cb, int ldL, int relu_S, float scale);
