@@ -7,7 +7,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libganinpaint.so")
+# GI_LIB_PATH: another build of the same library (tools/: A/B runs against an ablation build); there is no other fallback
+LIB_PATH = os.environ.get("GI_LIB_PATH") or os.path.join(_HERE, "libganinpaint.so")
 
 GI_F32, GI_F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2

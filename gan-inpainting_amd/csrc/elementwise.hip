@@ -179,6 +179,16 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
   const int64_t total = pixels * cpp;
   const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int cc = (int)(gid0 & (cpp - 1));
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t esz = (int64_t)sizeof(T);
+  // the pass is HBM-bound: a thread's first four 16-byte loads are issued BEFORE the scale / shift vectors are derived (FUSED:
+  // a chain of dependent accumulator / parameter loads of 2 - 3 us during which every co-resident block would otherwise
+  // request nothing), and from then on the next four are in flight while the current four are finished
+  int64_t gid = gid0;
+  bool full = gid + 3 * stride < total;
+  u4_t r[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) r[u] = full ? *(const u4_t*)(x + (((gid + u * stride) >> lg) * c + cc * EPC) * esz) : u4_t{0u, 0u, 0u, 0u};
   float sc[EPC], sh[EPC], sc1[G2 ? EPC : 1], sh1[G2 ? EPC : 1];
   if constexpr (FUSED) {
     extern __shared__ __attribute__((aligned(16))) float aff[];   // [groups][2][c]
@@ -246,17 +256,18 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
     }
     store_vec<T, EPC>(y, pix * ldy + coffy + cc * EPC, v);
   };
-  // four independent 16-byte loads in flight per thread before any arithmetic (the pass is HBM-bound: 64 B per lane
-  // outstanding instead of 16)
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t esz = (int64_t)sizeof(T);
-  int64_t gid = gid0;
-  for (; gid + 3 * stride < total; gid += 4 * stride) {
-    u4_t r[4];
+  while (full) {
+    const int64_t gn = gid + 4 * stride;
+    const bool nfull = gn + 3 * stride < total;
+    u4_t rn[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = *(const u4_t*)(x + (((gid + u * stride) >> lg) * c + cc * EPC) * esz);
+    for (int u = 0; u < 4; ++u) rn[u] = nfull ? *(const u4_t*)(x + (((gn + u * stride) >> lg) * c + cc * EPC) * esz) : u4_t{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int u = 0; u < 4; ++u) finish((gid + u * stride) >> lg, r[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = rn[u];
+    gid = gn;
+    full = nfull;
   }
   for (; gid < total; gid += stride) finish(gid >> lg, *(const u4_t*)(x + ((gid >> lg) * c + cc * EPC) * esz));
 }
@@ -325,6 +336,41 @@ __device__ __forceinline__ void load_dz(const BwdP& p, int64_t pix, int ch0, boo
   if (p.g2) load_vec<T, EPC>(p.g2, pix * p.ldg2 + p.coffg2 + ch0, in.g2);
   if (with_y) load_vec<T, EPC>(p.y, pix * p.ldy + p.coffy + ch0, in.y);
 }
+// The same loads as raw 16-byte chunks, so that a thread can keep the loads of SEVERAL pixels in flight before it converts
+// and computes anything (these passes are HBM-bound; with one pixel per iteration a lane has 32 - 48 bytes outstanding and
+// the chip 4 - 6 MB, i.e. 2 TB/s at the ~2 us a loaded memory system takes to answer).
+struct RawIn { u4_t x, g1, g2, y; };
+template <typename T>
+__device__ __forceinline__ void load_raw(const BwdP& p, int64_t pix, int ch0, bool with_x, bool with_y, RawIn& r) {
+  constexpr int64_t ES = (int64_t)sizeof(T);
+  if (with_x) r.x = *(const u4_t*)(p.x + (pix * p.c + ch0) * ES);
+  if (p.g1) r.g1 = *(const u4_t*)(p.g1 + (pix * p.ldg1 + p.coffg1 + ch0) * ES);
+  if (p.g2) r.g2 = *(const u4_t*)(p.g2 + (pix * p.ldg2 + p.coffg2 + ch0) * ES);
+  if (with_y) r.y = *(const u4_t*)(p.y + (pix * p.ldy + p.coffy + ch0) * ES);
+}
+template <typename T, int EPC>
+__device__ __forceinline__ void cvt_raw(u4_t raw, float (&v)[EPC]) {
+  if constexpr (std::is_same<T, half_t>::value) {
+    const h8_t h = __builtin_bit_cast(h8_t, raw);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = (float)h[e];
+  } else {
+    const f4_t f = __builtin_bit_cast(f4_t, raw);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) v[e] = f[e];
+  }
+}
+// the loads of one chunk with the input combination known at compile time (IN: 1 = g1, 2 = g2, 3 = both; LOAD_Y: the saved
+// activation): fields that are not loaded cost no registers
+template <typename T, int IN, bool LOAD_Y>
+struct RawB { u4_t x, g1, g2, y; };
+template <typename T, int EPC>
+__device__ __forceinline__ void unpack_raw(const BwdP& p, const RawIn& r, bool with_x, bool with_y, float (&xv)[EPC], DzIn<T, EPC>& in) {
+  if (with_x) cvt_raw<T, EPC>(r.x, xv);
+  if (p.g1) cvt_raw<T, EPC>(r.g1, in.g1);
+  if (p.g2) cvt_raw<T, EPC>(r.g2, in.g2);
+  if (with_y) cvt_raw<T, EPC>(r.y, in.y);
+}
 // sgn: values with the sign of the activation's input (the saved y, or fma(x, scale, shift) of the forward)
 template <typename T, int EPC>
 __device__ __forceinline__ void finish_dz(const BwdP& p, const DzIn<T, EPC>& in, const float (&sgn)[EPC], float (&dz)[EPC]) {
@@ -351,8 +397,9 @@ __device__ __forceinline__ void compute_dz(const BwdP& p, int64_t pix, int ch0, 
   finish_dz<T, EPC>(p, in, in.y, dz);
 }
 
-// pass 1: partial sums of dz and dz*xhat
-template <typename T>
+// pass 1: partial sums of dz and dz*xhat. IN / LOAD_Y: which inputs exist (RawB); the host picks the instantiation from the
+// pointers (a null g1 / g2 contributes 0, exactly as the run-time test of finish_dz does)
+template <typename T, int IN, bool LOAD_Y>
 __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
   constexpr int EPC = 16 / (int)sizeof(T);
   __shared__ float red[2 * 256 * EPC];
@@ -369,18 +416,40 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
     for (int e = 0; e < EPC; ++e) { sc[e] = p.scale[so + q * EPC + e]; sh[e] = p.shift[so + q * EPC + e]; }
   }
   const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
-  for (int64_t r = r0 + rl; r < r1; r += RL) {
-    float dz[EPC], xv[EPC];
-    DzIn<T, EPC> in;
-    load_vec<T, EPC>(p.x, r * p.c + q * EPC, xv);
-    load_dz<T, EPC>(p, r, q * EPC, need_y && !p.scale, in);
-    if (p.scale || !need_y) {
+  constexpr int U = 4;   // rows whose loads are in flight together (the sums still run over the rows in ascending order)
+  constexpr int64_t ES = (int64_t)sizeof(T);
+  const bool have_scale = p.scale != nullptr;
+  for (int64_t r = r0 + rl; r < r1; r += (int64_t)U * RL) {
+    RawB<T, IN, LOAD_Y> raw[U];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) in.y[e] = p.scale ? fmaf(xv[e], sc[e], sh[e]) : 1.f;
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + (int64_t)u * RL;
+      if (rr < r1) {
+        raw[u].x = *(const u4_t*)(p.x + (rr * p.c + q * EPC) * ES);
+        if constexpr ((IN & 1) != 0) raw[u].g1 = *(const u4_t*)(p.g1 + (rr * p.ldg1 + p.coffg1 + q * EPC) * ES);
+        if constexpr ((IN & 2) != 0) raw[u].g2 = *(const u4_t*)(p.g2 + (rr * p.ldg2 + p.coffg2 + q * EPC) * ES);
+        if constexpr (LOAD_Y) raw[u].y = *(const u4_t*)(p.y + (rr * p.ldy + p.coffy + q * EPC) * ES);
+      }
     }
-    finish_dz<T, EPC>(p, in, in.y, dz);
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) { s[e] += dz[e]; sx[e] = fmaf(dz[e], (xv[e] - mu[e]) * iv[e], sx[e]); }
+    for (int u = 0; u < U; ++u) {
+      if (r + (int64_t)u * RL < r1) {
+        float dz[EPC], xv[EPC];
+        DzIn<T, EPC> in;
+        cvt_raw<T, EPC>(raw[u].x, xv);
+        if constexpr ((IN & 1) != 0) cvt_raw<T, EPC>(raw[u].g1, in.g1);
+        if constexpr ((IN & 2) != 0) cvt_raw<T, EPC>(raw[u].g2, in.g2);
+        if constexpr (LOAD_Y) cvt_raw<T, EPC>(raw[u].y, in.y);
+        else {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) in.y[e] = have_scale ? fmaf(xv[e], sc[e], sh[e]) : 1.f;
+        }
+        (void)need_y;
+        finish_dz<T, EPC>(p, in, in.y, dz);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { s[e] += dz[e]; sx[e] = fmaf(dz[e], (xv[e] - mu[e]) * iv[e], sx[e]); }
+      }
+    }
   }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) { red[threadIdx.x * EPC + e] = s[e]; red[256 * EPC + threadIdx.x * EPC + e] = sx[e]; }
@@ -456,6 +525,16 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
   const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int cc = (int)(gid0 & (cpp - 1));
   constexpr int NG = G2 ? 2 : 1;
+  constexpr int U = 4;   // chunks whose loads are in flight together
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
+  const bool load_y = need_y && !(HAS_BN && p.scale);
+  // the first U chunks are requested BEFORE the coefficients are derived (HAS_BN == 2: a chain of dependent accumulator and
+  // parameter loads during which all co-resident blocks would otherwise request nothing)
+  RawIn raw[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (gid0 + u * stride < total) load_raw<T>(p, (gid0 + u * stride) >> lg, cc * EPC, HAS_BN != 0, load_y, raw[u]);
   float k1[NG][EPC], k2[NG][EPC], k3[NG][EPC], sc[NG][EPC], sh[NG][EPC];
   if constexpr (HAS_BN == 2) {
     extern __shared__ __attribute__((aligned(16))) float coef[];   // [groups][5][c]: k1, k2, k3, scale, shift
@@ -503,32 +582,149 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
       }
     }
   }
-  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
-  for (int64_t gid = gid0; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int64_t pix = gid >> lg;
-    float dz[EPC];
-    if (!HAS_BN) {
-      compute_dz<T, EPC>(p, pix, cc * EPC, dz);
-    } else {
-      float xv[EPC];
+  for (int64_t gid = gid0; gid < total; gid += U * stride) {
+    if (gid != gid0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (gid + u * stride < total) load_raw<T>(p, (gid + u * stride) >> lg, cc * EPC, HAS_BN != 0, load_y, raw[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (gid + u * stride >= total) break;
+      const int64_t pix = (gid + u * stride) >> lg;
+      float dz[EPC], xv[EPC];
       DzIn<T, EPC> in;
-      load_vec<T, EPC>(p.x, pix * p.c + cc * EPC, xv);
-      load_dz<T, EPC>(p, pix, cc * EPC, need_y && !p.scale, in);
-      const int g = (G2 && pix >= p.pg) ? 1 : 0;
-      if (p.scale || !need_y) {
+      unpack_raw<T, EPC>(p, raw[u], HAS_BN != 0, load_y, xv, in);
+      if (!HAS_BN) {
+        if (!need_y) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) in.y[e] = p.scale ? fmaf(xv[e], G2 ? (g ? sc[NG - 1][e] : sc[0][e]) : sc[0][e], G2 ? (g ? sh[NG - 1][e] : sh[0][e]) : sh[0][e]) : 1.f;
+          for (int e = 0; e < EPC; ++e) in.y[e] = 1.f;
+        }
+        finish_dz<T, EPC>(p, in, in.y, dz);
+      } else {
+        const int g = (G2 && pix >= p.pg) ? 1 : 0;
+        if (p.scale || !need_y) {
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) in.y[e] = p.scale ? fmaf(xv[e], G2 ? (g ? sc[NG - 1][e] : sc[0][e]) : sc[0][e], G2 ? (g ? sh[NG - 1][e] : sh[0][e]) : sh[0][e]) : 1.f;
+        }
+        finish_dz<T, EPC>(p, in, in.y, dz);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float a1 = G2 ? (g ? k1[NG - 1][e] : k1[0][e]) : k1[0][e];
+          const float a2 = G2 ? (g ? k2[NG - 1][e] : k2[0][e]) : k2[0][e];
+          const float a3 = G2 ? (g ? k3[NG - 1][e] : k3[0][e]) : k3[0][e];
+          dz[e] = fmaf(a1, dz[e], fmaf(a2, xv[e], a3));
+        }
       }
-      finish_dz<T, EPC>(p, in, in.y, dz);
+      store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, dz);
+    }
+  }
+}
+
+// The apply pass of the accumulator path (HAS_BN == 2) for the input combinations the networks produce, built for bytes in
+// flight: measured with hardware counters (round 3, critic conv2 at n = 64: 200 MB in 57 us), a wave of the generic kernel
+// above lives ~18 us - a chain of dependent accumulator / parameter loads, then eight load -> wait -> compute -> store
+// rounds - and its 100 - 250 registers leave 2 - 4 waves per SIMD, so the chip has ~7 MB outstanding where a plain copy of
+// the same three streams runs at 6.7 TB/s (tools/micro/stream_bw.hip). Here the coefficient vectors stay in LDS (ten
+// ds_read_b128 per chunk instead of 40 - 80 registers), only the pointers that exist are loaded (IN: 1 = g1, 2 = g2 masked by
+// the activation's sign, 3 = both; LOAD_Y: the sign comes from the saved activation, else from fma(x, scale, shift)), two
+// chunks per thread are requested before the coefficients are derived and the next two before the current two are finished.
+// Same arithmetic, same order: results are bit-identical to the generic kernel.
+template <typename T, int IN, bool LOAD_Y, bool G2>
+__global__ void __launch_bounds__(256) act_bn_bwd_apply_acc_kernel(BwdP p) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int64_t ES = (int64_t)sizeof(T);
+  constexpr int NG = G2 ? 2 : 1;
+  constexpr int U = 2;
+  extern __shared__ __attribute__((aligned(16))) float coef[];   // [groups][5][c]: k1, k2, k3, scale, shift
+  const int c = p.c;
+  const int cpp = c / EPC;
+  const int lg = 31 - __builtin_clz(cpp);
+  const int64_t total = p.pixels * cpp;
+  const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int cc = (int)(gid0 & (cpp - 1));
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  auto load = [&](int64_t gid, RawB<T, IN, LOAD_Y>& r) {
+    const int64_t pix = gid >> lg;
+    r.x = *(const u4_t*)(p.x + (pix * c + cc * EPC) * ES);
+    if constexpr ((IN & 1) != 0) r.g1 = *(const u4_t*)(p.g1 + (pix * p.ldg1 + p.coffg1 + cc * EPC) * ES);
+    if constexpr ((IN & 2) != 0) r.g2 = *(const u4_t*)(p.g2 + (pix * p.ldg2 + p.coffg2 + cc * EPC) * ES);
+    if constexpr (LOAD_Y) r.y = *(const u4_t*)(p.y + (pix * p.ldy + p.coffy + cc * EPC) * ES);
+  };
+  RawB<T, IN, LOAD_Y> cur[U], nxt[U];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const float a1 = G2 ? (g ? k1[NG - 1][e] : k1[0][e]) : k1[0][e];
-        const float a2 = G2 ? (g ? k2[NG - 1][e] : k2[0][e]) : k2[0][e];
-        const float a3 = G2 ? (g ? k3[NG - 1][e] : k3[0][e]) : k3[0][e];
-        dz[e] = fmaf(a1, dz[e], fmaf(a2, xv[e], a3));
+  for (int u = 0; u < U; ++u)
+    if (gid0 + u * stride < total) load(gid0 + u * stride, cur[u]);
+  for (int ch = threadIdx.x; ch < c; ch += 256)
+    for (int g = 0; g < NG; ++g) {
+      float s1 = 0.f, s2 = 0.f;
+      if (p.acc) {
+        s1 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 0, ch);
+        s2 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 1, ch);
+      }
+      const int so = g * p.stat_stride + ch;
+      const float iv = p.inv[so];
+      const float a1 = p.gamma[ch] * iv;
+      const float a2 = -a1 * iv * s2 * p.invM;
+      float* o = coef + (int64_t)g * 5 * c;
+      o[ch] = a1;
+      o[c + ch] = a2;
+      o[2 * c + ch] = -a1 * s1 * p.invM - a2 * p.mean[so];
+      o[3 * c + ch] = p.scale ? p.scale[so] : 0.f;
+      o[4 * c + ch] = p.scale ? p.shift[so] : 0.f;
+      if (blockIdx.x == 0) {     // parameter gradients accumulate population by population, as separate calls would
+        if (p.dbeta) p.dbeta[ch] += s1 * p.inv_loss_scale;
+        if (p.dgamma) p.dgamma[ch] += s2 * p.inv_loss_scale;
       }
     }
-    store_vec<T, EPC>(p.dx, pix * p.c + cc * EPC, dz);
+  if (blockIdx.x == 0 && p.zero_next) zero_words64(p.zero_next, p.zero_words);
+  __syncthreads();
+  const bool have_scale = p.scale != nullptr;
+  const int act = p.act;
+  const float drop_scale = p.drop_scale;
+  for (int64_t gid = gid0; gid < total; gid += U * stride) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (gid + (U + u) * stride < total) load(gid + (U + u) * stride, nxt[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (gid + u * stride < total) {
+        const int64_t pix = (gid + u * stride) >> lg;
+        const float* o = coef + ((G2 && pix >= p.pg) ? 5 * c : 0) + cc * EPC;
+        float xv[EPC], sg[EPC], g1v[EPC], g2v[EPC], k[EPC], out[EPC];
+        cvt_raw<T, EPC>(cur[u].x, xv);
+        if constexpr (LOAD_Y) cvt_raw<T, EPC>(cur[u].y, sg);
+        else {
+          float scv[EPC], shv[EPC];
+          load_f32<EPC>(o + 3 * c, scv);
+          load_f32<EPC>(o + 4 * c, shv);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) sg[e] = have_scale ? fmaf(xv[e], scv[e], shv[e]) : 1.f;
+        }
+        if constexpr ((IN & 1) != 0) cvt_raw<T, EPC>(cur[u].g1, g1v);
+        if constexpr ((IN & 2) != 0) cvt_raw<T, EPC>(cur[u].g2, g2v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const bool pos = sg[e] > 0.f;
+          float g = (IN & 1) ? g1v[e] : 0.f;
+          if constexpr ((IN & 2) != 0) g += pos ? g2v[e] : 0.f;
+          float sl = 1.f;
+          if (act == GI_ACT_LRELU) sl = pos ? 1.f : 0.2f;
+          else if (act == GI_ACT_RELU) sl = pos ? 1.f : 0.f;
+          out[e] = g * sl * drop_scale;
+        }
+        // dx = k1 * dz + (k2 * x + k3), the same fmaf nest as the generic kernel
+        float k1v[EPC], k3v[EPC];
+        load_f32<EPC>(o, k1v);
+        load_f32<EPC>(o + c, k);
+        load_f32<EPC>(o + 2 * c, k3v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) out[e] = fmaf(k1v[e], out[e], fmaf(k[e], xv[e], k3v[e]));
+        store_vec<T, EPC>(p.dx, pix * c + cc * EPC, out);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
   }
 }
 
@@ -1299,6 +1495,22 @@ int op_bwd_rows_per_block(int64_t pixels) {
   return rows_per_block_for(pixels, &blocks);
 }
 
+static int launch_bwd_reduce(hipStream_t st, int dtype, const BwdP& p, int blocks) {
+  const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
+  const bool load_y = need_y && !p.scale;
+  const int in = (p.g1 ? 1 : 0) | (p.g2 ? 2 : 0);
+  GI_REQUIRE(in != 0, "act_bn_bwd: no upstream gradient");
+#define GI_RED(T, IN_, LY_) hipLaunchKernelGGL((act_bn_bwd_reduce_kernel<T, IN_, LY_>), dim3(blocks), dim3(256), 0, st, p)
+#define GI_RED_T(IN_, LY_) do { if (dtype == GI_F16) GI_RED(half_t, IN_, LY_); else GI_RED(float, IN_, LY_); } while (0)
+  if (in == 1) { if (load_y) GI_RED_T(1, true); else GI_RED_T(1, false); }
+  else if (in == 2) { if (load_y) GI_RED_T(2, true); else GI_RED_T(2, false); }
+  else { if (load_y) GI_RED_T(3, true); else GI_RED_T(3, false); }
+#undef GI_RED_T
+#undef GI_RED
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
 int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   const int epc = dtype == GI_F16 ? 8 : 4;
   const int Q = a.c / epc;
@@ -1337,28 +1549,40 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   }
   if (a.has_bn && a.acc) {
     // exact accumulators: reduce pass (train mode only) + apply pass, no sums launch in between
-    const int grid3 = nblocks(a.pixels * Q, 8);
+    const int grid3 = nblocks(a.pixels * Q, gi_tune("GI_BWD_APPLY_CPT", 8));
     const size_t lds = (size_t)groups * 5 * a.c * sizeof(float);
     if (!a.eval_bn) {
       GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
                  (long long)p.pg, p.rows_per_block);
       p.acc = a.acc;
       if (!a.reduce_done) {
-        if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks * groups), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
-        GI_LAUNCH_CHECK();
+        GI_TRY(launch_bwd_reduce(st, dtype, p, blocks * groups));
       }
       p.zero_next = a.zero_next; p.zero_words = a.zero_words;
     } else {
       p.dgamma = nullptr; p.dbeta = nullptr;
     }
-    if (groups == 2) {
+    const bool need_y = a.g2 != nullptr || a.act != GI_ACT_NONE;
+    const bool load_y = need_y && !p.scale;
+    const int in = (a.g1 ? 1 : 0) | (a.g2 ? 2 : 0);
+    // the input combinations the networks produce (critic: g1; encoder: g1 + g2; decoder: g2, with the saved activation where
+    // dropout follows the norm) take the kernel built for bytes in flight; anything else the generic one
+#define GI_APPLY_ACC(T, IN_, LY_, G2_) hipLaunchKernelGGL((act_bn_bwd_apply_acc_kernel<T, IN_, LY_, G2_>), dim3(grid3), dim3(256), lds, st, p)
+#define GI_APPLY_ACC_T(IN_, LY_, G2_) do { if (dtype == GI_F16) GI_APPLY_ACC(half_t, IN_, LY_, G2_); else GI_APPLY_ACC(float, IN_, LY_, G2_); } while (0)
+    if (in == 1 && !load_y && groups == 2) GI_APPLY_ACC_T(1, false, true);
+    else if (in == 1 && !load_y && groups == 1) GI_APPLY_ACC_T(1, false, false);
+    else if (in == 3 && !load_y && groups == 1) GI_APPLY_ACC_T(3, false, false);
+    else if (in == 2 && !load_y && groups == 1) GI_APPLY_ACC_T(2, false, false);
+    else if (in == 2 && load_y && groups == 1) GI_APPLY_ACC_T(2, true, false);
+    else if (groups == 2) {
       if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 2, true>), dim3(grid3), dim3(256), lds, st, p);
       else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 2, true>), dim3(grid3), dim3(256), lds, st, p);
     } else {
       if (dtype == GI_F16) hipLaunchKernelGGL((act_bn_bwd_apply_kernel<half_t, 2, false>), dim3(grid3), dim3(256), lds, st, p);
       else hipLaunchKernelGGL((act_bn_bwd_apply_kernel<float, 2, false>), dim3(grid3), dim3(256), lds, st, p);
     }
+#undef GI_APPLY_ACC_T
+#undef GI_APPLY_ACC
   } else if (a.has_bn && a.eval_bn) {
     // running-statistics BatchNorm is a per-channel affine map: the batch-mean terms vanish (sums = 0)
     hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, 0, a.c, a.sums, (float*)nullptr, (float*)nullptr, 0.f, 1,
@@ -1369,9 +1593,7 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   } else if (a.has_bn) {
     GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
                (long long)p.pg, p.rows_per_block);
-    if (dtype == GI_F16) hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<half_t>, dim3(blocks * groups), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(act_bn_bwd_reduce_kernel<float>, dim3(blocks * groups), dim3(256), 0, st, p);
-    GI_LAUNCH_CHECK();
+    GI_TRY(launch_bwd_reduce(st, dtype, p, blocks * groups));
     hipLaunchKernelGGL(bwd_sums_kernel, dim3(a.c), dim3(256), 0, st, a.partials, blocks, a.c, a.sums, a.dgamma, a.dbeta, a.inv_loss_scale,
                        groups, a.gamma, a.save_mean, a.save_invstd, p.scale, p.shift, a.stat_stride, 1.f / (float)p.pg);
     GI_LAUNCH_CHECK();
