@@ -262,6 +262,15 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   __syncthreads();
 
   // ---- split-K fix-up by the last arriver of the tile ---------------------------------------------------------------------
+  // Hand-off form: guides/MI355X_MICROARCH.md, "Valid forms", first row of the table of hand-offs measured with sc1 loads in
+  // place of the acquire: EVERY payload store is a 16-byte sc1 (write-through) buffer store, every storing wave drains them
+  // (s_waitcnt vmcnt(0)), a workgroup barrier, then ONE lane's agent-scope atomic add on the tile's ticket; the workgroup
+  // whose add returned splitk - 1 is the consumer: its other waves pass a workgroup barrier the adding lane then joins, and
+  // EVERY load of the handed-off bytes is a 16-byte sc1 buffer load to registers (one workgroup per CU: 96 - 128 KiB of
+  // LDS). That row is a measured property of gfx950 / ROCm 7.2, not an architectural guarantee of the LLVM memory model;
+  // the alternative (release fence in every workgroup + acquire in the last arriver) measured 1.6x slower on these layers.
+  // The tickets are zero at bind time and every launch leaves them zero (the last arriver resets its tile's ticket); a launch
+  // that FAILS leaves the context unusable anyway (GI_ERR_HIP), so a stale ticket never meets a later launch of a live context.
   if (p.splitk > 1) {
     constexpr int NF = MT * NT;
     constexpr int TILE_BYTES = BM * BN * 4;

@@ -83,8 +83,9 @@ def run_epochs(state, loaders, exp_dir, logger, device, net_G, nets_D, batch_fn,
     loader's third item (the segmentation labels of dataset.py:35-51) when pass_extra is set."""
     num_epochs, save_every, evaluate_every = state["numepoch"], state["saveevery"], state["evalevery"]
     log_every = state.get("logevery", 50)
-    flow_G = util.GradFlow(net_G)
-    flows_D = [util.GradFlow(d) for d in nets_D]
+    gscale = step.sync.grad_scale() if (step is not None and getattr(step, "sync", None) is not None) else 1.0
+    flow_G = util.GradFlow(net_G, gscale)
+    flows_D = [util.GradFlow(d, gscale) for d in nets_D]
     history, eval_hist = [], []
     side = step.side_stream() if step is not None else None
     side_keys = set(step.side_keys()) if step is not None else set()

@@ -46,8 +46,12 @@ class GradFlow:
     """mean(|grad|) of every parameter whose name has no 'bias' (minimaxgan_l1.py:103-108,
     :180-182), computed by one kernel and read back with one copy instead of one .item() per tensor."""
 
-    def __init__(self, net):
+    def __init__(self, net, scale=1.0):
+        """scale: factor applied to the measured means - 1/world_size under data parallelism, where the flat gradient buffer
+        holds the SUM over the ranks until the optimizer kernel divides (parallel.GradSync.grad_scale), so that the logged
+        values are those of the averaged gradient a single-process run would log."""
         self.net = net
+        self.scale = float(scale)
         inv = [t for t in net._inv if t["kind"] <= 1 and "bias" not in t["name"]]
         self.names = [t["name"] for t in inv]
         dev = net.device
@@ -60,7 +64,7 @@ class GradFlow:
         g = self.net.flat_grads()
         B.check(B.lib().gi_grad_absmean(B.get_ctx(g.device), B.ptr(g), B.ptr(self.off), B.ptr(self.len), len(self.names),
                                         B.ptr(self.out)))
-        return self.out
+        return self.out if self.scale == 1.0 else self.out * self.scale
 
     def as_dict(self):
         vals = self.measure().tolist()

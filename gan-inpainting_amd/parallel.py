@@ -18,10 +18,15 @@ class GradSync:
     """bucket_floats=None (default): ONE collective per launched range - the ranges are the backward's completion phases
     (generator: decoder 26.5 M floats, inner encoder 12.6 M, outer encoder 2.7 M; critic: conv4 + head, conv3..1), large
     messages for 7 x 153 GB/s of xGMI per GPU; a number splits a range into buckets of that many floats.
-    Every network has its own communication stream and pending list (`key`, default id(flat)): the critic's reduction
-    (issued from the critic's side stream) and the generator's never queue behind each other.
+    Every network has its own communication stream and pending list (`key`, default id(flat)), so a network's reduction is
+    ordered only behind ITS gradients. The collectives themselves share ONE communicator (torch: the process group's RCCL
+    communicator and its internal stream; abi: one ncclComm per GradSync): RCCL runs the operations of a communicator one
+    after the other, in the order every rank issued them - the critic's and the generator's reductions do queue behind each
+    other there, and all ranks must launch them in the same order (they do: the step schedule is identical on every rank).
     comm='torch' uses torch.distributed (RCCL behind backend "nccl", gloo on CPU); comm='abi' drives RCCL through the
-    library's own C entry points (gi_comm_* / gi_allreduce_sum_f32: include/ganinpaint.h), one communicator per GradSync."""
+    library's own C entry points (gi_comm_* / gi_allreduce_sum_f32: include/ganinpaint.h; executed on one rank only so
+    far - experimental until a multi-GPU run has exercised it); its communicator is created by prepare(device), which the
+    step classes call before the first batch, not in the middle of a step."""
 
     def __init__(self, bucket_floats=None, group=None, use_side_stream=True, comm=None):
         if not dist.is_initialized():
@@ -70,6 +75,12 @@ class GradSync:
             B.check(lib.gi_comm_create(raw, self.rank, self.world, device.index or 0, C.byref(h)))
             self._abi = h
         return self._abi
+
+    def prepare(self, device):
+        """Create what the first launch() would otherwise create lazily in the middle of a step (the C-ABI communicator: a
+        collective rendezvous of all ranks)."""
+        if self.comm == "abi" and self.world > 1 and torch.device(device).type == "cuda":
+            self._abi_comm(torch.device(device))
 
     def launch(self, flat, begin=0, end=None, key=None):
         """Start the SUM all-reduce of flat[begin:end] (asynchronously on GPU tensors)."""

@@ -51,6 +51,9 @@ def shard_rows(df, rank, world, batchsize):
     """Rows of `df` for this rank: the first floor(len / (world*batchsize)) * world*batchsize rows, interleaved, so that
     all ranks get the same number of full batches (drop_last loaders)."""
     keep = (len(df) // (world * batchsize)) * world * batchsize
+    if keep == 0:
+        raise ValueError(f"{len(df)} rows cannot fill one batch of {batchsize} on each of {world} ranks (every rank would run zero batches "
+                         f"per epoch): lower --batchsize or the number of ranks")
     return df.iloc[:keep].iloc[rank::world].reset_index(drop=True)
 
 

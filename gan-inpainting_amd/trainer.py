@@ -92,6 +92,7 @@ class _StepBase:
             # mark the network dirty: re-derive packed weights once per update instead of once per forward
             n.always_sync = False
         if sync is not None:
+            sync.prepare(net_G.device)
             sync.broadcast_parameters([net_G] + self.Ds)    # replicas start identical whatever the ranks' RNG state
             if hasattr(net_G, "set_dropout_seed"):          # ... but draw their own dropout masks
                 net_G.set_dropout_seed(0x5EED0000 + 1000 * sync.rank)

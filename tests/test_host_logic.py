@@ -101,7 +101,10 @@ def test_real_data_shards_have_equal_batch_counts():
     import pandas as pd
     import gan_inpainting_amd  # noqa: F401
     from gan_inpainting_amd import train
-    for rows, world, bs in ((127, 2, 32), (1000, 8, 32), (64, 2, 32), (63, 2, 32), (5000, 3, 7)):
+    import pytest
+    with pytest.raises(ValueError, match="zero batches"):      # fewer rows than one batch per rank: loud, not an empty epoch
+        train.shard_rows(pd.DataFrame({"groundtruth_source": [f"g{i}" for i in range(63)]}), 0, 2, 32)
+    for rows, world, bs in ((127, 2, 32), (1000, 8, 32), (64, 2, 32), (5000, 3, 7)):
         df = pd.DataFrame({"groundtruth_source": [f"g{i}" for i in range(rows)]})
         shards = [train.shard_rows(df, r, world, bs) for r in range(world)]
         counts = {len(s) // bs for s in shards}
