@@ -1,0 +1,30 @@
+// Kernel arguments of the halo-resident implicit GEMMs (igemm5.hip: igemm5 / igemm6; igemm8.hip), filled by op_igemm5.
+#pragma once
+#include "common.h"
+
+struct KP5 {
+  const char* in;
+  const char* w;      // [4 phases][cout][4*cin] (K order: tap, channel)
+  char* out;
+  const char* zero;
+  const float* bias;
+  float* partials;
+  unsigned long long* stat_acc; int stat_pg, stat_reps;   // IgemmArgs::stat_acc
+  int Hs, Ws, n;      // the small grid (MODE 1: input, MODE 0: output)
+  int TH, TW;         // patch of the small grid, TH*TW = 256; TW a power of two
+  int tiles_x, tiles_per_img, mtiles;
+  int cin, ldin, coffin;
+  int cout, ldout, coffout;
+  int nchunk;         // cin / 64
+  int relu_in, relu_cend, act_out;
+  int ntiles;
+  const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
+  const char* add; int ldadd, coffadd;
+  // fused BatchNorm-backward reduction (IgemmArgs::bwd_*)
+  const char* bwd_x; int bwd_ldx;
+  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
+  float bwd_slope;
+  unsigned long long* bwd_acc; int bwd_reps; int bwd_pg_tiles;   // bwd_pg_tiles: M tiles per BatchNorm population (0: one population)
+  int dbg_epi;        // builds with -DGI_ABLATION only (GI_EPI_DBG): 1 = all tiles store into one 64 KiB window (no HBM write burst)
+};
+

@@ -24,36 +24,12 @@
 
 #include "common.h"
 #include "stat_acc.h"
+#include "halo_args.h"
 
 const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
+int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp);   // igemm8.hip
 
 namespace {
-
-struct KP5 {
-  const char* in;
-  const char* w;      // [4 phases][cout][4*cin] (K order: tap, channel)
-  char* out;
-  const char* zero;
-  const float* bias;
-  float* partials;
-  unsigned long long* stat_acc; int stat_pg, stat_reps;   // IgemmArgs::stat_acc
-  int Hs, Ws, n;      // the small grid (MODE 1: input, MODE 0: output)
-  int TH, TW;         // patch of the small grid, TH*TW = 256; TW a power of two
-  int tiles_x, tiles_per_img, mtiles;
-  int cin, ldin, coffin;
-  int cout, ldout, coffout;
-  int nchunk;         // cin / 64
-  int relu_in, relu_cend, act_out;
-  int ntiles;
-  const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
-  const char* add; int ldadd, coffadd;
-  // fused BatchNorm-backward reduction (IgemmArgs::bwd_*)
-  const char* bwd_x; int bwd_ldx;
-  const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
-  float bwd_slope;
-  unsigned long long* bwd_acc; int bwd_reps; int bwd_pg_tiles;   // bwd_pg_tiles: M tiles per BatchNorm population (0: one population)
-  int dbg_epi;        // builds with -DGI_ABLATION only (GI_EPI_DBG): 1 = all tiles store into one 64 KiB window (no HBM write burst)
-};
 
 __device__ __forceinline__ float act5(float v, int act) {
   if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
@@ -825,6 +801,17 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   static bool attr[6] = {false, false, false, false, false, false};
   const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
                        (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
+  // igemm8 (igemm8.hip): the same tile on four waves, two workgroups per CU. GI_IGEMM8: 0 off, 1 (default) layers whose grid
+  // gives every CU at least two workgroups (with one per CU half the wave slots stay empty: measured d3 / u4 / critic conv4,
+  // 256 workgroups, 10 - 16 % slower than igemm6; every layer with >= 512 workgroups 3 - 16 % faster), 2 every eligible layer
+  const int use8 = gi_opt(GI_OPT_IGEMM8);
+  if (use8 && mode != 2 && (dual || BN == 128) && a.cin % 32 == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
+      (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&
+      (use8 >= 2 || grid >= gi_tune("GI_IGEMM8_MINGRID", 512))) {
+    GI_TRY(op_igemm8_launch(st, mode, dual, a.relu_in != 0, grid, kp));
+    a.ntiles_out = mtiles * nph;
+    return GI_OK;
+  }
   const int use6 = gi_opt(GI_OPT_IGEMM6);   // GI_IGEMM6=0: the first-generation halo kernels (also the fallback beyond 2^31-byte tensors)
   if (use6 && mode != 2 && in_px * a.ldin * 2 < (1ll << 31) && (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) &&
       !(mode == 0 && a.relu_in)) {

@@ -1,0 +1,491 @@
+// igemm8: the halo-resident implicit GEMM of igemm6 (igemm5.hip; Conv2d 4x4 / s2 / p1 of lib/models/networks.py:285-318 as a
+// stride-2 gather, MODE 0, or as sub-pixel phases, MODE 1 / 3) re-cut so that TWO workgroups share a CU.
+//
+// Why. igemm6 runs one 8-wave workgroup per CU (200 VGPRs x 8 waves, 144 KiB of LDS). Its per-tile fixed costs - launch and
+// offset set-up 2.9 us, the wait for the first halo and weight slices 3.1 us, the epilogue 2 - 5.75 us (measured by ablation,
+// DESIGN.md 4.1g) - are serial with the K loop because nothing else is resident: on the layers with a 16-step K loop (d2, u2,
+// the critic's conv2 and its input gradient) they are 40 - 55 % of a tile's time, and on every layer the eight waves reach
+// their barrier, their fragment reads and their MFMAs in lockstep (two waves per SIMD running the same program:
+// guides/MI355X_MICROARCH.md, "Two waves per SIMD", item 9). A persistent form of igemm6 was measured slower (registers).
+//
+// What changes. A workgroup is FOUR waves with the same 256 x 128 output tile: every wave owns 64 pixels x all 128 columns
+// (accumulators 128 registers; 12 fragment reads per 32 MFMAs = 0.375 per MFMA instead of 0.5), the K step is 32 channels:
+//   LDS per workgroup: halo 2 x 320 rows x 64 B = 40 KiB | weight ring 4 stages x 128 rows x 64 B = 32 KiB  -> 72 KiB,
+// so two workgroups (2 x 4 waves = the same two waves per SIMD) are resident per CU and the hardware overlaps one's
+// prologue / epilogue / barrier waits with the other's MFMAs. Per wave and per MFMA the LDS-DMA issue rate (2 weight pieces
+// + 1.25 halo pieces per 32 MFMAs), the bytes per MAC (26 KiB per 256 x 128 x 64 MACs) and the wait / barrier schedule are
+// igemm6's: a step (tap t of channel chunk c) waits for everything but the pieces issued during the previous step, passes
+// ONE workgroup barrier, and issues the weight slice of step s + 3 and (taps 0, 1) the next chunk's halo between its MFMAs.
+// Rows are 64 bytes (32 channels); a 1 KiB LDS-DMA piece is 16 rows; 16-byte chunk q of row R sits at physical chunk
+// q ^ ((R >> 1) & 3) (applied to the per-lane DMA source offset): `ds_read_b128` of 16 consecutive rows is conflict-free
+// for every alignment of the first row (enumerated over the instruction's four lane groups).
+// Fragment schedule of a step (32 MFMAs = 4 pixel tiles x 8 column tiles, column half H0 = tiles 0..3, H1 = tiles 4..7):
+//   in registers at the barrier: the pixel fragments a[0..3] and the column fragments b[0..3] of this step (read during the
+//   previous step's H1: the data of a step lands one step early); during H0: b[4..7] (MODE 3 also the four pixel fragments
+//   of px 1, whose halo rows are one column to the right); during H1: a[0..3], b[0..3] of the NEXT step.
+// MODE 3 (64 output channels per N tile): columns 0..63 = px 0, 64..127 = px 1 of the same 64 channels, as in igemm6.
+// K order per accumulator: 32-channel chunks ascending, taps 0..3 inside a chunk (igemm6: 64-channel chunks, per tap both
+// 32-channel halves) - the two kernels agree to fp32 rounding, not bit for bit.
+#include "common.h"
+#include "stat_acc.h"
+#include "halo_args.h"
+
+namespace {
+
+__device__ __forceinline__ float act8(float v, int act) {
+  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// ---- epilogue (contract of igemm3 / epilogue5): bias / activation, per-tile column statistics, the tile staged through LDS
+//      and stored with 16-byte rows; optional fused activation backward and BatchNorm-backward reduction. 256 threads, wave w
+//      holds rows 64 w .. 64 w + 63 x 128 columns. -----------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][8], char* smem, int tid, int lane, int wave, int mt_idx,
+                                          int ph, int py, int px, int n0, int img, int y0, int x0, int lgTW) {
+  constexpr bool DUAL = MODE == 3;
+  constexpr bool PH = MODE == 1 || MODE == 3;
+  constexpr int BM = 256, BN = 128, MT = 4, NT = 8;
+  const int lr = lane & 15, lq = lane >> 4;
+  auto out_pixel = [&](int m) -> int {
+    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+    if constexpr (PH) return (img * 2 * p.Hs + 2 * (y0 + ty_l) + py) * (2 * p.Ws) + 2 * (x0 + tx_l) + px;   // DUAL: + 1 for px 1, below
+    else return (img * p.Hs + y0 + ty_l) * p.Ws + x0 + tx_l;
+  };
+  constexpr int SLD = BN + 8;
+  half_t* stg = (half_t*)smem;
+  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4 waves][BN][2]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int ch = nt * 16 + 4 * lq;                     // column of the tile (DUAL: px * 64 + channel)
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      h4_t o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[mt][nt][r] + bs[r];
+        s[r] += v;
+        q[r] += v * v;
+        o[r] = (half_t)act8(v, p.act_out);
+      }
+      *(h4_t*)(stg + (wave * 64 + mt * 16 + lr) * SLD + ch) = o;
+    }
+    if (p.partials || p.stat_acc) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+      }
+      if (lr == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { red[(wave * BN + ch + r) * 2] = s[r]; red[(wave * BN + ch + r) * 2 + 1] = q[r]; }
+      }
+    }
+  }
+  __syncthreads();
+  if ((p.partials || p.stat_acc) && tid < BN) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s += red[(i * BN + tid) * 2]; q += red[(i * BN + tid) * 2 + 1]; }
+    const int phr = MODE == 1 ? ph : (DUAL ? py * 2 + (tid >> 6) : 0);       // sub-pixel phase of this column
+    const int col = DUAL ? (tid & 63) : tid;
+    if (p.stat_acc) {   // a patch lies inside one image, i.e. inside one BatchNorm population
+      const int grp = (p.stat_pg > 0 && mt_idx * BM >= p.stat_pg) ? 1 : 0, rep = (mt_idx + phr) & (p.stat_reps - 1);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 0, n0 + col, s);
+      gi_stat_add(p.stat_acc, p.cout, rep, grp, 1, n0 + col, q);
+    } else {
+      const int64_t trow = (int64_t)mt_idx + (int64_t)p.mtiles * phr;
+      p.partials[(trow * 2 + 0) * p.cout + n0 + col] = s;
+      p.partials[(trow * 2 + 1) * p.cout + n0 + col] = q;
+    }
+  }
+  constexpr int CPRO = BN / 8;          // 16-byte chunks per row
+  const int oc = tid % CPRO;
+  const bool bwd = !DUAL && p.bwd_acc != nullptr;
+  float bsc[8], bsh[8], bmu[8], biv[8], bs[8], bsx[8];
+  if (bwd) {
+    const int go = (p.bwd_pg_tiles > 0 && mt_idx >= p.bwd_pg_tiles) ? p.bwd_stride : 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = go + n0 + oc * 8 + e;
+      bsc[e] = p.bwd_scale[ch]; bsh[e] = p.bwd_shift[ch]; bmu[e] = p.bwd_mean[ch]; biv[e] = p.bwd_inv[ch];
+      bs[e] = bsx[e] = 0.f;
+    }
+  }
+  // a thread copies 16 rows (one 16-byte chunk each), eight at a time: all global loads of the eight rows (fused mask, second
+  // gradient, BatchNorm input) go out before the first store (as epilogue5)
+  constexpr int RP = 256 / CPRO;        // rows per pass of the workgroup
+  constexpr int NR = 8;
+  const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
+#pragma unroll 1
+  for (int h = 0; h < BM / (RP * NR); ++h) {
+    int opxs[NR];
+    u4_t mk[NR], ad[NR], xs[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = tid / CPRO + (h * NR + k) * RP;
+      opxs[k] = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
+      const int64_t opx = opxs[k];
+      if (p.mask) mk[k] = *(const u4_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
+      if (p.mask && p.add) ad[k] = *(const u4_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
+      if (bwd) xs[k] = *(const u4_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = tid / CPRO + (h * NR + k) * RP;
+      const int64_t opx = opxs[k];
+      const int64_t o = opx * p.ldout + p.coffout + och;
+      u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+      if (bwd) {
+        const h8_t xv = __builtin_bit_cast(h8_t, xs[k]);
+        const h8_t gv = __builtin_bit_cast(h8_t, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xf = (float)xv[e];
+          const float dz = (float)gv[e] * (fmaf(xf, bsc[e], bsh[e]) > 0.f ? 1.f : p.bwd_slope);
+          bs[e] += dz;
+          bsx[e] = fmaf(dz, (xf - bmu[e]) * biv[e], bsx[e]);
+        }
+      }
+      if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
+        const h8_t m = __builtin_bit_cast(h8_t, mk[k]);
+        h8_t hv = __builtin_bit_cast(h8_t, v);
+        if (p.add) {
+          const h8_t a8 = __builtin_bit_cast(h8_t, ad[k]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bool pos = (float)m[e] > 0.f;
+            const float g = (float)hv[e] + (pos ? (float)a8[e] : 0.f);
+            hv[e] = (half_t)(pos ? g : g * p.mask_slope);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) hv[e] = (float)m[e] > 0.f ? hv[e] : (half_t)((float)hv[e] * p.mask_slope);
+        }
+        v = __builtin_bit_cast(u4_t, hv);
+      }
+      *(u4_t*)(p.out + o * 2) = v;
+    }
+  }
+  if (bwd) {
+    // lanes oc, oc + 16, oc + 32, oc + 48 of a wave hold the same channels: fold them, then the 4 waves through LDS.
+    // (row order per thread differs from epilogue5's - 16 rows of a 4-wave workgroup instead of 8 of an 8-wave one - so
+    //  these fp32 sums agree with igemm6's to rounding, not bit for bit; the accumulators they go to are exact)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int off = CPRO; off < 64; off <<= 1) { bs[e] += __shfl_xor(bs[e], off); bsx[e] += __shfl_xor(bsx[e], off); }
+    }
+    __syncthreads();      // the staged tile has been read by every thread
+    float* fold = (float*)smem;   // [4 waves][BN][2]
+    if (lane < CPRO) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { fold[(wave * BN + oc * 8 + e) * 2] = bs[e]; fold[(wave * BN + oc * 8 + e) * 2 + 1] = bsx[e]; }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s += fold[(w * BN + tid) * 2]; q += fold[(w * BN + tid) * 2 + 1]; }
+      const int grp = (p.bwd_pg_tiles > 0 && mt_idx >= p.bwd_pg_tiles) ? 1 : 0, rep = (mt_idx + (MODE == 1 ? ph : 0)) & (p.bwd_reps - 1);
+      gi_stat_add(p.bwd_acc, p.cout, rep, grp, 0, n0 + tid, s);
+      gi_stat_add(p.bwd_acc, p.cout, rep, grp, 1, n0 + tid, q);
+    }
+  }
+}
+
+template <int MODE, bool RELU>
+__global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
+  static_assert(MODE == 0 || MODE == 1 || MODE == 3, "4-tap modes");
+  constexpr bool DUAL = MODE == 3;
+  constexpr bool PH = MODE == 1 || MODE == 3;
+  constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups (parity classes) per channel chunk
+  constexpr int NTAP = 4;
+  constexpr int PADX = DUAL ? 2 : 1;
+  constexpr int BN = 128, BK = 32, NW = 4;
+  constexpr int AJ = 5;                                 // halo pieces (16 rows x 64 B) per wave and group: 320 rows
+  constexpr int A_BYTES = AJ * NW * 1024;               // 20 KiB per buffer
+  constexpr int B_BYTES = BN * 64;                      // 8 KiB per stage
+  constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;         // + 4 ring stages: 72 KiB
+  constexpr int BJ = (BN / 16) / NW;                    // weight-slice pieces per wave and step (2)
+  constexpr int MT = 4, NT = 8, NH = 4;                 // NH: column tiles per half step
+  constexpr unsigned OOB = 0x80000000u;                 // beyond any tensor (sizes are checked < 2^31 bytes): reads as zeros
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- XCD-aware tile order (as igemm5 / igemm6)
+  const int nyz = p.ntiles * (DUAL ? 2 : (PH ? 4 : 1));
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int mt_idx = (local / nyz) * 8 + xcd;
+  if (mt_idx >= p.mtiles) return;
+  const int yz = local % nyz;
+  const int nt_idx = yz % p.ntiles;
+  const int ph = yz / p.ntiles;
+  const int py = DUAL ? ph : (ph >> 1), px = DUAL ? 0 : (ph & 1);
+  const int n0 = nt_idx * (DUAL ? 64 : BN);
+  const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
+  const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
+  const int HC = p.TW + PADX, HR = p.TH + 1;
+  const int Ktot2 = (PH ? 4 : 16) * p.cin * 2;          // bytes per weight row
+  const int64_t phase_bytes = (int64_t)p.cout * Ktot2;
+  const int Win = 2 * p.Ws, Hin = 2 * p.Hs;             // mode 0: the large (input) grid
+
+  const int64_t in_bytes = (int64_t)p.n * (MODE == 0 ? 4 : 1) * p.Hs * p.Ws * p.ldin * 2;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)in_bytes, 0x00020000);
+  const char* wbase = p.w + (MODE == 1 ? ph * phase_bytes : (DUAL ? (py * 2) * phase_bytes : 0));
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, (int)(DUAL ? 2 * phase_bytes : phase_bytes), 0x00020000);
+
+  // ---- per-lane piece offsets (loop invariant): lane l of a piece = row l >> 2, LDS chunk l & 3 = logical chunk (l & 3) ^ s(row)
+  const int lrow = lane >> 2, lc = lane & 3;
+  unsigned voffA[NQ][AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; ++j) {
+    const int r = (wave * AJ + j) * 16 + lrow;
+    const int hr = r / HC, hc = r - hr * HC;
+    const int cb = (lc ^ ((r >> 1) & 3)) * 16;
+    if constexpr (MODE != 0) {
+      const int iy = y0 + py - 1 + hr, ix = x0 + (MODE == 1 ? px : 0) - 1 + hc;   // DUAL: columns x0-1 .. x0+TW
+      const bool ok = hr < HR && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+      voffA[0][j] = ok ? (unsigned)((((img * p.Hs + iy) * p.Ws + ix) * p.ldin + p.coffin) * 2 + cb) : OOB;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {   // halo (hr,hc) of parity class (qy,qx) is input pixel (2*(y0+hr) - qy, 2*(x0+hc) - qx)
+        const int iy = 2 * (y0 + hr) - (q >> 1), ix = 2 * (x0 + hc) - (q & 1);
+        const bool ok = hr < HR && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        voffA[q][j] = ok ? (unsigned)((((img * Hin + iy) * Win + ix) * p.ldin + p.coffin) * 2 + cb) : OOB;
+      }
+    }
+  }
+  unsigned voffB[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; ++j) {
+    const int rb = (wave * BJ + j) * 16 + lrow;                     // row of the B tile (0..127)
+    const int cb = (lc ^ ((rb >> 1) & 3)) * 16;
+    if constexpr (DUAL) voffB[j] = (unsigned)((rb >> 6) * phase_bytes + (int64_t)(n0 + (rb & 63)) * Ktot2 + cb);   // rows 64.. = px 1
+    else voffB[j] = (unsigned)((int64_t)(n0 + rb) * Ktot2 + cb);
+  }
+
+  // ---- fragment read offsets (loop invariant) -----------------------------------------------------------------------------
+  const int lr = lane & 15, lq = lane >> 4;
+  const int lgTW = 31 - __builtin_clz(p.TW);
+  int rdA[MT][NTAP];                   // (pixel tile, tap) inside an A buffer; DUAL: px 0
+  // DUAL, px 1: its halo rows lie one column to the right, so tap (ty, tx = 1) of px 1 reads the rows of px 0's tap (ty, tx = 0)
+  // (rdA[mt][2 ty]); only its tx = 0 taps (column tx_l + 2) need addresses of their own: [pixel tile][ty]
+  int rdA2[DUAL ? MT : 1][2];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = wave * 64 + mt * 16 + lr;
+    const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      const int R = PH ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1)) : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
+      rdA[mt][tap] = A_OFF + R * 64 + ((lq ^ ((R >> 1) & 3)) << 4);
+      if constexpr (DUAL) {
+        if ((tap & 1) == 0) rdA2[mt][tap >> 1] = A_OFF + (R + 1) * 64 + ((lq ^ (((R + 1) >> 1) & 3)) << 4);
+      }
+    }
+  }
+  auto rd_px1 = [&](int mt, auto TAP) -> int {      // address of px 1's pixel fragment (DUAL)
+    constexpr int tap = decltype(TAP)::value;
+    if constexpr ((tap & 1) != 0) return rdA[mt][tap & ~1];
+    else return rdA2[mt][tap >> 1];
+  };
+  const int rdB = B_OFF + lr * 64 + ((lq ^ ((lr >> 1) & 3)) << 4);   // + column tile * 1024 + stage * B_BYTES
+
+  f4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = p.cin / BK;
+  const int ngroups = nchunk * NQ, nsteps = ngroups * NTAP;
+  const int relu_cend = p.relu_in ? p.relu_cend : 0;
+
+  // RELU kernels: the decoder's ReLU on a pixel fragment right before its first use. rmin = 0 for the skip half of a concat
+  // buffer, 0x8000 (the smallest 16-bit integer: no change) for the rest - no branch either way
+  auto relu_a = [&](h8_t& v, int rmin) {
+    if constexpr (RELU) {
+      typedef short s8_t __attribute__((ext_vector_type(8)));
+      const short m = (short)rmin;
+      const s8_t lo = {m, m, m, m, m, m, m, m};
+      v = __builtin_bit_cast(h8_t, __builtin_elementwise_max(__builtin_bit_cast(s8_t, v), lo));
+    }
+  };
+  auto rmin_of = [&](int chunk) -> int { return chunk * BK < relu_cend ? 0 : -32768; };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+
+  auto issue_b = [&](unsigned (&vb)[BJ], int chunk, auto Q, auto TAP, auto J) {
+    constexpr int q = decltype(Q)::value, tap = decltype(TAP)::value, j = decltype(J)::value;
+    int koff;
+    if constexpr (MODE != 0) {
+      koff = tap * p.cin + chunk * BK;
+    } else {
+      constexpr int ky = (q >> 1) ? 2 * (tap >> 1) : 2 * (tap >> 1) + 1, kx = (q & 1) ? 2 * (tap & 1) : 2 * (tap & 1) + 1;
+      koff = (ky * 4 + kx) * p.cin + chunk * BK;
+    }
+    blds16(rsB, vb[j], koff * 2, smem + B_OFF + tap * B_BYTES + (wave * BJ + j) * 1024);
+  };
+
+  // ---- prologue: halo of group 0, weight slices of steps 0, 1, 2 (nsteps >= 4) ------------------------------------------------
+  static_for<AJ>([&](auto J) { blds16(rsA, voffA[0][decltype(J)::value], 0, smem + A_OFF + (wave * AJ + decltype(J)::value) * 1024); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I0{}, J); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I1{}, J); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I2{}, J); });
+  // fragment registers: two pixel-fragment sets and the eight column fragments
+  //   not DUAL: fa[tap & 1] = this step's pixels (both halves), fa[(tap & 1) ^ 1] receives the next step's during H1
+  //   DUAL:     fa[0] = px 0 rows (H0; refilled with the next step's during H1), fa[1] = px 1 rows (read during H0, used in H1)
+  h8_t fa[2][MT], fb[NT];
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the slice of step 2 (BJ = 2 pieces)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MT; ++i) fa[0][i] = *(const h8_t*)(smem + rdA[i][0]);
+#pragma unroll
+  for (int i = 0; i < NH; ++i) fb[i] = *(const h8_t*)(smem + rdB + i * 1024);
+
+  // One halo group = four steps of straight-line code (igemm6's structure): every step issues the same number of LDS-DMA pieces
+  // (beyond the end of the K loop with out-of-range offsets), so the counted waits are immediates. GI = group index modulo 2
+  // (modes 1, 3) or 4 (mode 0): halo buffer GI & 1, parity class GI (mode 0).
+  auto group = [&](int c, auto GIc) {
+    constexpr int GI = decltype(GIc)::value;
+    constexpr int BUF = GI & 1, Q = MODE == 0 ? GI : 0, QN = MODE == 0 ? ((GI + 1) & 3) : 0;
+    using QT = std::integral_constant<int, Q>;
+    using QNT = std::integral_constant<int, QN>;
+    const int chunk = c / NQ, chunk_n = (c + 1) / NQ;            // channel chunk of this group / of the next one
+    const int rmin = rmin_of(chunk);
+    const bool next_a = c + 1 < ngroups;
+    unsigned va[AJ];                                            // the next group's halo pieces (none after the last group)
+#pragma unroll
+    for (int j = 0; j < AJ; ++j) va[j] = next_a ? voffA[QN][j] : OOB;
+    static_for<NTAP>([&](auto TAPc) {
+      constexpr int tap = decltype(TAPc)::value;
+      const int s = c * NTAP + tap;
+      // in flight may stay: the pieces issued during step s-1 = a weight slice (BJ) + its halo pieces (3 in tap 0, 2 in tap 1)
+      constexpr int ptap = (tap + 3) & 3;
+      constexpr int nwait = BJ + (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0));
+      if constexpr (nwait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if constexpr (nwait == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // weight slice of step s + 3 = (group c, tap 3) during tap 0, else (group c + 1, tap - 1); out of range past the end
+      unsigned vb[BJ];
+#pragma unroll
+      for (int j = 0; j < BJ; ++j) vb[j] = s + 3 < nsteps ? voffB[j] : OOB;
+      auto issue_piece = [&](auto IDX) {
+        constexpr int idx = decltype(IDX)::value;      // MFMA counter of this step, 0 .. 31
+        constexpr int NM = MT * NT;
+        if constexpr (tap == 0) {      // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
+          if constexpr (idx == NM / 4) blds16(rsA, va[0], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 0) * 1024);
+          if constexpr (idx == NM / 4 + 2) blds16(rsA, va[1], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 1) * 1024);
+          if constexpr (idx == NM / 4 + 4) blds16(rsA, va[2], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 2) * 1024);
+        } else if constexpr (tap == 1) {
+          if constexpr (idx == NM / 4) blds16(rsA, va[3], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 3) * 1024);
+          if constexpr (idx == NM / 4 + 3) blds16(rsA, va[4], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 4) * 1024);
+        }
+        static_for<BJ>([&](auto Jc) {
+          constexpr int j = decltype(Jc)::value;
+          if constexpr (idx == NM - 2 - (BJ - 1 - j) * 2) {
+            if constexpr (tap == 0) issue_b(vb, chunk, QT{}, I3{}, Jc);
+            else issue_b(vb, chunk_n, QNT{}, std::integral_constant<int, tap - 1>{}, Jc);
+          }
+        });
+      };
+      constexpr int CUR = DUAL ? 0 : (tap & 1);        // pixel fragments of H0 (not DUAL: of the whole step)
+      constexpr int OTH = DUAL ? 1 : (CUR ^ 1);        // DUAL: px 1 rows of this step; else: the next step's set
+      // ---- H0: column tiles 0..3. One fragment read behind every second MFMA:
+      //   not DUAL: b[4..7] of this step;  DUAL: a1[0], b[4..7], a1[1..3] of this step
+      static_for<MT * NH>([&](auto IDX) {
+        constexpr int idx = decltype(IDX)::value, mt = idx / NH, nt = idx % NH;
+        if constexpr (nt == 0) relu_a(fa[CUR][mt], rmin);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[CUR][mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+        if constexpr ((idx & 1) == 0) {
+          constexpr int k = idx / 2;                   // read slot 0 .. 7
+          if constexpr (!DUAL) {
+            if constexpr (k < NH) fb[NH + k] = *(const h8_t*)(smem + rdB + tap * B_BYTES + (NH + k) * 1024);
+          } else {
+            if constexpr (k == 0) fa[1][0] = *(const h8_t*)(smem + rd_px1(0, TAPc) + BUF * A_BYTES);
+            else if constexpr (k <= NH) fb[NH + k - 1] = *(const h8_t*)(smem + rdB + tap * B_BYTES + (NH + k - 1) * 1024);
+            else fa[1][k - NH] = *(const h8_t*)(smem + rd_px1(k - NH, TAPc) + BUF * A_BYTES);
+          }
+        }
+        issue_piece(IDX);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // ---- H1: column tiles 4..7; behind every second MFMA one fragment of the NEXT step (a[0], b[0..3], a[1..3]); that
+      //      step's data landed one step early (after the last step: stale bytes, never used)
+      static_for<MT * NH>([&](auto IDX) {
+        constexpr int idx = decltype(IDX)::value, mt = idx / NH, nt = NH + idx % NH;
+        constexpr int HS = DUAL ? 1 : CUR;             // pixel fragments of H1
+        if constexpr (DUAL && nt == NH) relu_a(fa[1][mt], rmin);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[HS][mt], acc[mt][nt], 0, 0, 0);
+        if constexpr ((idx & 1) == 0) {
+          constexpr int k = idx / 2;
+          constexpr int NXT = DUAL ? 0 : OTH;          // DUAL: fa[0] is free after H0
+          constexpr int ntap = (tap + 1) & 3;
+          constexpr int nbuf = tap < 3 ? BUF : (BUF ^ 1);
+          // (not DUAL: fa[CUR] stays live through H1, the next step's pixels go to the other set;
+          //  b[0..3] are free after H0)
+          if constexpr (k == 0) fa[NXT][0] = *(const h8_t*)(smem + rdA[0][ntap] + nbuf * A_BYTES);
+          else if constexpr (k <= NH) fb[k - 1] = *(const h8_t*)(smem + rdB + ntap * B_BYTES + (k - 1) * 1024);
+          else fa[NXT][k - NH] = *(const h8_t*)(smem + rdA[k - NH][ntap] + nbuf * A_BYTES);
+        }
+        issue_piece(std::integral_constant<int, idx + MT * NH>{});
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+
+  if constexpr (MODE == 0) {
+    for (int c = 0; c < ngroups; c += 4) { group(c, I0{}); group(c + 1, I1{}); group(c + 2, I2{}); group(c + 3, I3{}); }
+  } else {
+    int c = 0;
+    for (; c + 1 < ngroups; c += 2) { group(c, I0{}); group(c + 1, I1{}); }
+    if (c < ngroups) group(c, I0{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  asm volatile("" ::: "memory");
+  epilogue8<MODE>(p, acc, smem, tid, lane, wave, mt_idx, ph, py, px, n0, img, y0, x0, lgTW);
+}
+
+}  // namespace
+
+// Launched by op_igemm5 (igemm5.hip) with the kernel arguments it has prepared; grid as igemm6's.
+int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp) {
+  constexpr int LDS = 2 * 20480 + 4 * 8192;   // = the epilogue's 256 x 136 halves + 4 x 128 x 2 floats
+  static bool attr[6] = {false, false, false, false, false, false};
+  const int v = (dual ? 2 : mode) * 2 + (relu ? 1 : 0);
+#define GI_K8(MODE_, RELU_, NAME_) do { \
+    if (!attr[v]) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<MODE_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr[v] = true; } \
+    hipLaunchKernelGGL((igemm8_kernel<MODE_, RELU_>), dim3(grid), dim3(256), LDS, st, kp); gi_note_kernel(NAME_); } while (0)
+  switch (v) {
+    case 0: GI_K8(0, false, "igemm8<0>"); break;
+    case 1: GI_K8(0, true, "igemm8<0,relu>"); break;
+    case 2: GI_K8(1, false, "igemm8<1>"); break;
+    case 3: GI_K8(1, true, "igemm8<1,relu>"); break;
+    case 4: GI_K8(3, false, "igemm8<3>"); break;
+    default: GI_K8(3, true, "igemm8<3,relu>"); break;
+  }
+#undef GI_K8
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}

@@ -53,6 +53,8 @@ int gi_version(void);
  * variable of the same name if set (read once), else the number in brackets. Nothing here exists in the reference.
  *   GI_IGEMM5 [7]         bit 0 / 1 / 2: halo-resident implicit GEMM for sub-pixel phases / 4x4-s2 gather / 3x3-s1 (else igemm3)
  *   GI_IGEMM6 [1]         0: first-generation halo kernels (igemm5) instead of the buffer-descriptor LDS-DMA ones
+ *   GI_IGEMM8 [1]         0: never the four-wave / two-workgroups-per-CU halo kernel (igemm8); 1: on layers with >= 512
+ *                         workgroups; 2: on every eligible layer
  *   GI_IGEMM7 [1]         0: small-M layers on the generic kernel (igemm.hip) instead of the four-stage ring kernel
  *   GI_IGEMM_FIXUP [1]    0: split-K partial sums added by a finish launch instead of the last arriver inside the GEMM
  *   GI_IGEMM_VARIANT [3]  1: fp16 layers on the register-staged generic kernel only

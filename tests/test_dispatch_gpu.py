@@ -17,6 +17,23 @@ F16 = B.GI_F16
 TOL = 2e-3   # relative to max|ref|: fp16 output rounding, fp32 accumulate
 
 
+@pytest.fixture(params=["default", "igemm6", "igemm8"])
+def family(request):
+    """The halo-resident layers run three times: with the default choice (GI_IGEMM8 = 1: igemm8.hip - the same tile on four
+    waves, two workgroups per CU - where the grid has >= 512 workgroups, igemm6 otherwise), with igemm6 everywhere and with
+    igemm8 everywhere. expect(name, workgroups) maps igemm6's name to the kernel that must have served the layer."""
+    mode = request.param
+    if mode != "default":
+        B.set_option("GI_IGEMM8", 0 if mode == "igemm6" else 2)
+
+    def expect(name, workgroups):
+        if mode == "igemm6" or not name.startswith("igemm6<") or ",64" in name or (mode == "default" and workgroups < 512):
+            return name
+        return f"igemm8<{name[7]}{',relu' if name.endswith('relu>') else ''}>"
+    yield expect
+    B.set_option("GI_IGEMM8", -1)
+
+
 def _rand(shape, seed, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.rand(shape, generator=g) * 2 - 1) * scale
@@ -80,8 +97,9 @@ CONV_FWD = [
 
 
 @pytest.mark.parametrize("case", CONV_FWD, ids=[c[0] for c in CONV_FWD])
-def test_conv_forward_with_statistics_at_headline_shapes(case):
+def test_conv_forward_with_statistics_at_headline_shapes(case, family):
     name, n, HW, cb, ca, groups, kernel = case
+    kernel = family(kernel, n * (HW // 2) ** 2 // 256 * (ca // 128))
     ex = B.IgemmEx()
     acc = _acc(ca)
     M = n * (HW // 2) ** 2
@@ -114,8 +132,9 @@ CONVT_FWD = [
 
 
 @pytest.mark.parametrize("case", CONVT_FWD, ids=[c[0] for c in CONVT_FWD])
-def test_convT_forward_with_statistics_at_headline_shapes(case):
+def test_convT_forward_with_statistics_at_headline_shapes(case, family):
     name, n, HW, ca, cb, cend, kernel = case
+    kernel = family(kernel, n * HW * HW // 256 * (4 * cb // 128))
     ex = B.IgemmEx()
     acc = _acc(cb)
     ex.stat_acc = B.ptr(acc)
@@ -137,7 +156,7 @@ def test_convT_forward_with_statistics_at_headline_shapes(case):
         assert err <= 1e-5, f"{name}: column statistics off by {err:.2e} of sum|x|"
 
 
-def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1():
+def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1(family):
     """d2's input gradient at n = 32 (sub-pixel phases with 64 output channels: the dual-px kernel) with d1's activation
     backward in the epilogue: out = (g + [y > 0] * skip gradient) * (y > 0 ? 1 : 0.2), y = the saved LeakyReLU output of d1
     (networks.py:287: the skip IS lrelu(x)), both read from 128-channel concat buffers."""
@@ -154,7 +173,7 @@ def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1():
     ex.mask = B.ptr(ybuf); ex.ldmask = 2 * cb; ex.mask_slope = 0.2   # noqa: E702
     ex.add = B.ptr(gbuf); ex.ldadd = 2 * cb                           # noqa: E702
     out, g = _convT(n, Hs, Hs, ca, cb, ex, x=D, w=w)
-    assert B.last_kernel() == "igemm6<3,128>" and ex.mask_applied == 1, (B.last_kernel(), ex.mask_applied)
+    assert B.last_kernel() == family("igemm6<3,128>", 1024) and ex.mask_applied == 1, (B.last_kernel(), ex.mask_applied)
     pos = (y > 0).float()
     ref = (g + pos * skip) * (pos + (1 - pos) * 0.2)
     ok, msg = report("d2 dgrad + fused LeakyReLU backward", from_nhwc(out), ref, TOL)
@@ -162,7 +181,7 @@ def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1():
 
 
 @pytest.mark.parametrize("layer", ["conv3", "conv2"])
-def test_critic_dgrad_with_fused_batchnorm_backward_reduction(layer):
+def test_critic_dgrad_with_fused_batchnorm_backward_reduction(layer, family):
     """The stacked critic (n = 64, two BatchNorm populations): the input-gradient GEMM of conv4 / conv3 produces the gradient
     g w.r.t. LeakyReLU(BatchNorm(x)) of conv3 / conv2 and adds sum dz, sum dz * xhat per channel and population to the exact
     accumulators, dz = g * (fma(x, scale, shift) > 0 ? 1 : 0.2), xhat = (x - mean) * inv (networks.py:338-344)."""
@@ -187,7 +206,7 @@ def test_critic_dgrad_with_fused_batchnorm_backward_reduction(layer):
     ex.bwd_reps = 4 if tiles * 4 > 1024 else (2 if tiles * 4 > 256 else 1)
     ex.bwd_pg = n // 2 * 4 * Hs * Hs
     out, g = _convT(n, Hs, Hs, ca, cb, ex, x=D, w=w)
-    assert B.last_kernel() == "igemm6<1,128>" and ex.bwd_applied == 1, (B.last_kernel(), ex.bwd_applied)
+    assert B.last_kernel() == family("igemm6<1,128>", n * Hs * Hs // 256 * (4 * cb // 128)) and ex.bwd_applied == 1, (B.last_kernel(), ex.bwd_applied)
     ok, msg = report(f"critic {layer} output gradient", from_nhwc(out), g, TOL)
     assert ok, msg
     gk = from_nhwc(out).double()                                   # the kernel reduces the fp16 gradient it stores

@@ -81,6 +81,12 @@ LAYER_OPTIONS = [
     ("GI_IGEMM7", 0, "convT", (32, 4, 1024, 512), "igemm<f16,fixup>", "igemm7<1,128>"),
     ("GI_IGEMM_VARIANT", 1, "conv", (16, 128, 64, 128), "igemm<f16>", "igemm6<0,128>"),
     ("GI_IGEMM_VARIANT", 1, "convT", (4, 8, 512, 256), "igemm<f16,fixup>", "igemm7<1,64>"),
+    ("GI_IGEMM8", 2, "conv", (16, 128, 64, 128), "igemm8<0>", "igemm6<0,128>"),       # 256 workgroups: igemm6 by default
+    ("GI_IGEMM8", 2, "convT", (8, 32, 256, 128), "igemm8<1>", "igemm6<1,128>"),      # 128 workgroups
+    ("GI_IGEMM8", 2, "convT", (8, 32, 128, 64), "igemm8<3>", "igemm6<3,128>"),       # 128 workgroups (dual px)
+    ("GI_IGEMM8", 0, "conv", (32, 128, 64, 128), "igemm6<0,128>", "igemm8<0>"),       # 512 workgroups: igemm8 by default
+    ("GI_IGEMM8", 0, "convT", (32, 32, 256, 128), "igemm6<1,128>", "igemm8<1>"),
+    ("GI_IGEMM8", 0, "convT", (32, 64, 128, 64), "igemm6<3,128>", "igemm8<3>"),
     ("GI_WGRAD3", 0, "wgrad", (16, 32, 256, 128), "wgrad2<2>", "wgrad3<4>"),
     ("GI_WGRAD2", 0, "wgrad", (16, 32, 256, 128), "wgrad<f16>", "wgrad3<4>"),
 ]
@@ -150,7 +156,7 @@ def _patchgan_run(dtype, seed=66, N=8, HW=128, groups=2):
 
 
 NET_OPTIONS = [("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
-               ("GI_IGEMM6", 0), ("GI_WGRAD3", 0), ("GI_WGRAD2", 0)]
+               ("GI_IGEMM6", 0), ("GI_WGRAD3", 0), ("GI_WGRAD2", 0), ("GI_IGEMM8", 2), ("GI_IGEMM8", 0)]
 
 
 @pytest.mark.parametrize("net_kind", ["unet", "patchgan"])
