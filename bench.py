@@ -141,72 +141,136 @@ def whole_job_rate(world, per_rank_batch, steps, dt):
     return world * per_rank_batch * steps / dt
 
 
-def dominant_kernel(iters):
-    """u3 of the generator at 256x256 / bs=32: ConvTranspose2d(512 -> 128) on 32x32 maps, i.e. four
-    sub-pixel GEMMs of M=32768, N=128, K=2048 (SURVEY.md 8a2 'u3')."""
+PEAK_F32_TFLOPS = 157.3    # MI355X f32-input MFMA (guides/MI355X_MICROARCH.md)
+
+
+def dominant_kernel(iters, dtype="fp16", n=None, hs=32):
+    """u3 of the generator: ConvTranspose2d(512 -> 128) with the fused input ReLU, i.e. four sub-pixel GEMMs of
+    M = n * hs * hs, N = 128, K = 2048. Headline: 256x256 / bs=32 -> hs = 32. Timed with HIP events on the kernel's stream
+    inside the library (gi_time_convT_s2)."""
     from gan_inpainting_amd import backend as B
     import ctypes as C
-    n, hs, ws, ca, cb = BS, 32, 32, 512, 128
-    x = (torch.rand((n, hs, ws, ca), device="cuda") - 0.3).half()
+    code = B.dtype_code(dtype)
+    n = BS if n is None else n
+    ws, ca, cb = hs, 512, 128
+    x = (torch.rand((n, hs, ws, ca), device="cuda") - 0.3).to(B.torch_dtype(code))
     w = ((torch.rand((ca, 4, 4, cb), device="cuda") * 2 - 1) * 0.02)
-    phase = torch.empty(ca * 16 * cb, dtype=torch.float16, device="cuda")
-    B.check(B.lib().gi_pack_weights(B.get_ctx(), B.GI_F16, B.ptr(w), ca, cb, None, B.ptr(phase)))
-    out = torch.empty((n, 2 * hs, 2 * ws, cb), dtype=torch.float16, device="cuda")
+    phase = torch.empty(ca * 16 * cb, dtype=B.torch_dtype(code), device="cuda")
+    B.check(B.lib().gi_pack_weights(B.get_ctx(), code, B.ptr(w), ca, cb, None, B.ptr(phase)))
+    out = torch.empty((n, 2 * hs, 2 * ws, cb), dtype=B.torch_dtype(code), device="cuda")
     ms = C.c_float()
-    B.check(B.lib().gi_time_convT_s2(B.get_ctx(), B.GI_F16, B.ptr(x), B.ptr(phase), B.ptr(out), n, hs, ws, ca, ca, cb, cb, iters,
+    B.check(B.lib().gi_time_convT_s2(B.get_ctx(), code, B.ptr(x), B.ptr(phase), B.ptr(out), n, hs, ws, ca, ca, cb, cb, iters,
                                      C.byref(ms)))
     flop = 2.0 * 4 * (n * hs * ws) * cb * (4 * ca)
-    return dict(name="igemm6_kernel<1, 128, true> fp16 halo-resident LDS-DMA implicit GEMM (ConvTranspose2d 512->128 with the fused input ReLU, "
-                     "32x32->64x64, bs=32; generator u3)", ms=ms.value, flop=flop)
+    nbytes = (x.numel() + phase.numel() + out.numel()) * x.element_size()
+    return dict(name=f"{B.last_kernel()} ({dtype} implicit GEMM, ConvTranspose2d 512->128 with the fused input ReLU, {hs}x{hs}->{2 * hs}x{2 * hs}, "
+                     f"n={n}; generator u3)", ms=ms.value, flop=flop, bytes=nbytes)
 
 
-def cpu_baseline():
-    """The oracle's WGAN schedule (oracle/torch_ref.wgan_step, fp32) on the host cores at the GPU workload's own batch,
-    bs=32 at 256x256: critic-only batches and one batch with a generator update, combined 4:1 like the GPU cadence. A bs=32
-    batch takes several seconds on the box's host cores, so the sample is 1 warm-up + 2 critic-only + 1 generator-update
-    batch (stated in `sample`), repeated at 8 threads, 32 and all host threads."""
+def critic_conv2_kernel(iters):
+    """The layer family with the most kernel time in the headline benchmark (profiles/r02_summary.md B: igemm6<0,128>, now
+    igemm8<0>): the critic's conv2 on the stacked batch, Conv2d(64 -> 128) 128x128 -> 64x64 at n = 64, a 16-tap x 64-channel
+    K loop (M = 262144, N = 128, K = 1024)."""
+    from gan_inpainting_amd import backend as B
+    import ctypes as C
+    n, hw, cb, ca = 2 * BS, H // 2, 64, 128
+    x = (torch.rand((n, hw, hw, cb), device="cuda") - 0.3).half()
+    w = ((torch.rand((ca, 4, 4, cb), device="cuda") * 2 - 1) * 0.02)
+    packed = torch.empty(ca * 16 * cb, dtype=torch.float16, device="cuda")
+    B.check(B.lib().gi_pack_weights(B.get_ctx(), B.GI_F16, B.ptr(w), ca, cb, B.ptr(packed), None))
+    out = torch.empty((n, hw // 2, hw // 2, ca), dtype=torch.float16, device="cuda")
+    ms = C.c_float()
+    B.check(B.lib().gi_time_conv_s2(B.get_ctx(), B.GI_F16, B.ptr(x), B.ptr(packed), B.ptr(out), n, hw, hw, cb, cb, ca, ca, iters, C.byref(ms)))
+    flop = 2.0 * n * (hw // 2) ** 2 * ca * 16 * cb
+    return dict(name=f"{B.last_kernel()} (fp16 implicit GEMM, Conv2d 64->128 {hw}x{hw}->{hw // 2}x{hw // 2}, n={n}; critic conv2 on the stacked batch)",
+                ms=ms.value, flop=flop, bytes=(x.numel() + packed.numel() + out.numel()) * 2)
+
+
+def roofline_of(k, dtype="fp16", traffic=None, traffic_src=None):
+    peak = PEAK_F16_TFLOPS if dtype == "fp16" else PEAK_F32_TFLOPS
+    achieved = k["flop"] / (k["ms"] * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": k["name"], "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "avg_launch_ms": k["ms"], "flop_per_launch": k["flop"], "algorithmic_bytes_per_launch": k["bytes"], "traffic": traffic,
+            "traffic_source": traffic_src}
+
+
+def cpu_baseline(workload="wgan_rmse_256", full=True):
+    """The oracle's schedule of the workload (oracle/torch_ref.py, fp32: the port of the reference's torch-CPU path) on the host
+    cores at the GPU workload's own batch. Protocol: a SHORT thread sweep first (1 warm-up + 1 critic-only + 1
+    generator-update batch at 8 / 32 / all host threads: torch-CPU throughput peaks well below the box's core count), then at
+    the best thread count >= 3 warm-up + >= 10 timed critic-only batches and >= 3 timed generator-update batches, weighted
+    4 : 1 like the GPU cadence. full=False (secondary workloads): 1 warm-up + 2 + 1 timed batches at the best thread count."""
     import numpy as np
     from oracle import params as op
     from oracle import torch_ref as orc
+    dual = workload == "dual_d_256"
+    gp = workload == "wgan_gp_128"
+    c5 = workload == "config5_512"
+    n, hw = BS, H
 
-    def run(n, warm, n_critic, n_gen):
+    def setup():
         PG = orc.to_torch(op.make_unet_params(1234))
-        PD = orc.to_torch(op.make_patchgan_params(4321, H, W))
-        oG, oD = orc.RMSprop(orc.trainable(PG)), orc.RMSprop(orc.trainable(PD))
-        ground, mask = op.synth_batch(0x5EED, n, H, W)
-        ground, mask = torch.from_numpy(ground), torch.from_numpy(mask)
-        rng = np.random.Generator(np.random.PCG64(1))
-        masks = {5: torch.from_numpy((rng.random((n, 512, 16, 16)) < 0.5).astype(np.uint8)),
-                 6: torch.from_numpy((rng.random((n, 512, 8, 8)) < 0.5).astype(np.uint8))}
+        PD = orc.to_torch(op.make_patchgan_params(4321, hw, hw))
+        ground, mask = op.synth_batch(0x5EED, n, hw, hw)
+        masks = {k: torch.from_numpy(v) for k, v in op.synth_dropout_masks(1, 7, n, hw, hw).items()}
+        st = dict(PG=PG, PD=PD, ground=torch.from_numpy(ground), mask=torch.from_numpy(mask), masks=masks)
+        if dual:
+            st["PD2"] = orc.to_torch(op.make_patchgan_params(9876, hw, hw))
+            st["oG"] = orc.Adam(orc.trainable(PG))
+            st["oD"] = orc.Adam(orc.trainable(PD) + orc.trainable(st["PD2"]))
+        else:
+            st["oG"], st["oD"] = orc.RMSprop(orc.trainable(PG)), orc.RMSprop(orc.trainable(PD))
+        if c5:
+            st["PS"] = orc.to_torch(op.make_unet_params(777, ngf=32, out_c=4), requires_grad=False)
+            st["PV"] = orc.to_torch(op.make_vgg19_params(99), requires_grad=False)
+            st["seg"] = torch.from_numpy(op.synth_segmentation(5, n, 4, hw, hw)[0])
+        return st
+
+    def batch(st, upd):
+        if dual:      # every batch updates the generator and both discriminators
+            return orc.dual_d_step(st["PG"], st["PD"], st["PD2"], st["oG"], st["oD"], st["ground"], st["mask"], 7, st["masks"])
+        extra = orc.config5_extra(st["PV"], st["PS"], st["seg"]) if (c5 and upd) else None
+        out = orc.wgan_step(st["PG"], st["PD"], st["oG"], st["oD"], st["ground"], st["mask"], 7, st["masks"], upd,
+                            recon="l1" if gp else "rmse", extra=extra)
+        if gp:        # + the penalty's forward and double backward (the extension has no step schedule in the oracle: the work of
+            eps = torch.full((n, 1, 1, 1), 0.5)   # its term is timed beside the clipped WGAN batch, its gradients are dropped)
+            orc.set_requires_grad(st["PD"], True)
+            pen = orc.gradient_penalty(st["PD"], st["ground"], out["inpainted"], eps, lam=10.0)
+            torch.autograd.grad(pen, orc.trainable(st["PD"]), allow_unused=True)
+        return out
+
+    def run(warm, n_critic, n_gen):
+        st = setup()
         for _ in range(warm):
-            orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, False, recon="rmse")
+            batch(st, False)
         t = []
         for upd, reps in ((False, n_critic), (True, n_gen)):
             t0 = time.perf_counter()
             for _ in range(reps):
-                orc.wgan_step(PG, PD, oG, oD, ground, mask, 7, masks, upd, recon="rmse")
-            t.append((time.perf_counter() - t0) / reps)
-        return n / (((G_EVERY - 1) * t[0] + t[1]) / G_EVERY), t
+                batch(st, upd)
+            t.append((time.perf_counter() - t0) / max(reps, 1))
+        per_batch = t[1] if dual else ((G_EVERY - 1) * t[0] + t[1]) / G_EVERY
+        return n / per_batch, t
 
-    # the oracle is torch-CPU code: its throughput peaks well below the box's core count (measured on the 128-core GPU host:
-    # 8 threads beat 128 by 4x at this size), so the same sample runs at 8, 32 and all threads and the best is the baseline
     threads = torch.get_num_threads()
     sweep = {}
     try:
         for nt in sorted({min(8, threads), min(32, threads), threads}):
             torch.set_num_threads(nt)
-            v, t = run(BS, 1, 2, 1)
-            sweep[nt] = (v, t)
+            sweep[nt] = run(1, 0 if dual else 1, 1)[0]
+        best = max(sweep, key=lambda k: sweep[k])
+        torch.set_num_threads(best)
+        warm, nc, ng = (3, 10, 3) if full else (1, 2, 1)
+        v, t = run(warm, 0 if dual else nc, ng)
     finally:
         torch.set_num_threads(threads)
-    best = max(sweep, key=lambda k: sweep[k][0])
-    v, t = sweep[best]
-    out = dict(value=v, unit="images/sec", cores=best, kind="port",
-               sample=f"oracle/torch_ref.wgan_step fp32, bs={BS} at {H}x{W}: 1 warm-up + 2 critic-only batches ({t[0]:.2f} s each) "
-                      f"+ 1 batch with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1 (reduced from 10 + 3 batches to keep the default run short); "
-                      f"torch threads swept, best shown",
-               sweep={str(k): round(sweep[k][0], 3) for k in sorted(sweep)})
-    return out
+    what = {"wgan_rmse_256": "wgan_step (RMSE)", "wgan_gp_128": "wgan_step (L1) + gradient_penalty forward / double backward",
+            "dual_d_256": "dual_d_step", "config5_512": "wgan_step + config5_extra"}[workload]
+    return dict(value=v, unit="images/sec", cores=best, kind="port",
+                sample=f"oracle/torch_ref {what} fp32, bs={n} at {hw}x{hw}, {best} torch threads (best of a 1+1+1-batch sweep over "
+                       f"{sorted(sweep)} threads): {warm} warm-up + {0 if dual else nc} critic-only batches ({t[0]:.2f} s each) + {ng} "
+                       f"batch(es) with G update ({t[1]:.2f} s), weighted {G_EVERY - 1}:1" + ("" if full else " (reduced sample: secondary workload)"),
+                sweep={str(k): round(sweep[k], 3) for k in sorted(sweep)})
 
 
 def ssim_workload(args, dev):
@@ -306,7 +370,11 @@ def dual_d_workload(args, dev):
         L = one(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"metric": "training images/sec at 256x256 bs=32/GPU (experiment1_global_local_D)", "value": BS * args.steps / dt,
+    k = dominant_kernel(args.kernel_iters, "fp16", BS, 32)
+    extra = {"roofline": roofline_of(k, "fp16")}
+    if not args.no_cpu_baseline:
+        extra["cpu_baseline"] = cpu_baseline("dual_d_256", full=False)
+    return {**extra, "metric": "training images/sec at 256x256 bs=32/GPU (experiment1_global_local_D)", "value": BS * args.steps / dt,
             "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if args.dtype == "fp16" else "f32",
             "data": "synthetic",
@@ -432,21 +500,29 @@ def main():
 
     if rank != 0:
         return
-    if c5:   # secondary workload: plain line
-        print(json.dumps({"metric": "training images/sec at 512x512 bs=8/GPU (wgan_perceptual_style_faceparsing)",
-                          "value": alive * BS * args.steps / dt, "unit": "images/sec", "n_gpus": alive, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-                          "config": {"workload": "wgan_perceptual_style_faceparsing 512x512 bs=8/GPU fp16 (BASELINE.json configs[4]): WGAN + "
-                                                 "global/local RMSE + frozen face-parsing U-Net (ngf=32, random init) + VGG-19 perceptual/style "
-                                                 "(random init) + TV; G update every 5th batch"}, "losses": losses}))
+    if c5:   # secondary workload: its dominant kernel is the same transposed convolution at 512x512 / bs=8 (u3: 64x64 maps)
+        line = {"metric": "training images/sec at 512x512 bs=8/GPU (wgan_perceptual_style_faceparsing)",
+                "value": alive * BS * args.steps / dt, "unit": "images/sec", "n_gpus": alive, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+                "config": {"workload": "wgan_perceptual_style_faceparsing 512x512 bs=8/GPU fp16 (BASELINE.json configs[4]): WGAN + "
+                                       "global/local RMSE + frozen face-parsing U-Net (ngf=32, random init) + VGG-19 perceptual/style "
+                                       "(random init) + TV; G update every 5th batch"}, "losses": losses,
+                "roofline": roofline_of(dominant_kernel(args.kernel_iters, "fp16", BS, 64), "fp16")}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline("config5_512", full=False)
+        print(json.dumps(line))
         return
-    if gp:   # secondary workload: plain line, no roofline / cpu legs
-        print(json.dumps({"metric": "training images/sec at 128x128 bs=16/GPU (wgan_l1 + gradient penalty, fp32)",
-                          "value": alive * BS * args.steps / dt, "unit": "images/sec", "n_gpus": alive, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "wgan_l1 128x128 bs=16 fp32 + WGAN-GP (BASELINE.json configs[1])"}, "losses": losses}))
+    if gp:   # secondary workload, fp32: the f32-input MFMA path (peak 157.3 TFLOP/s); u3 at 128x128 / bs=16 is 16x16 -> 32x32
+        line = {"metric": "training images/sec at 128x128 bs=16/GPU (wgan_l1 + gradient penalty, fp32)",
+                "value": alive * BS * args.steps / dt, "unit": "images/sec", "n_gpus": alive, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "wgan_l1 128x128 bs=16 fp32 + WGAN-GP (BASELINE.json configs[1])"}, "losses": losses,
+                "roofline": roofline_of(dominant_kernel(args.kernel_iters, "fp32", BS, 16), "fp32")}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline("wgan_gp_128", full=False)
+        print(json.dumps(line))
         return
     # generator forward latency (train-mode forward as inside the loop), HIP events on the compute stream
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -483,7 +559,6 @@ def main():
     G.train()
 
     k = dominant_kernel(args.kernel_iters)
-    achieved = k["flop"] / (k["ms"] * 1e-3) / 1e12
     traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "dominant_kernel_traffic.json")
     if os.path.exists(tp):
@@ -519,10 +594,10 @@ def main():
         "generator_fwd_mfma_frac": BS * F_G / (gen_fwd_ms * 1e-3) / (PEAK_F16_TFLOPS * 1e12),
         "step_algorithmic_tflops": flop_batch / (dt / args.steps) / 1e12,
         "losses": losses,
-        "roofline": {"bound": "mfma", "kernel": k["name"], "achieved": achieved, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F16_TFLOPS, "avg_launch_ms": k["ms"], "flop_per_launch": k["flop"], "traffic": traffic,
-                     "traffic_source": traffic_src},
+        "roofline": roofline_of(k, "fp16" if args.dtype == "fp16" else "fp32", traffic, traffic_src),
     }
+    if args.dtype == "fp16":   # the short-K layer family with the most kernel time of the benchmark, beside the dominant kernel
+        out["roofline_short_k"] = roofline_of(critic_conv2_kernel(args.kernel_iters), "fp16")
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

@@ -112,6 +112,7 @@ PROTOTYPES = {
     "gi_convert": (_i, [_vp, _i, _vp, _vp, _i64]),
     "gi_convert_back": (_i, [_vp, _i, _vp, _vp, _i64]),
     "gi_time_convT_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f)]),
+    "gi_time_conv_s2": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, C.POINTER(_f)]),
 }
 
 _lib = None

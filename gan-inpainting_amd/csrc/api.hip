@@ -255,4 +255,25 @@ int gi_time_convT_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_phase
   return GI_OK;
 }
 
+/* the same for the strided convolution (gi_conv_s2_forward): the critic's conv2 / the generator's d2 family */
+int gi_time_conv_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out, int n, int H, int W, int cb, int ldin, int ca,
+                    int ldout, int iters, float* ms_out_host) {
+  GI_REQUIRE(ctx && ms_out_host && iters > 0, "time_conv_s2: bad argument");
+  hipEvent_t e0, e1;
+  GI_HIP(hipEventCreate(&e0));
+  GI_HIP(hipEventCreate(&e1));
+  GI_TRY(gi_conv_s2_forward(ctx, dtype, in, w_packed, out, n, H, W, cb, ldin, ca, ldout, 0, GI_ACT_NONE, nullptr, 0));
+  GI_HIP(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < iters; ++i)
+    GI_TRY(gi_conv_s2_forward(ctx, dtype, in, w_packed, out, n, H, W, cb, ldin, ca, ldout, 0, GI_ACT_NONE, nullptr, 0));
+  GI_HIP(hipEventRecord(e1, ctx->stream));
+  GI_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  GI_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out_host = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return GI_OK;
+}
+
 }  // extern "C"

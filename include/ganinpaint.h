@@ -388,6 +388,8 @@ int gi_convert_back(gi_ctx* ctx, int dtype, const void* src, float* dst, int64_t
  * milliseconds per launch in *ms_out (used by bench.py for the roofline object) */
 int gi_time_convT_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_phase, void* out, int n, int H,
                      int W, int ca, int ldin, int cb, int ldout, int iters, float* ms_out_host);
+int gi_time_conv_s2(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out, int n, int H, int W,
+                    int cb, int ldin, int ca, int ldout, int iters, float* ms_out_host);   /* the same for gi_conv_s2_forward */
 
 #ifdef __cplusplus
 }
