@@ -26,6 +26,8 @@
 // MODE 3 (64 output channels per N tile): columns 0..63 = px 0, 64..127 = px 1 of the same 64 channels, as in igemm6.
 // K order per accumulator: 32-channel chunks ascending, taps 0..3 inside a chunk (igemm6: 64-channel chunks, per tap both
 // 32-channel halves) - the two kernels agree to fp32 rounding, not bit for bit.
+#include <stdlib.h>
+
 #include "common.h"
 #include "stat_acc.h"
 #include "halo_args.h"
@@ -204,7 +206,9 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][8], char*
   }
 }
 
-template <int MODE, bool RELU>
+// DBG (builds with -DGI_ABLATION only, WRONG results, timing experiments): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no fragment
+// reads, 8 no ReLU on the fragments, 16 no per-step barrier, 32 no epilogue
+template <int MODE, bool RELU, int DBG = 0>
 __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   static_assert(MODE == 0 || MODE == 1 || MODE == 3, "4-tap modes");
   constexpr bool DUAL = MODE == 3;
@@ -318,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   // RELU kernels: the decoder's ReLU on a pixel fragment right before its first use. rmin = 0 for the skip half of a concat
   // buffer, 0x8000 (the smallest 16-bit integer: no change) for the rest - no branch either way
   auto relu_a = [&](h8_t& v, int rmin) {
-    if constexpr (RELU) {
+    if constexpr (RELU && (DBG & 8) == 0) {
       typedef short s8_t __attribute__((ext_vector_type(8)));
       const short m = (short)rmin;
       const s8_t lo = {m, m, m, m, m, m, m, m};
@@ -326,6 +330,10 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
     }
   };
   auto rmin_of = [&](int chunk) -> int { return chunk * BK < relu_cend ? 0 : -32768; };
+  auto ldsr = [&](int off) -> h8_t {          // one fragment read
+    if constexpr ((DBG & 4) != 0) { h8_t v = {1, 1, 1, 1, 1, 1, 1, 1}; asm volatile("" : "+v"(v)); return v; }
+    else return *(const h8_t*)(smem + off);
+  };
 
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
@@ -384,7 +392,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
       if constexpr (nwait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if constexpr (nwait == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // weight slice of step s + 3 = (group c, tap 3) during tap 0, else (group c + 1, tap - 1); out of range past the end
       unsigned vb[BJ];
@@ -393,6 +401,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
       auto issue_piece = [&](auto IDX) {
         constexpr int idx = decltype(IDX)::value;      // MFMA counter of this step, 0 .. 31
         constexpr int NM = MT * NT;
+        if constexpr ((DBG & 1) != 0) return;
         if constexpr (tap == 0) {      // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
           if constexpr (idx == NM / 4) blds16(rsA, va[0], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 0) * 1024);
           if constexpr (idx == NM / 4 + 2) blds16(rsA, va[1], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 1) * 1024);
@@ -416,15 +425,16 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
       static_for<MT * NH>([&](auto IDX) {
         constexpr int idx = decltype(IDX)::value, mt = idx / NH, nt = idx % NH;
         if constexpr (nt == 0) relu_a(fa[CUR][mt], rmin);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[CUR][mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+        if constexpr ((DBG & 2) != 0) { asm volatile("" :: "v"(fa[CUR][mt])); asm volatile("" :: "v"(fb[nt])); }
+        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[CUR][mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
         if constexpr ((idx & 1) == 0) {
           constexpr int k = idx / 2;                   // read slot 0 .. 7
           if constexpr (!DUAL) {
-            if constexpr (k < NH) fb[NH + k] = *(const h8_t*)(smem + rdB + tap * B_BYTES + (NH + k) * 1024);
+            if constexpr (k < NH) fb[NH + k] = ldsr(rdB + tap * B_BYTES + (NH + k) * 1024);
           } else {
-            if constexpr (k == 0) fa[1][0] = *(const h8_t*)(smem + rd_px1(0, TAPc) + BUF * A_BYTES);
-            else if constexpr (k <= NH) fb[NH + k - 1] = *(const h8_t*)(smem + rdB + tap * B_BYTES + (NH + k - 1) * 1024);
-            else fa[1][k - NH] = *(const h8_t*)(smem + rd_px1(k - NH, TAPc) + BUF * A_BYTES);
+            if constexpr (k == 0) fa[1][0] = ldsr(rd_px1(0, TAPc) + BUF * A_BYTES);
+            else if constexpr (k <= NH) fb[NH + k - 1] = ldsr(rdB + tap * B_BYTES + (NH + k - 1) * 1024);
+            else fa[1][k - NH] = ldsr(rd_px1(k - NH, TAPc) + BUF * A_BYTES);
           }
         }
         issue_piece(IDX);
@@ -436,7 +446,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
         constexpr int idx = decltype(IDX)::value, mt = idx / NH, nt = NH + idx % NH;
         constexpr int HS = DUAL ? 1 : CUR;             // pixel fragments of H1
         if constexpr (DUAL && nt == NH) relu_a(fa[1][mt], rmin);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[HS][mt], acc[mt][nt], 0, 0, 0);
+        if constexpr ((DBG & 2) != 0) { asm volatile("" :: "v"(fa[HS][mt])); asm volatile("" :: "v"(fb[nt])); }
+        else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[HS][mt], acc[mt][nt], 0, 0, 0);
         if constexpr ((idx & 1) == 0) {
           constexpr int k = idx / 2;
           constexpr int NXT = DUAL ? 0 : OTH;          // DUAL: fa[0] is free after H0
@@ -444,9 +455,9 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
           constexpr int nbuf = tap < 3 ? BUF : (BUF ^ 1);
           // (not DUAL: fa[CUR] stays live through H1, the next step's pixels go to the other set;
           //  b[0..3] are free after H0)
-          if constexpr (k == 0) fa[NXT][0] = *(const h8_t*)(smem + rdA[0][ntap] + nbuf * A_BYTES);
-          else if constexpr (k <= NH) fb[k - 1] = *(const h8_t*)(smem + rdB + ntap * B_BYTES + (k - 1) * 1024);
-          else fa[NXT][k - NH] = *(const h8_t*)(smem + rdA[k - NH][ntap] + nbuf * A_BYTES);
+          if constexpr (k == 0) fa[NXT][0] = ldsr(rdA[0][ntap] + nbuf * A_BYTES);
+          else if constexpr (k <= NH) fb[k - 1] = ldsr(rdB + ntap * B_BYTES + (k - 1) * 1024);
+          else fa[NXT][k - NH] = ldsr(rdA[k - NH][ntap] + nbuf * A_BYTES);
         }
         issue_piece(std::integral_constant<int, idx + MT * NH>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -464,6 +475,15 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   asm volatile("" ::: "memory");
+  if constexpr ((DBG & 32) != 0) {   // no epilogue: keep the accumulators alive with a store that never happens
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 12345.678f) p.out[0] = 1;
+    return;
+  }
   epilogue8<MODE>(p, acc, smem, tid, lane, wave, mt_idx, ph, py, px, n0, img, y0, x0, lgTW);
 }
 
@@ -477,6 +497,21 @@ int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, c
 #define GI_K8(MODE_, RELU_, NAME_) do { \
     if (!attr[v]) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<MODE_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr[v] = true; } \
     hipLaunchKernelGGL((igemm8_kernel<MODE_, RELU_>), dim3(grid), dim3(256), LDS, st, kp); gi_note_kernel(NAME_); } while (0)
+#ifdef GI_ABLATION   // timing-only ablation kernels compute wrong results: compiled only with `build.sh -DGI_ABLATION`
+  { const char* e = getenv("GI_IGEMM8_DBG"); const int dbg = e ? atoi(e) : 0;
+    if (dbg && v == 3) {
+#define GI_K8D(D_) do { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<1, true, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+      hipLaunchKernelGGL((igemm8_kernel<1, true, D_>), dim3(grid), dim3(256), LDS, st, kp); } while (0)
+      switch (dbg) {
+        case 1: GI_K8D(1); break; case 2: GI_K8D(2); break; case 4: GI_K8D(4); break; case 8: GI_K8D(8); break; case 16: GI_K8D(16); break;
+        case 32: GI_K8D(32); break; case 5: GI_K8D(5); break; case 7: GI_K8D(7); break; case 6: GI_K8D(6); break; case 3: GI_K8D(3); break;
+        case 39: GI_K8D(39); break; case 13: GI_K8D(13); break; default: GI_K8D(15); break;
+      }
+#undef GI_K8D
+      GI_LAUNCH_CHECK();
+      return GI_OK;
+    } }
+#endif
   switch (v) {
     case 0: GI_K8(0, false, "igemm8<0>"); break;
     case 1: GI_K8(0, true, "igemm8<0,relu>"); break;
