@@ -634,7 +634,7 @@ template <int NT>   // NT = c / 16
 __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const float* __restrict__ img, float* dW,
                                                             int n, int Hs, int Ws, int ldx, int coffx, int relu_in,
                                                             float scale, float img_scale, const char* X2, int ld2,
-                                                            const float* __restrict__ sc2, const float* __restrict__ sh2) {
+                                                            const float* __restrict__ sc2, const float* __restrict__ sh2, float* __restrict__ part) {
   constexpr int C = NT * 16;
   constexpr int LROW = C * 2 + 32;                  // padded LDS row: conflict-free transposing reads
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -741,8 +741,27 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave * (C * 16) + (nt * 16 + (lane & 15)) * 16 + 4 * (lane >> 4) + r] = acc[nt][r];
   __syncthreads();
-  for (int i = threadIdx.x; i < C * 16; i += 256)
-    atomicAdd(dW + i, (red[i] + red[C * 16 + i] + red[2 * C * 16 + i] + red[3 * C * 16 + i]) * scale);
+  // part != null: this block's sums go to part[block][C*16] (plain stores) and c1_wgrad_reduce_kernel adds the blocks in a fixed
+  // order (bit-reproducible); else one float atomic per (c, tap) and block
+  for (int i = threadIdx.x; i < C * 16; i += 256) {
+    const float v = (red[i] + red[C * 16 + i] + red[2 * C * 16 + i] + red[3 * C * 16 + i]) * scale;
+    if (part) part[(int64_t)blockIdx.x * (C * 16) + i] = v;
+    else atomicAdd(dW + i, v);
+  }
+}
+
+// dW[i] += sum over blocks of part[block][i], blocks in ascending order (four independent chains per thread, added in a fixed order)
+__global__ void __launch_bounds__(256) c1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int count, int blocks) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int b = 0;
+  for (; b + 4 <= blocks; b += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += part[(int64_t)(b + u) * count + i];
+  }
+  for (; b < blocks; ++b) s[0] += part[(int64_t)b * count + i];
+  dW[i] += (s[0] + s[1]) + (s[2] + s[3]);
 }
 
 // ---- discriminator head ----------------------------------------------------------------------
@@ -1293,7 +1312,7 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
 }
 
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws, int c,
-                int ldx, int coffx, int relu_in, float scale, float img_scale, const C1Affine* aff) {
+                int ldx, int coffx, int relu_in, float scale, float img_scale, const C1Affine* aff, float* scratch, int64_t scratch_floats) {
   GI_REQUIRE(!aff || (op_c1_affine_ok(dtype, c, Ws, ldx, coffx) && aff->ld2 % 8 == 0), "c1_wgrad: fused upper half unsupported here");
   const char* x2 = aff ? (const char*)aff->x2 : nullptr;
   const int ld2 = aff ? aff->ld2 : 0;
@@ -1305,13 +1324,18 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
     if (grid > 512) grid = 512;                        // 512 blocks x 1024 atomics on the same 1-2K addresses
     size_t lds = (size_t)4 * 32 * (c * 2 + 32);
     if (lds < (size_t)4 * c * 16 * 4) lds = (size_t)4 * c * 16 * 4;
+    float* part = (scratch && scratch_floats >= (int64_t)grid * c * 16) ? scratch : nullptr;   // deterministic two-stage sum
     if (c == 64)
       hipLaunchKernelGGL(c1_wgrad_mfma_kernel<4>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
-                         scale, img_scale, x2, ld2, sc2, sh2);
+                         scale, img_scale, x2, ld2, sc2, sh2, part);
     else
       hipLaunchKernelGGL(c1_wgrad_mfma_kernel<8>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, ldx, coffx, relu_in,
-                         scale, img_scale, x2, ld2, sc2, sh2);
+                         scale, img_scale, x2, ld2, sc2, sh2, part);
     GI_LAUNCH_CHECK();
+    if (part) {
+      hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((c * 16 + 255) / 256), dim3(256), 0, st, (const float*)part, dW, c * 16, grid);
+      GI_LAUNCH_CHECK();
+    }
     return GI_OK;
   }
   const int epc = dtype == GI_F16 ? 8 : 4;

@@ -186,8 +186,10 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
                   int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale,
                   void* col_scratch, float* img2 = nullptr, const C1Affine* aff = nullptr);
 // dW[c][tap] += scale * sum_p relu?(X[p][c]) * img[n,2y-1+ky,2x-1+kx]
+// scratch (optional, >= 512 * c * 16 floats): the workgroups' partial sums go there and are added in a fixed order (bit-reproducible)
 int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, float* dW, int n, int Hs, int Ws,
-                int c, int ldx, int coffx, int relu_in, float scale, float img_scale, const C1Affine* aff = nullptr);
+                int c, int ldx, int coffx, int relu_in, float scale, float img_scale, const C1Affine* aff = nullptr,
+                float* scratch = nullptr, int64_t scratch_floats = 0);
 
 // BatchNorm helpers -------------------------------------------------------------------------
 // partials [rows][2][c] -> scale/shift (y = x*scale + shift), saved mean / invstd; train mode also

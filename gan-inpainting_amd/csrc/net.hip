@@ -845,14 +845,25 @@ __global__ void __launch_bounds__(256) fill_f32_kernel(float* dst, int count, fl
   for (int i = threadIdx.x; i < count; i += 256) dst[i] = v;
 }
 
-__global__ void __launch_bounds__(256) sum_acc_kernel(const float* src, int64_t count, float* dst, float scale) {
+// dst += scale * sum(src), bit-reproducible: per-block sums (fp64) to part[gridDim.x], then ONE block adds them in index order
+__global__ void __launch_bounds__(256) sum_part_kernel(const float* src, int64_t count, double* part) {
   __shared__ double sh[4];
   double s = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) s += src[i];
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(dst, (float)((sh[0] + sh[1] + sh[2] + sh[3]) * scale));
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void __launch_bounds__(256) sum_finish_kernel(const double* part, int blocks, float* dst, float scale) {
+  __shared__ double sh[256];
+  sh[threadIdx.x] = threadIdx.x < blocks ? part[threadIdx.x] : 0.0;   // blocks <= 256
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dst[0] += (float)(sh[0] * scale);
 }
 
 int grid1d(int64_t work) {
@@ -1119,7 +1130,9 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   // u1: ConvTranspose2d(2ngf -> 1) + bias
   const int c1 = 2 * net->ch[1];
   if (need_wgrad) {
-    hipLaunchKernelGGL(sum_acc_kernel, dim3(256), dim3(256), 0, st, G0, npx, net->grads + net->up[1].bias_off, iLS);
+    // (the u1 bias gradient: a sum over every output pixel, fixed order)
+    hipLaunchKernelGGL(sum_part_kernel, dim3(256), dim3(256), 0, st, G0, npx, (double*)net->shared(net->oPart));
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)net->shared(net->oPart), 256, net->grads + net->up[1].bias_off, iLS);
     GI_LAUNCH_CHECK();
     C1Affine aff;
     const bool fused = net->slot_fused_u2[s] != 0;
@@ -1127,7 +1140,8 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
       BNPtrs p = bn_ptrs(net, s, net->unorm[2]);
       aff.x2 = net->slot(s, net->oU[2]); aff.ld2 = net->ch[1]; aff.scale = p.scale; aff.shift = p.shift;
     }
-    GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, fused ? &aff : nullptr));
+    GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, fused ? &aff : nullptr,
+                       (float*)net->shared(net->oPart), net->part_floats));
   }
   if (net->out_c == 1) {
     GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
@@ -1199,7 +1213,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     else GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
     if (need_wgrad)
       GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c,
-                         0, 0, iLS, 1.f));
+                         0, 0, iLS, 1.f, nullptr, (float*)net->shared(net->oPart), net->part_floats));
     if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS,
                                  net->shared(net->oCol)));
   }
@@ -1308,7 +1322,8 @@ int unet_backward_plain(gi_net* net, int s, const float* dy, float* dx, int need
     GI_TRY(op_tanh_bwd(st, dy, (const float*)net->slot(s, net->oOut), G0, npx * net->out_c, LS));
     const int c1 = 2 * net->ch[1];
     if (need_wgrad) {
-      hipLaunchKernelGGL(sum_acc_kernel, dim3(256), dim3(256), 0, st, G0, npx, net->grads + net->up[1].bias_off, iLS);
+      hipLaunchKernelGGL(sum_part_kernel, dim3(256), dim3(256), 0, st, G0, npx, (double*)net->shared(net->oPart));
+      hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)net->shared(net->oPart), 256, net->grads + net->up[1].bias_off, iLS);
       GI_LAUNCH_CHECK();
       GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, nullptr));
     }
@@ -1489,7 +1504,8 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
                       1.f, nullptr, need_wgrad));
   }
   if (need_wgrad)
-    GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f));
+    GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f,
+                       nullptr, (float*)net->shared(net->oPart), net->part_floats));
   if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS,
                                net->shared(net->oCol)));
   return GI_OK;

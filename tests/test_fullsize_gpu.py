@@ -49,8 +49,10 @@ def test_headline_step_properties_256_bs32_fp16():
 
 
 def test_generator_backward_is_linear_in_the_output_gradient_256_bs32():
-    """d(params) for 2*dy equals 2 * d(params) for dy (powers of two commute with every fp16 / fp32 rounding),
-    except the atomically accumulated weight gradients whose summation order varies: compare with a tolerance there."""
+    """d(params) for 2*dy equals 2 * d(params) for dy: the two forwards are bit-identical (split-K sums in a fixed order, exact
+    BatchNorm statistics), every parameter gradient is summed in a fixed order, and powers of two commute with every fp16 /
+    fp32 rounding of NORMAL numbers - what remains are fp16 gradient values in the subnormal range (below 6e-5 at this loss
+    scale), whose rounding does not scale."""
     torch.manual_seed(3)
     G = networks.UnetGenerator(1, 1, 7, ngf=64, use_dropout=False, dtype="fp16").cuda().train()    # no dropout: same forward twice
     G.set_loss_scale(1024.0)
@@ -65,10 +67,11 @@ def test_generator_backward_is_linear_in_the_output_gradient_256_bs32():
     y2, s, g = G._forward_raw(x)
     G._backward_raw(s, g, 2 * dy, False, True)
     g2 = G.flat_grads()
-    assert torch.equal(y, y2) or (y - y2).abs().max().item() <= 3e-2       # split-K atomics in the 6 deepest layers, amplified by train-mode BatchNorm (observed 5e-3)
+    assert torch.equal(y, y2), "two train-mode forwards of the same batch differ"
+    bad = (g2 != 2 * g1)
     rel = float((g2.double() - 2 * g1.double()).norm() / (2 * g1.double()).norm())
-    print("linearity rel L2", rel)
-    assert rel <= 2e-2   # the two forwards differ in the last bits (split-K atomics), the backward itself is exactly linear
+    print(f"linearity: {int(bad.sum())} of {g1.numel()} entries not exactly doubled, rel L2 {rel:.3e}")
+    assert rel <= 1e-3
 
 
 def test_eval_forward_is_independent_of_batch_composition_and_handle_size():
@@ -85,7 +88,7 @@ def test_eval_forward_is_independent_of_batch_composition_and_handle_size():
         solo = G2.cuda().eval()(x[:5].contiguous())  # fresh handle sized for 5
     # the deep layers take different split-K shapes at different batch sizes: fp16-level agreement, not bitwise
     assert (full[:5] - part).abs().max().item() <= 2e-2
-    assert (part - solo).abs().max().item() <= 2e-2      # same shapes, but the split-K atomics order their sums freely
+    assert torch.equal(part, solo)                       # same shapes, same kernels, fixed summation orders: bit for bit
 
 
 def test_train_forward_is_permutation_equivariant():

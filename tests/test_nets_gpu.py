@@ -234,11 +234,12 @@ def test_patchgan_vs_oracle(dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
-def test_unet_forward_and_input_gradient_are_reproducible(dtype):
-    """Split-K layers reduce inside the GEMM kernel: whichever workgroup arrives last adds the splits in split order, and the
-    BatchNorm statistics go through exact integer accumulators - so the forward output, the running statistics and the input
-    gradient repeat BIT FOR BIT from run to run (igemm7 / the generic kernel's fix-up, stat_acc.h). (Parameter gradients of the
-    layers whose weight-gradient kernel uses fp32 atomics are not part of this statement.)"""
+def test_unet_forward_and_gradients_are_reproducible(dtype):
+    """Split-K layers reduce inside the GEMM kernel (whichever workgroup arrives last adds the splits in split order), the
+    BatchNorm statistics go through exact integer accumulators, weight gradients are summed from partial tiles in a fixed order
+    (the single-channel layers d1 / u1 and the u1 bias included: c1_wgrad_reduce_kernel, sum_finish_kernel) - so the forward
+    output, the running statistics, the input gradient and, in fp16 (the benchmarked path), EVERY parameter gradient repeat BIT
+    FOR BIT from run to run. (fp32: the VALU form of the single-channel weight gradient still adds with float atomics.)"""
     nd, N, HW = 7, 3, 128
     P = op.make_unet_params(777, num_downs=nd)
     ground, mask = op.synth_batch(778, N, HW, HW)
@@ -250,12 +251,36 @@ def test_unet_forward_and_input_gradient_are_reproducible(dtype):
         y = net(x)
         y.sum().backward()
         stats = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k}
-        runs.append((y.detach().cpu().clone(), x.grad.detach().cpu().clone(), stats))
+        grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
+        runs.append((y.detach().cpu().clone(), x.grad.detach().cpu().clone(), stats, grads))
     for r in runs[1:]:
         assert torch.equal(runs[0][0], r[0]), "forward output differs between runs"
         assert torch.equal(runs[0][1], r[1]), "input gradient differs between runs"
         for k in runs[0][2]:
             assert torch.equal(runs[0][2][k], r[2][k]), k
+        for k in runs[0][3]:
+            if dtype == "fp16" or k not in ("model.model.0.weight", "model.model.3.weight"):   # (fp32: d1 / u1 weights, see above)
+                assert torch.equal(runs[0][3][k], r[3][k]), f"parameter gradient {k} differs between runs"
+
+
+@pytest.mark.parametrize("dtype", ["fp16"])
+def test_patchgan_gradients_are_reproducible(dtype):
+    """The stacked critic of the headline step (two BatchNorm populations): output, input gradient and every parameter
+    gradient bit for bit from run to run."""
+    HW, N = 128, 8
+    P = op.make_patchgan_params(901, HW, HW)
+    ground, _ = op.synth_batch(902, N, HW, HW)
+    runs = []
+    for _ in range(3):
+        net = make_d(P, HW, False, dtype)
+        net.zero_grad()
+        y, s, g = net._forward_raw(torch.from_numpy(ground).cuda(), 2)
+        dx = net._backward_raw(s, g, torch.ones_like(y), True, True)
+        torch.cuda.synchronize()
+        runs.append((y.cpu().clone(), dx.cpu().clone(), net.flat_grads().cpu().clone()))
+    for r in runs[1:]:
+        assert torch.equal(runs[0][0], r[0]) and torch.equal(runs[0][1], r[1])
+        assert torch.equal(runs[0][2], r[2]), f"{int((runs[0][2] != r[2]).sum())} parameter-gradient entries differ between runs"
 
 
 @pytest.mark.parametrize("cfg", [(64, 5), (256, 4), (512, 1)])
