@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-run() { name=$1; shift; echo "== $name"; timeout -k 10 400 "$@" > $OUT/$name.log 2>&1 || { echo "$name failed"; tail -5 $OUT/$name.log; }; }
+run() { name=$1; shift; echo "== $name"; timeout -k 10 600 "$@" > $OUT/$name.log 2>&1 || { echo "$name failed"; tail -5 $OUT/$name.log; }; }
 # A. the dominant kernel alone; B. the whole benchmark process; C. its HBM traffic (one --pmc pass per counter)
 run kernel_only rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_only -- python3 $R/bench.py --kernel-only --kernel-iters 50
 run bench rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --steps 20 --warmup 5 --preheat 50 --no-cpu-baseline
@@ -18,7 +18,8 @@ i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM" \
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_INT32 SQ_INSTS_BRANCH" \
-           "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS"; do
+           "SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" \
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   run pmc_g$i rocprofv3 --pmc $grp --output-format csv -d $OUT/pmc_g$i -- python3 $R/bench.py --kernel-only --kernel-iters 5
 done
@@ -31,7 +32,9 @@ for wl in wgan_gp_128 dual_d_256 config5_512; do
   run line_$wl python3 $R/bench.py --workload $wl --steps 20 --warmup 5 --preheat 50 --no-cpu-baseline
   run stats_$wl rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 5 --preheat 10 --no-cpu-baseline
 done
-# G. the headline line itself, unprofiled (with the CPU baseline)
+# G. the headline line itself, unprofiled (with the CPU baseline); H. the multi-rank launch path rehearsed with two gloo ranks on
+# this one card (RCCL needs one GPU per rank: the 8-GPU run is the driver's)
 run line_headline python3 $R/bench.py --steps 20 --warmup 5
+GI_DIST_BACKEND=gloo run line_two_ranks_gloo python3 $R/bench.py --gpus 2 --steps 10 --warmup 2 --preheat 20 --no-cpu-baseline
 find $OUT -name "*.csv" | wc -l
 echo done

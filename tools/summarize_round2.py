@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-DOM = "igemm6_kernel<1, 128, true"      # the roofline object's kernel (generator u3 with the fused input ReLU)
+DOM = os.environ.get("GI_DOM_KERNEL", "igemm8_kernel<1, true")      # the roofline object's kernel (generator u3 with the fused input ReLU; round 2: igemm6_kernel<1, 128, true)
 
 
 def newest(pattern):
@@ -109,7 +109,7 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
               f"{algo / 1e6:.1f} MB -> {traffic / algo:.2f}x.\n")
     out.write(f"* rocprof average duration of the dominant kernel: **{avg_ms * 1e3:.1f} us** -> {flop / avg_ms / 1e9:.0f} TFLOP/s = {flop / avg_ms / 1e9 / 2500 * 100:.1f} % of 2.5 PFLOP/s dense fp16.\n\n")
     json.dump({"hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch, "write_size_kb": write, "correction": "2*FETCH_SIZE + WRITE_SIZE (gfx950)",
-               "rocprof_avg_ms": avg_ms, "round": tag, "kernel": "igemm6_kernel<1, 128, true> (generator u3)", "commit": commit},
+               "rocprof_avg_ms": avg_ms, "round": tag, "kernel": DOM + "> (generator u3)", "commit": commit},
               open("profiles/dominant_kernel_traffic.json", "w"), indent=1)
     # D. counters
     counters = {}
@@ -123,13 +123,18 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
                 acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in acc.items():
             counters[k] = sum(v) / len(v)
-    json.dump({"kernel": "igemm6_kernel<1, 128, true> on the u3 shape (bench.py --kernel-only)", "round": tag, "commit": commit, "per_launch_avg": counters},
+    json.dump({"kernel": DOM + "> on the u3 shape (bench.py --kernel-only)", "round": tag, "commit": commit, "per_launch_avg": counters},
               open(f"profiles/{tag}_dominant_kernel_pmc.json", "w"), indent=1, sort_keys=True)
     if counters.get("SQ_VALU_MFMA_BUSY_CYCLES") and counters.get("SQ_BUSY_CYCLES"):
         busy = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0     # 256 CUs x 4 SIMDs
         out.write("## D. Counters of the dominant kernel (`profiles/%s_dominant_kernel_pmc.json`)\n\n" % tag)
-        out.write(f"* MFMA-busy cycles per SIMD = SQ_VALU_MFMA_BUSY_CYCLES / 1024 = {busy:.0f}; elapsed = avg duration x 2.4 GHz = {avg_ms * 1e-3 * 2.4e9:.0f} cycles -> "
-                  f"**{busy / (avg_ms * 1e-3 * 2.4e9):.2f}** of the launch (round 1, igemm5: 0.38).\n")
+        out.write(f"* MFMA-busy cycles per SIMD = SQ_VALU_MFMA_BUSY_CYCLES / 1024 = {busy:.0f}; elapsed at the NOMINAL 2.4 GHz = {avg_ms * 1e-3 * 2.4e9:.0f} cycles -> "
+                  f"{busy / (avg_ms * 1e-3 * 2.4e9):.2f} of the launch.\n")
+        if counters.get("GRBM_GUI_ACTIVE"):   # measured clock: GRBM_GUI_ACTIVE is the sum over the 8 XCDs (guides/MI355X_MICROARCH.md, DVFS give-back)
+            cyc = counters["GRBM_GUI_ACTIVE"] / 8.0
+            out.write(f"* measured clock: GRBM_GUI_ACTIVE / 8 = {cyc:.0f} cycles per launch (the counter pass's own launches) -> MFMA-busy **{busy / cyc:.2f}** of the "
+                      f"elapsed cycles (round 1, igemm5: 0.38 at a measured 1.96 GHz; round 2, igemm6: 0.45 at that clock); the quotient cycles / duration reads "
+                      f"{cyc / (avg_ms * 1e-3) / 1e9:.2f} GHz against the un-profiled duration (high on launches this short, as the guide warns).\n")
         for k in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT"):
             if k in counters:
                 out.write(f"* {k}: {counters[k]:.0f}\n")
