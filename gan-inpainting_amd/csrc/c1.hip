@@ -143,62 +143,61 @@ __global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __res
 }
 
 // ---- fp16 gather on the matrix cores ---------------------------------------------------------------
-// out[p][c] = act(sum_tap G[p][tap] * w[c][tap]) as D[c][pixel] = A[c][tap] * B[tap][pixel], K = 16 taps
-// zero-padded to 32 (v_mfma_f32_16x16x32_f16): the weights (A) live in registers, each wave gathers
-// the 16 taps of 16 consecutive pixels of one image row (lanes with k-chunk 0/1: two image rows x 4
-// columns each), and every lane ends with 4 consecutive channels of its pixel per 16-channel tile.
-template <int MTC>   // MTC = c / 16
+// out[p][c] = act(sum_tap G[p][tap] * w[c][tap]) as D[c][pixel] = A[c][tap] * B[tap][pixel], K = 16 taps = one
+// v_mfma_f32_16x16x16_f16: the weights (A) live in registers, each wave gathers the 16 taps of 16 consecutive pixels of
+// one image row - lane (pixel lr, k-chunk kq) holds tap row ky = kq, i.e. the four image columns 2x-1 .. 2x+2 of image row
+// 2y-1+kq: one 8-byte load for the aligned middle pair and two single loads, from clamped addresses with the padding
+// zeroed by selects (no divergent branches; the group index is wave-uniform, so the (image, row, column) split is
+// scalar 32-bit arithmetic). Every lane ends with 4 consecutive channels of its pixel per 16-channel tile.
+// The first form of this kernel (K padded to 32, half the lanes loading 8 taps behind per-tap bounds branches, 64-bit
+// divisions per group) spent 22 of its 39 us on the critic's conv1 in address arithmetic, measured with loads and stores
+// switched off; the layer is 134 MB of stores.
+template <int MTC, int ACT>   // MTC = c / 16
 __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              char* out, int n, int Hs, int Ws, int ldout, int coffout,
-                                                             int act, float in_scale) {
+                                                             float in_scale) {
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
-  const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  // A[row lr of tile mt][k = tap 8*kq + j] (zero for kq >= 2) holds the weights of channel
-  //   ch(mt, lr) = (mt >> 2) * 64 + (lr >> 2) * 16 + (mt & 3) * 4 + (lr & 3)
-  // D row i of a tile lands in lane group kq = i >> 2, register r = i & 3, so after its four tiles a lane owns the
-  // 16 CONSECUTIVE channels (mt >> 2) * 64 + kq * 16 .. + 15 of its pixel: two 16-byte stores, and the four lanes
-  // of a pixel write its 128-byte row in one instruction (the natural order gave 8-byte pieces on 16 lines).
-  h8_t af[MTC];
+  // A[row lr of tile mt][k = 4*kq + j] = w[ch][tap 4*kq + j] with
+  //   ch(mt, lr) = (mt >> 2) * 64 + ((mt >> 1) & 1) * 32 + (lr >> 2) * 8 + (mt & 1) * 4 + (lr & 3)
+  // D row i of a tile lands in lane group kq = i >> 2, register r = i & 3, so after tiles 0,1 a lane owns the 8
+  // consecutive channels kq * 8 .. + 7 of its pixel's first 32 and after tiles 2,3 those of the second 32: each of the
+  // two 16-byte stores of the four lanes of a pixel covers 64 contiguous bytes.
+  h4_t af[MTC];
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
-    af[mt] = zero;
-    if (kq < 2) {
-      const int ch = (mt >> 2) * 64 + (lr >> 2) * 16 + (mt & 3) * 4 + (lr & 3);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) af[mt][j] = (half_t)w[ch * 16 + kq * 8 + j];
-    }
+    const int ch = (mt >> 2) * 64 + ((mt >> 1) & 1) * 32 + (lr >> 2) * 8 + (mt & 1) * 4 + (lr & 3);
+    const f4_t v = *(const f4_t*)(w + ch * 16 + kq * 4);
+    af[mt] = h4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
   }
   const int H = 2 * Hs, W = 2 * Ws;
-  const int64_t ngroups = (int64_t)n * Hs * Ws / 16;     // Ws % 16 == 0: a group lies in one image row
-  const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
-  auto load_b = [&](int64_t g, float (&bv)[8]) {
-    const int64_t p0 = g * 16;
-    const int x = (int)(p0 % Ws) + lr;
-    const int64_t rowi = p0 / Ws;
-    const int y = (int)(rowi % Hs);
-    const int nn = (int)(rowi / Hs);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = 0.f;
-    if (kq < 2) {
-      const float* ip = img + (int64_t)nn * H * W;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int iy = 2 * y - 1 + 2 * kq + (j >> 2), ix = 2 * x - 1 + (j & 3);
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) bv[j] = ip[(int64_t)iy * W + ix];
-      }
-    }
+  const int gpr = Ws >> 4;                       // groups per small-grid row (Ws % 16 == 0)
+  const int ngroups = n * Hs * gpr;              // < 2^31 (checked by the host)
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int nwaves = (int)gridDim.x * 4;
+  auto load_b = [&](int g, float (&bv)[4]) {
+    const int rowi = g / gpr;                    // wave-uniform
+    const int x = (g - rowi * gpr) * 16 + lr;
+    const int nn = rowi / Hs, y = rowi - nn * Hs;
+    const int iy = 2 * y - 1 + kq;
+    const bool rok = iy >= 0 && iy < H;
+    const float* rp = img + ((int64_t)nn * H + (rok ? iy : 0)) * W;
+    const int ix0 = 2 * x - 1;                   // -1 only at x = 0; ix0 + 3 = W only at x = Ws - 1
+    const float a0 = rp[ix0 < 0 ? 0 : ix0];
+    const float2 mid = *(const float2*)(rp + ix0 + 1);
+    const float a3 = rp[ix0 + 3 < W ? ix0 + 3 : W - 1];
+    bv[0] = (rok && ix0 >= 0) ? a0 : 0.f;
+    bv[1] = rok ? mid.x : 0.f;
+    bv[2] = rok ? mid.y : 0.f;
+    bv[3] = (rok && ix0 + 3 < W) ? a3 : 0.f;
   };
-  float bv[8], bn[8];
-  int64_t g = wave;
+  float bv[4], bn[4];
+  int g = wave;
   if (g < ngroups) load_b(g, bv);
   for (; g < ngroups; g += nwaves) {
     if (g + nwaves < ngroups) load_b(g + nwaves, bn);
-    h8_t bf;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bf[j] = (half_t)(bv[j] * in_scale);
-    const int64_t pix = g * 16 + lr;
+    const h4_t bf = {(half_t)(bv[0] * in_scale), (half_t)(bv[1] * in_scale), (half_t)(bv[2] * in_scale), (half_t)(bv[3] * in_scale)};
+    const int64_t pix = (int64_t)g * 16 + lr;
     char* dst = out + ((pix * ldout + coffout) << 1);
 #pragma unroll
     for (int mq = 0; mq < MTC / 4; ++mq) {
@@ -206,15 +205,20 @@ __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __rest
 #pragma unroll
       for (int m4 = 0; m4 < 4; ++m4) {
         f4_t acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mq * 4 + m4], bf, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(af[mq * 4 + m4], bf, acc, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[m4 >> 1][(m4 & 1) * 4 + r] = (half_t)act_f(acc[r], act);
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[r];
+          if (ACT == GI_ACT_RELU) v = fmaxf(v, 0.f);
+          if (ACT == GI_ACT_LRELU) v = fmaxf(v, 0.2f * v);      // = v > 0 ? v : 0.2 v
+          o[m4 >> 1][(m4 & 1) * 4 + r] = (half_t)v;
+        }
       }
-      *(h8_t*)(dst + ((mq * 64 + kq * 16) << 1)) = o[0];         // channels mq*64 + kq*16 + 0..7
-      *(h8_t*)(dst + ((mq * 64 + kq * 16 + 8) << 1)) = o[1];     //                          + 8..15
+      *(h8_t*)(dst + ((mq * 64 + kq * 8) << 1)) = o[0];          // channels mq*64 + kq*8 + 0..7
+      *(h8_t*)(dst + ((mq * 64 + 32 + kq * 8) << 1)) = o[1];     //          mq*64 + 32 + kq*8 + 0..7
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = bn[j];
+    for (int j = 0; j < 4; ++j) bv[j] = bn[j];
   }
 }
 
@@ -412,7 +416,7 @@ __global__ void __launch_bounds__(256) c1_gather_mc4_kernel(const float* __restr
   constexpr int OC = 4;
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
-  // A[row lr of tile mt][k = 32 s + 8 kq + j] = w[ch][tap = 8 (kq & 1) + j][o = 2 s + (kq >> 1)], ch as in c1_gather_mfma_kernel
+  // A[row lr of tile mt][k = 32 s + 8 kq + j] = w[ch][tap = 8 (kq & 1) + j][o = 2 s + (kq >> 1)], ch = 16 consecutive channels per lane (the mapping c1_gather_mfma_kernel used before its 64-byte store pieces)
   h8_t af[MTC][2];
 #pragma unroll
   for (int mt = 0; mt < MTC; ++mt) {
@@ -750,18 +754,32 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
   }
 }
 
-// dW[i] += sum over blocks of part[block][i], blocks in ascending order (four independent chains per thread, added in a fixed order)
+// dW[i] += sum over blocks of part[block][i] in a fixed order: a workgroup owns 16 outputs, thread (i, g) adds the blocks of
+// group g (a contiguous range, four independent chains) and the 16 group sums are added in ascending order by one thread
+// per output. (One thread per output walking all 512 blocks was 41 us on 4 workgroups; this is latency-bound on 32 loads.)
 __global__ void __launch_bounds__(256) c1_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int count, int blocks) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + o;
+  const int per = (blocks + 15) / 16;
+  const int b0 = g * per, b1 = min(blocks, b0 + per);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  int b = 0;
-  for (; b + 4 <= blocks; b += 4) {
+  if (i < count) {
+    int b = b0;
+    for (; b + 4 <= b1; b += 4) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] += part[(int64_t)(b + u) * count + i];
+      for (int u = 0; u < 4; ++u) s[u] += part[(int64_t)(b + u) * count + i];
+    }
+    for (; b < b1; ++b) s[0] += part[(int64_t)b * count + i];
   }
-  for (; b < blocks; ++b) s[0] += part[(int64_t)b * count + i];
-  dW[i] += (s[0] + s[1]) + (s[2] + s[3]);
+  red[g][o] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (g == 0 && i < count) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][o];
+    dW[i] += t;
+  }
 }
 
 // ---- discriminator head ----------------------------------------------------------------------
@@ -1237,11 +1255,16 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
   const int groups = c / 8;
   if (dtype == GI_F16 && !bias && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 8 == 0 && coffout % 8 == 0) {
     const int64_t ngroups = (int64_t)n * Hs * Ws / 16;
+    GI_REQUIRE(ngroups < (1ll << 31) && (act_out == GI_ACT_NONE || act_out == GI_ACT_RELU || act_out == GI_ACT_LRELU), "c1_gather: %lld pixel groups / activation %d",
+               (long long)ngroups, act_out);
     const int grid = grid_for(ngroups, 4, 256 * 8);
-    if (c == 64)
-      hipLaunchKernelGGL(c1_gather_mfma_kernel<4>, dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, act_out, in_scale);
-    else
-      hipLaunchKernelGGL(c1_gather_mfma_kernel<8>, dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, act_out, in_scale);
+#define GI_C1G(MTC_, ACT_) hipLaunchKernelGGL((c1_gather_mfma_kernel<MTC_, ACT_>), dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, in_scale)
+    if (c == 64) {
+      if (act_out == GI_ACT_LRELU) GI_C1G(4, GI_ACT_LRELU); else if (act_out == GI_ACT_RELU) GI_C1G(4, GI_ACT_RELU); else GI_C1G(4, GI_ACT_NONE);
+    } else {
+      if (act_out == GI_ACT_LRELU) GI_C1G(8, GI_ACT_LRELU); else if (act_out == GI_ACT_RELU) GI_C1G(8, GI_ACT_RELU); else GI_C1G(8, GI_ACT_NONE);
+    }
+#undef GI_C1G
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
@@ -1333,7 +1356,7 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
                          scale, img_scale, x2, ld2, sc2, sh2, part);
     GI_LAUNCH_CHECK();
     if (part) {
-      hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((c * 16 + 255) / 256), dim3(256), 0, st, (const float*)part, dW, c * 16, grid);
+      hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((c * 16 + 15) / 16), dim3(256), 0, st, (const float*)part, dW, c * 16, grid);
       GI_LAUNCH_CHECK();
     }
     return GI_OK;

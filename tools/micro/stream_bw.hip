@@ -45,6 +45,20 @@ __global__ void __launch_bounds__(256) pass_kernel(const char* a, const char* b,
   }
 }
 
+// write-only stream (the single-channel gather layers write 8x what they read): every thread stores U 16-byte chunks per trip
+template <int U>
+__global__ void __launch_bounds__(256) fill_kernel(char* out, long total, unsigned v) {
+  const long stride = (long)gridDim.x * 256;
+  const u4_t x = {v, v + 1, v + 2, v + 3};
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += U * stride) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      if (i < total) *(u4_t*)(out + i * 16) = x;
+    }
+  }
+}
+
 template <int R, int U, bool NT>
 float run(const char* a, const char* b, const char* c, char* out, long total, int cpp, int ldf, int blocks, int iters) {
   hipEvent_t e0, e1;
@@ -68,6 +82,19 @@ int main(int argc, char** argv) {
   // a spacer buffer the passes alternate with, so that nothing survives in the 256 MiB Infinity Cache between iterations
   printf("stream %ld MiB per tensor; columns: R reads + 1 write, U chunks in flight, blocks/CU, layout, policy -> us, GB/s total\n", mb);
   const int cpp = 16;   // 128 channels fp16
+  for (int bpc : {2, 8, 32}) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(fill_kernel<2>, dim3(256 * bpc), dim3(256), 0, 0, a, 2 * total, 7u);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(fill_kernel<2>, dim3(256 * bpc), dim3(256), 0, 0, a, 2 * total, 7u + i);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 20;
+    printf("write only, %ld MiB, b/CU=%2d : %7.1f us %7.0f GB/s\n", 2 * mb, bpc, ms * 1e3, 2.0 * bytes / ms / 1e6);
+  }
   for (int ldf = 1; ldf <= 2; ++ldf)
     for (int bpc : {2, 4, 8, 16}) {
       const int blocks = 256 * bpc;
