@@ -253,21 +253,34 @@ __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float*
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
   const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t g = wave; g < ngroups; g += nwaves) {
+  // a wave walks 4+ groups: the next group's 16-byte row pieces are requested before this group's are used
+  auto load_g = [&](int64_t g, h8_t (&raw)[KS]) {
     const int64_t pix = g * 16 + tapr;   // this lane's B column = pixel
+    const bool live = pix < P;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (X2 && ks >= KH) raw[ks] = live ? *(const h8_t*)(X2 + ((pix * ld2 + (ks - KH) * 32 + kq * 8) << 1)) : zero;
+      else raw[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
+    }
+  };
+  h8_t raw[KS], nxt[KS];
+  int64_t g = wave;
+  if (g < ngroups) load_g(g, raw);
+  for (; g < ngroups; g += nwaves) {
+    if (g + nwaves < ngroups) load_g(g + nwaves, nxt);
+    const int64_t pix = g * 16 + tapr;
     const bool live = pix < P;
     h8_t bf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (X2 && ks >= KH) {
-        const h8_t raw = live ? *(const h8_t*)(X2 + ((pix * ld2 + (ks - KH) * 32 + kq * 8) << 1)) : zero;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float t = fmaf((float)raw[j], s2[ks >= KH ? ks - KH : 0][j], h2[ks >= KH ? ks - KH : 0][j]);
+          const float t = fmaf((float)raw[ks][j], s2[ks >= KH ? ks - KH : 0][j], h2[ks >= KH ? ks - KH : 0][j]);
           bf[ks][j] = live ? (half_t)(t > 0.f ? t : 0.f) : (half_t)0.f;
         }
       } else {
-        bf[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
+        bf[ks] = raw[ks];
         if (relu_in) bf[ks] = __builtin_elementwise_max(bf[ks], zero);
       }
     }
@@ -278,6 +291,8 @@ __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float*
       h4_t o = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
       *(h4_t*)(col + pix * 16 + kq * 4) = o;   // taps 4kq..4kq+3 of this pixel
     }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) raw[ks] = nxt[ks];
   }
 }
 
@@ -673,20 +688,23 @@ __global__ void __launch_bounds__(256) c1_wgrad_mfma_kernel(const char* X, const
       xv[i] = upper ? *(const u4_t*)(X2 + ((row * ld2 + xc * 8 - C / 2) << 1)) : *(const u4_t*)(X + ((row * ldx + coffx) << 1) + xc * 16);
     }
   };
-  auto load_a = [&](int64_t t, float (&av)[8]) {   // 8 pixels x0 + 8*kq + j of the tile's image row, tap (ky,kx)
-    const int64_t p0 = t * 32;
-    const int x0 = (int)(p0 % Ws);
-    const int64_t rowi = p0 / Ws;
-    const int y = (int)(rowi % Hs);
-    const int nn = (int)(rowi / Hs);
+  auto load_a = [&](int64_t t64, float (&av)[8]) {   // 8 pixels x0 + 8*kq + j of the tile's image row, tap (ky,kx)
+    // the tile index is wave-uniform and < 2^31 (host check): scalar 32-bit divisions; clamped addresses + selects, no branches
+    const int t32 = __builtin_amdgcn_readfirstlane((int)t64);
+    const int tpr = Ws >> 5;                      // tiles per small-grid row (Ws % 32 == 0)
+    const int rowi = t32 / tpr;
+    const int x0 = (t32 - rowi * tpr) * 32;
+    const int nn = rowi / Hs, y = rowi - nn * Hs;
     const int iy = 2 * y - 1 + ky;
     const bool yok = iy >= 0 && iy < H;
     const float* ip = img + ((int64_t)nn * H + (yok ? iy : 0)) * W;
+    const int ixb = 2 * (x0 + 8 * kq) - 1 + kx;   // -1 only for j = 0 at the row start, W only for j = 7 at the row end
+    const float a0 = ip[ixb < 0 ? 0 : ixb];
+    const float a7 = ip[ixb + 14 < W ? ixb + 14 : W - 1];
+    av[0] = (yok && ixb >= 0) ? a0 : 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ix = 2 * (x0 + 8 * kq + j) - 1 + kx;
-      av[j] = (yok && ix >= 0 && ix < W) ? ip[ix] : 0.f;
-    }
+    for (int j = 1; j < 7; ++j) { const float a = ip[ixb + 2 * j]; av[j] = yok ? a : 0.f; }
+    av[7] = (yok && ixb + 14 < W) ? a7 : 0.f;
   };
   u4_t xv[NP], xn[NP];
   float av[8], an[8];
@@ -1343,8 +1361,10 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
   const float* sh2 = aff ? aff->shift : nullptr;
   if (dtype == GI_F16 && (c == 64 || c == 128) && Ws % 32 == 0 && ldx % 8 == 0 && coffx % 8 == 0) {
     const int64_t ntiles = (int64_t)n * Hs * Ws / 32;
+    GI_REQUIRE(ntiles < (1ll << 31), "c1_wgrad: %lld pixel tiles", (long long)ntiles);
     int grid = (int)((ntiles + 3) / 4);
-    if (grid > 512) grid = 512;                        // 512 blocks x 1024 atomics on the same 1-2K addresses
+    const int cap = gi_tune("GI_C1W_GRID", 512);       // per workgroup: c*16 partial sums (stores or atomics)
+    if (grid > cap) grid = cap;
     size_t lds = (size_t)4 * 32 * (c * 2 + 32);
     if (lds < (size_t)4 * c * 16 * 4) lds = (size_t)4 * c * 16 * 4;
     float* part = (scratch && scratch_floats >= (int64_t)grid * c * 16) ? scratch : nullptr;   // deterministic two-stage sum
