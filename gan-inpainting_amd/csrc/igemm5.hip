@@ -805,8 +805,9 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   // gives every CU at least two workgroups (with one per CU half the wave slots stay empty: measured d3 / u4 / critic conv4,
   // 256 workgroups, 10 - 16 % slower than igemm6; every layer with >= 512 workgroups 3 - 16 % faster), 2 every eligible layer
   const int use8 = gi_opt(GI_OPT_IGEMM8);
-  if (use8 && mode != 2 && (dual || BN == 128) && a.cin % 32 == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
-      (int64_t)a.cout * (mode == 1 ? 4 : 16) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&
+  // (the 3x3 mode: 128-column tiles on 32-wide patches, no fused input ReLU; VGG-19 from conv2_1 to conv4_4)
+  if (use8 && (mode != 2 || (BN == 128 && TW == 32 && !a.relu_in)) && (dual || BN == 128) && a.cin % 32 == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
+      (int64_t)a.cout * (mode == 1 ? 4 : (mode == 2 ? 9 : 16)) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&
       (use8 >= 2 || grid >= gi_tune("GI_IGEMM8_MINGRID", 512))) {
     GI_TRY(op_igemm8_launch(st, mode, dual, a.relu_in != 0, grid, kp));
     a.ntiles_out = mtiles * nph;

@@ -210,17 +210,22 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][8], char*
 // reads, 8 no ReLU on the fragments, 16 no per-step barrier, 32 no epilogue
 template <int MODE, bool RELU, int DBG = 0>
 __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
-  static_assert(MODE == 0 || MODE == 1 || MODE == 3, "4-tap modes");
+  static_assert(MODE >= 0 && MODE <= 3, "modes 0 (stride-2 gather), 1 (phase), 2 (3x3 / s1), 3 (both px phases)");
+  static_assert(!(MODE == 2 && RELU), "the 3x3 mode has no fused input ReLU");
   constexpr bool DUAL = MODE == 3;
   constexpr bool PH = MODE == 1 || MODE == 3;
   constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups (parity classes) per channel chunk
-  constexpr int NTAP = 4;
-  constexpr int PADX = DUAL ? 2 : 1;
+  constexpr int NTAP = MODE == 2 ? 9 : 4;               // taps (steps) per halo group
+  constexpr int PADX = (DUAL || MODE == 2) ? 2 : 1, PADY = MODE == 2 ? 2 : 1;
   constexpr int BN = 128, BK = 32, NW = 4;
-  constexpr int AJ = 5;                                 // halo pieces (16 rows x 64 B) per wave and group: 320 rows
-  constexpr int A_BYTES = AJ * NW * 1024;               // 20 KiB per buffer
+  constexpr int AJ = MODE == 2 ? 6 : 5;                 // halo pieces (16 rows x 64 B) per wave and group
+  // MODE 2: the 10 x 34 halo is 340 rows = 22 pieces; waves 2, 3 issue their fifth piece twice so that every wave counts the
+  // same number of loads (piece index = j * 4 + wave there, wave * AJ + j in the 4-tap modes)
+  constexpr int APIECES = MODE == 2 ? 22 : AJ * NW;
+  constexpr int AHEAD = 3;                              // a weight slice is issued 3 steps before its step: ring of 4
+  constexpr int A_BYTES = APIECES * 1024;               // 20 (22) KiB per buffer
   constexpr int B_BYTES = BN * 64;                      // 8 KiB per stage
-  constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;         // + 4 ring stages: 72 KiB
+  constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;         // + 4 ring stages: 72 (76) KiB
   constexpr int BJ = (BN / 16) / NW;                    // weight-slice pieces per wave and step (2)
   constexpr int MT = 4, NT = 8, NH = 4;                 // NH: column tiles per half step
   constexpr unsigned OOB = 0x80000000u;                 // beyond any tensor (sizes are checked < 2^31 bytes): reads as zeros
@@ -242,8 +247,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   const int n0 = nt_idx * (DUAL ? 64 : BN);
   const int img = mt_idx / p.tiles_per_img, trem = mt_idx % p.tiles_per_img;
   const int y0 = (trem / p.tiles_x) * p.TH, x0 = (trem % p.tiles_x) * p.TW;
-  const int HC = p.TW + PADX, HR = p.TH + 1;
-  const int Ktot2 = (PH ? 4 : 16) * p.cin * 2;          // bytes per weight row
+  const int HC = p.TW + PADX, HR = p.TH + PADY;
+  const int Ktot2 = (PH ? 4 : (MODE == 2 ? 9 : 16)) * p.cin * 2;   // bytes per weight row
   const int64_t phase_bytes = (int64_t)p.cout * Ktot2;
   const int Win = 2 * p.Ws, Hin = 2 * p.Hs;             // mode 0: the large (input) grid
 
@@ -255,9 +260,13 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   // ---- per-lane piece offsets (loop invariant): lane l of a piece = row l >> 2, LDS chunk l & 3 = logical chunk (l & 3) ^ s(row)
   const int lrow = lane >> 2, lc = lane & 3;
   unsigned voffA[NQ][AJ];
+  auto piece_of = [&](int j) -> int {                    // halo piece index of this wave's j-th piece
+    if constexpr (MODE == 2) { const int P = j * NW + wave; return P < APIECES ? P : P - NW; }
+    else return wave * AJ + j;
+  };
 #pragma unroll
   for (int j = 0; j < AJ; ++j) {
-    const int r = (wave * AJ + j) * 16 + lrow;
+    const int r = piece_of(j) * 16 + lrow;
     const int hr = r / HC, hc = r - hr * HC;
     const int cb = (lc ^ ((r >> 1) & 3)) * 16;
     if constexpr (MODE != 0) {
@@ -285,7 +294,9 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   // ---- fragment read offsets (loop invariant) -----------------------------------------------------------------------------
   const int lr = lane & 15, lq = lane >> 4;
   const int lgTW = 31 - __builtin_clz(p.TW);
-  int rdA[MT][NTAP];                   // (pixel tile, tap) inside an A buffer; DUAL: px 0
+  // (pixel tile, tap) inside an A buffer; DUAL: px 0. MODE 2 keeps the halo row of tap (0,0) only (36 addresses would not fit
+  // the register budget) and derives a tap's address at its read: row + ky * HC + kx, then the chunk swizzle (5 VALU)
+  int rdA[MT][MODE == 2 ? 1 : NTAP];
   // DUAL, px 1: its halo rows lie one column to the right, so tap (ty, tx = 1) of px 1 reads the rows of px 0's tap (ty, tx = 0)
   // (rdA[mt][2 ty]); only its tx = 0 taps (column tx_l + 2) need addresses of their own: [pixel tile][ty]
   int rdA2[DUAL ? MT : 1][2];
@@ -293,15 +304,28 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   for (int mt = 0; mt < MT; ++mt) {
     const int m = wave * 64 + mt * 16 + lr;
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
+    if constexpr (MODE == 2) {
+      rdA[mt][0] = ty_l * HC + tx_l;               // a ROW here, not a byte address
+    } else {
 #pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      const int R = PH ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1)) : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
-      rdA[mt][tap] = A_OFF + R * 64 + ((lq ^ ((R >> 1) & 3)) << 4);
-      if constexpr (DUAL) {
-        if ((tap & 1) == 0) rdA2[mt][tap >> 1] = A_OFF + (R + 1) * 64 + ((lq ^ (((R + 1) >> 1) & 3)) << 4);
+      for (int tap = 0; tap < NTAP; ++tap) {
+        const int R = PH ? (ty_l + 1 - (tap >> 1)) * HC + (tx_l + 1 - (tap & 1)) : (ty_l + (tap >> 1)) * HC + (tx_l + (tap & 1));
+        rdA[mt][tap] = A_OFF + R * 64 + ((lq ^ ((R >> 1) & 3)) << 4);
+        if constexpr (DUAL) {
+          if ((tap & 1) == 0) rdA2[mt][tap >> 1] = A_OFF + (R + 1) * 64 + ((lq ^ (((R + 1) >> 1) & 3)) << 4);
+        }
       }
     }
   }
+  auto addrA = [&](int mt, auto TAP) -> int {       // byte address of (pixel tile, tap) inside an A buffer
+    constexpr int tap = decltype(TAP)::value;
+    if constexpr (MODE == 2) {
+      const int R = rdA[mt][0] + (tap / 3) * HC + (tap % 3);
+      return A_OFF + R * 64 + ((lq ^ ((R >> 1) & 3)) << 4);
+    } else {
+      return rdA[mt][tap];
+    }
+  };
   auto rd_px1 = [&](int mt, auto TAP) -> int {      // address of px 1's pixel fragment (DUAL)
     constexpr int tap = decltype(TAP)::value;
     if constexpr ((tap & 1) != 0) return rdA[mt][tap & ~1];
@@ -340,7 +364,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   using I2 = std::integral_constant<int, 2>;
   using I3 = std::integral_constant<int, 3>;
 
-  auto issue_b = [&](unsigned (&vb)[BJ], int chunk, auto Q, auto TAP, auto J) {
+  // weight slice of (chunk, tap) into ring stage `stage` (4-tap modes: stage = tap)
+  auto issue_b = [&](unsigned (&vb)[BJ], int chunk, auto Q, auto TAP, auto J, int stage) {
     constexpr int q = decltype(Q)::value, tap = decltype(TAP)::value, j = decltype(J)::value;
     int koff;
     if constexpr (MODE != 0) {
@@ -349,23 +374,23 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
       constexpr int ky = (q >> 1) ? 2 * (tap >> 1) : 2 * (tap >> 1) + 1, kx = (q & 1) ? 2 * (tap & 1) : 2 * (tap & 1) + 1;
       koff = (ky * 4 + kx) * p.cin + chunk * BK;
     }
-    blds16(rsB, vb[j], koff * 2, smem + B_OFF + tap * B_BYTES + (wave * BJ + j) * 1024);
+    blds16(rsB, vb[j], koff * 2, smem + B_OFF + stage * B_BYTES + (wave * BJ + j) * 1024);
   };
 
-  // ---- prologue: halo of group 0, weight slices of steps 0, 1, 2 (nsteps >= 4) ------------------------------------------------
-  static_for<AJ>([&](auto J) { blds16(rsA, voffA[0][decltype(J)::value], 0, smem + A_OFF + (wave * AJ + decltype(J)::value) * 1024); });
-  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I0{}, J); });
-  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I1{}, J); });
-  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I2{}, J); });
+  // ---- prologue: halo of group 0, weight slices of steps 0 .. AHEAD - 1 (nsteps >= 4) ---------------------------------------
+  static_for<AJ>([&](auto J) { blds16(rsA, voffA[0][decltype(J)::value], 0, smem + A_OFF + piece_of(decltype(J)::value) * 1024); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I0{}, J, 0); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I1{}, J, 1); });
+  static_for<BJ>([&](auto J) { issue_b(voffB, 0, I0{}, I2{}, J, 2); });
   // fragment registers: two pixel-fragment sets and the eight column fragments
   //   not DUAL: fa[tap & 1] = this step's pixels (both halves), fa[(tap & 1) ^ 1] receives the next step's during H1
   //   DUAL:     fa[0] = px 0 rows (H0; refilled with the next step's during H1), fa[1] = px 1 rows (read during H0, used in H1)
   h8_t fa[2][MT], fb[NT];
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the slice of step 2 (BJ = 2 pieces)
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the last slice issued (BJ = 2 pieces)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
-  for (int i = 0; i < MT; ++i) fa[0][i] = *(const h8_t*)(smem + rdA[i][0]);
+  for (int i = 0; i < MT; ++i) fa[0][i] = *(const h8_t*)(smem + addrA(i, I0{}));
 #pragma unroll
   for (int i = 0; i < NH; ++i) fb[i] = *(const h8_t*)(smem + rdB + i * 1024);
 
@@ -375,6 +400,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   auto group = [&](int c, auto GIc) {
     constexpr int GI = decltype(GIc)::value;
     constexpr int BUF = GI & 1, Q = MODE == 0 ? GI : 0, QN = MODE == 0 ? ((GI + 1) & 3) : 0;
+    constexpr int PAR0 = (MODE == 2) ? (GI & 1) : 0;             // nine taps per group: the fragment-set parity alternates per group
     using QT = std::integral_constant<int, Q>;
     using QNT = std::integral_constant<int, QN>;
     const int chunk = c / NQ, chunk_n = (c + 1) / NQ;            // channel chunk of this group / of the next one
@@ -386,23 +412,30 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
     static_for<NTAP>([&](auto TAPc) {
       constexpr int tap = decltype(TAPc)::value;
       const int s = c * NTAP + tap;
-      // in flight may stay: the pieces issued during step s-1 = a weight slice (BJ) + its halo pieces (3 in tap 0, 2 in tap 1)
-      constexpr int ptap = (tap + 3) & 3;
-      constexpr int nwait = BJ + (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0));
+      // in flight may stay: the pieces issued during step s-1 = a weight slice (BJ) + its halo pieces (3 in tap 0, 2 in tap 1;
+      // MODE 2: one in each of taps 0..5)
+      constexpr int ptap = (tap + NTAP - 1) % NTAP;
+      constexpr int nwait = BJ + (MODE == 2 ? (ptap < AJ ? 1 : 0) : (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0)));
       if constexpr (nwait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if constexpr (nwait == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else if constexpr (nwait == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       if constexpr ((DBG & 16) == 0) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // weight slice of step s + 3 = (group c, tap 3) during tap 0, else (group c + 1, tap - 1); out of range past the end
+      // weight slice of step s + 3: 4-tap modes (group c, tap 3) during tap 0, else (group c + 1, tap - 1); MODE 2 (chunk c,
+      // tap + 3) or (chunk c + 1, tap - 6); out of range past the end. Ring stage of a step = step & 3: a constant per tap in the
+      // 4-tap modes, a scalar in MODE 2 (nine taps per group)
+      const int stg = MODE == 2 ? (s & 3) : tap, nstg = MODE == 2 ? ((s + 1) & 3) : ((tap + 1) & 3), istg = MODE == 2 ? ((s + 3) & 3) : ((tap + 3) & 3);
       unsigned vb[BJ];
 #pragma unroll
-      for (int j = 0; j < BJ; ++j) vb[j] = s + 3 < nsteps ? voffB[j] : OOB;
+      for (int j = 0; j < BJ; ++j) vb[j] = s + AHEAD < nsteps ? voffB[j] : OOB;
       auto issue_piece = [&](auto IDX) {
         constexpr int idx = decltype(IDX)::value;      // MFMA counter of this step, 0 .. 31
         constexpr int NM = MT * NT;
         if constexpr ((DBG & 1) != 0) return;
-        if constexpr (tap == 0) {      // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
+        if constexpr (MODE == 2) {     // halo of chunk c+1: piece `tap` during taps 0..5
+          if constexpr (tap < AJ && idx == NM / 4) blds16(rsA, va[tap], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + piece_of(tap) * 1024);
+        } else if constexpr (tap == 0) {      // halo of group c+1: pieces 0,1,2 during tap 0, pieces 3,4 during tap 1
           if constexpr (idx == NM / 4) blds16(rsA, va[0], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 0) * 1024);
           if constexpr (idx == NM / 4 + 2) blds16(rsA, va[1], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 1) * 1024);
           if constexpr (idx == NM / 4 + 4) blds16(rsA, va[2], chunk_n * (BK * 2), smem + A_OFF + (BUF ^ 1) * A_BYTES + (wave * AJ + 2) * 1024);
@@ -413,12 +446,18 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
         static_for<BJ>([&](auto Jc) {
           constexpr int j = decltype(Jc)::value;
           if constexpr (idx == NM - 2 - (BJ - 1 - j) * 2) {
-            if constexpr (tap == 0) issue_b(vb, chunk, QT{}, I3{}, Jc);
-            else issue_b(vb, chunk_n, QNT{}, std::integral_constant<int, tap - 1>{}, Jc);
+            if constexpr (MODE == 2) {
+              if constexpr (tap + AHEAD < NTAP) issue_b(vb, chunk, QT{}, std::integral_constant<int, tap + AHEAD>{}, Jc, istg);
+              else issue_b(vb, chunk_n, QNT{}, std::integral_constant<int, tap + AHEAD - NTAP>{}, Jc, istg);
+            } else {
+              if constexpr (tap == 0) issue_b(vb, chunk, QT{}, I3{}, Jc, istg);
+              else issue_b(vb, chunk_n, QNT{}, std::integral_constant<int, tap - 1>{}, Jc, istg);
+            }
           }
         });
       };
-      constexpr int CUR = DUAL ? 0 : (tap & 1);        // pixel fragments of H0 (not DUAL: of the whole step)
+      constexpr int CUR = DUAL ? 0 : ((PAR0 + tap) & 1);   // pixel fragments of H0 (not DUAL: of the whole step)
+      const int rdBs = rdB + stg * B_BYTES, rdBn = rdB + nstg * B_BYTES;   // column fragments of this / the next step
       constexpr int OTH = DUAL ? 1 : (CUR ^ 1);        // DUAL: px 1 rows of this step; else: the next step's set
       // ---- H0: column tiles 0..3. One fragment read behind every second MFMA:
       //   not DUAL: b[4..7] of this step;  DUAL: a1[0], b[4..7], a1[1..3] of this step
@@ -430,10 +469,10 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
         if constexpr ((idx & 1) == 0) {
           constexpr int k = idx / 2;                   // read slot 0 .. 7
           if constexpr (!DUAL) {
-            if constexpr (k < NH) fb[NH + k] = ldsr(rdB + tap * B_BYTES + (NH + k) * 1024);
+            if constexpr (k < NH) fb[NH + k] = ldsr(rdBs + (NH + k) * 1024);
           } else {
             if constexpr (k == 0) fa[1][0] = ldsr(rd_px1(0, TAPc) + BUF * A_BYTES);
-            else if constexpr (k <= NH) fb[NH + k - 1] = ldsr(rdB + tap * B_BYTES + (NH + k - 1) * 1024);
+            else if constexpr (k <= NH) fb[NH + k - 1] = ldsr(rdBs + (NH + k - 1) * 1024);
             else fa[1][k - NH] = ldsr(rd_px1(k - NH, TAPc) + BUF * A_BYTES);
           }
         }
@@ -451,13 +490,14 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
         if constexpr ((idx & 1) == 0) {
           constexpr int k = idx / 2;
           constexpr int NXT = DUAL ? 0 : OTH;          // DUAL: fa[0] is free after H0
-          constexpr int ntap = (tap + 1) & 3;
-          constexpr int nbuf = tap < 3 ? BUF : (BUF ^ 1);
+          constexpr int ntap = (tap + 1) % NTAP;
+          constexpr int nbuf = tap < NTAP - 1 ? BUF : (BUF ^ 1);
+          using NT_ = std::integral_constant<int, ntap>;
           // (not DUAL: fa[CUR] stays live through H1, the next step's pixels go to the other set;
           //  b[0..3] are free after H0)
-          if constexpr (k == 0) fa[NXT][0] = ldsr(rdA[0][ntap] + nbuf * A_BYTES);
-          else if constexpr (k <= NH) fb[k - 1] = ldsr(rdB + ntap * B_BYTES + (k - 1) * 1024);
-          else fa[NXT][k - NH] = ldsr(rdA[k - NH][ntap] + nbuf * A_BYTES);
+          if constexpr (k == 0) fa[NXT][0] = ldsr(addrA(0, NT_{}) + nbuf * A_BYTES);
+          else if constexpr (k <= NH) fb[k - 1] = ldsr(rdBn + (k - 1) * 1024);
+          else fa[NXT][k - NH] = ldsr(addrA(k - NH, NT_{}) + nbuf * A_BYTES);
         }
         issue_piece(std::integral_constant<int, idx + MT * NH>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -491,9 +531,9 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
 
 // Launched by op_igemm5 (igemm5.hip) with the kernel arguments it has prepared; grid as igemm6's.
 int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp) {
-  constexpr int LDS = 2 * 20480 + 4 * 8192;   // = the epilogue's 256 x 136 halves + 4 x 128 x 2 floats
-  static bool attr[6] = {false, false, false, false, false, false};
-  const int v = (dual ? 2 : mode) * 2 + (relu ? 1 : 0);
+  const int LDS = (mode == 2 ? 2 * 22528 : 2 * 20480) + 4 * 8192;   // 4-tap modes: = the epilogue's 256 x 136 halves + 4 x 128 x 2 floats
+  static bool attr[8] = {false, false, false, false, false, false, false, false};
+  const int v = mode == 2 ? 6 : (dual ? 2 : mode) * 2 + (relu ? 1 : 0);
 #define GI_K8(MODE_, RELU_, NAME_) do { \
     if (!attr[v]) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<MODE_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr[v] = true; } \
     hipLaunchKernelGGL((igemm8_kernel<MODE_, RELU_>), dim3(grid), dim3(256), LDS, st, kp); gi_note_kernel(NAME_); } while (0)
@@ -518,7 +558,8 @@ int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, c
     case 2: GI_K8(1, false, "igemm8<1>"); break;
     case 3: GI_K8(1, true, "igemm8<1,relu>"); break;
     case 4: GI_K8(3, false, "igemm8<3>"); break;
-    default: GI_K8(3, true, "igemm8<3,relu>"); break;
+    case 5: GI_K8(3, true, "igemm8<3,relu>"); break;
+    default: GI_K8(2, false, "igemm8<2>"); break;
   }
 #undef GI_K8
   GI_LAUNCH_CHECK();

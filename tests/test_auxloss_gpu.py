@@ -75,6 +75,34 @@ def test_vgg_feature_maps_vs_oracle():
     assert np.abs(got3 - fx["tap3_head_0"]).max() <= 5e-3 * np.abs(fx["tap3_head_0"]).max()
 
 
+@pytest.mark.parametrize("family", ["igemm8", "igemm5"])
+def test_vgg_feature_maps_per_3x3_kernel_family(family):
+    """128x128 inputs put conv2_x (64 wide) and conv3_x (32 wide) on 32-wide patches, the shape class the 512x512 workload runs
+    its 3x3 layers in: with GI_IGEMM8=2 they take igemm8's nine-tap mode (two workgroups per CU, three-stage weight ring) whatever
+    the grid size, with GI_IGEMM8=0 igemm5's; both against the oracle's fp32 feature maps."""
+    _, networks = _mods()
+    from gan_inpainting_amd import backend as B
+    seed, n, hw = 77, 2, 128
+    P = op.make_vgg19_params(seed)
+    g, mk = op.synth_batch(seed + 1, n, hw, hw)
+    x = torch.from_numpy(g)
+    ref = orc.vgg19_tap_features({k: torch.from_numpy(v) for k, v in P.items()}, x)
+    old = B.get_option("GI_IGEMM8")
+    B.set_option("GI_IGEMM8", 2 if family == "igemm8" else 0)
+    try:
+        vgg = networks.VGG19Wrapper(max_pairs=2).cuda()
+        vgg.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()})
+        for tap in range(5):
+            got = vgg.features(x.cuda(), tap).cpu()
+            if tap == 2:      # ends with conv3_1 (128 -> 256 channels on a 32 x 32 map)
+                assert B.last_kernel() == ("igemm8<2>" if family == "igemm8" else "igemm5<2,128>"), B.last_kernel()
+            rel = float((got.double() - ref[tap].double()).norm() / ref[tap].double().norm())
+            print(f"{family} tap {tap} {tuple(got.shape)} rel L2 {rel:.2e}")
+            assert rel <= FEAT_TOL
+    finally:
+        B.set_option("GI_IGEMM8", old)
+
+
 def test_vgg_state_dict_roundtrip_and_errors():
     _, networks = _mods()
     from gan_inpainting_amd import backend as B
