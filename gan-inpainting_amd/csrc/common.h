@@ -142,6 +142,9 @@ struct IgemmArgs {
   float bwd_slope;
   unsigned long long* bwd_acc; int bwd_reps; int64_t bwd_pg;
   int bwd_applied;
+  // mode 2 (3x3 / s1) only: store the 2x2 / stride-2 max pool of the activated output instead of the output itself (`out` is then the
+  // (n, Hs/2, Ws/2, cout) tensor). Kernels that implement it set pool_applied = 1; otherwise the caller pools in a separate pass.
+  int pool2, pool_applied;
   int stat_used;   // (returned) 1: the statistics went to stat_acc; 0: to `partials` (split-K layers: their finish pass
                    // has few rows per block, the partial rows + finalize launch are cheaper there than 4 atomics per channel)
 };

@@ -25,6 +25,7 @@ struct KP5 {
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
   float bwd_slope;
   unsigned long long* bwd_acc; int bwd_reps; int bwd_pg_tiles;   // bwd_pg_tiles: M tiles per BatchNorm population (0: one population)
+  int pool;           // MODE 2: the epilogue stores the 2x2 max pool of the tile (IgemmArgs::pool2)
   int dbg_epi;        // builds with -DGI_ABLATION only (GI_EPI_DBG): 1 = all tiles store into one 64 KiB window (no HBM write burst)
 };
 

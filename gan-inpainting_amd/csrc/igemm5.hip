@@ -27,7 +27,7 @@
 #include "halo_args.h"
 
 const char* gi_igemm3_zero_page(int dev);   // igemm3.hip
-int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp);   // igemm8.hip
+int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp, int bn);   // igemm8.hip
 
 namespace {
 
@@ -773,6 +773,8 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.mask = (const char*)a.mask; kp.ldmask = a.ldmask; kp.coffmask = a.coffmask; kp.mask_slope = a.mask_slope;
   kp.add = a.mask ? (const char*)a.add : nullptr; kp.ldadd = a.ldadd; kp.coffadd = a.coffadd;
   kp.dbg_epi = 0;
+  kp.pool = 0;
+  a.pool_applied = 0;
 #ifdef GI_ABLATION
   { const char* e = getenv("GI_EPI_DBG"); if (e) kp.dbg_epi = atoi(e); }
 #endif
@@ -806,10 +808,15 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   // 256 workgroups, 10 - 16 % slower than igemm6; every layer with >= 512 workgroups 3 - 16 % faster), 2 every eligible layer
   const int use8 = gi_opt(GI_OPT_IGEMM8);
   // (the 3x3 mode: 128-column tiles on 32-wide patches, no fused input ReLU; VGG-19 from conv2_1 to conv4_4)
-  if (use8 && (mode != 2 || (BN == 128 && TW == 32 && !a.relu_in)) && (dual || BN == 128) && a.cin % 32 == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
+  if (use8 && (mode != 2 || (TW == 32 && !a.relu_in)) && (dual || BN == 128 || mode == 2) && a.cin % 32 == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
       (int64_t)a.cout * (mode == 1 ? 4 : (mode == 2 ? 9 : 16)) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&
       (use8 >= 2 || grid >= gi_tune("GI_IGEMM8_MINGRID", 512))) {
-    GI_TRY(op_igemm8_launch(st, mode, dual, a.relu_in != 0, grid, kp));
+    if (mode == 2 && a.pool2 && !a.mask && !a.stat_acc && !a.partials) {   // the pooled store: igemm8's 3x3 mode only
+      GI_REQUIRE(a.coffout == 0 && (int64_t)a.n * (a.Hs / 2) * (a.Ws / 2) * a.ldout < (1ll << 31), "igemm8: pooled output layout");
+      kp.pool = 1;
+      a.pool_applied = 1;
+    }
+    GI_TRY(op_igemm8_launch(st, mode, dual, a.relu_in != 0, grid, kp, BN));
     a.ntiles_out = mtiles * nph;
     return GI_OK;
   }

@@ -46,12 +46,12 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff,
 // ---- epilogue (contract of igemm3 / epilogue5): bias / activation, per-tile column statistics, the tile staged through LDS
 //      and stored with 16-byte rows; optional fused activation backward and BatchNorm-backward reduction. 256 threads, wave w
 //      holds rows 64 w .. 64 w + 63 x 128 columns. -----------------------------------------------------------------------------
-template <int MODE>
-__device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][8], char* smem, int tid, int lane, int wave, int mt_idx,
+template <int MODE, int BN>
+__device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16], char* smem, int tid, int lane, int wave, int mt_idx,
                                           int ph, int py, int px, int n0, int img, int y0, int x0, int lgTW) {
   constexpr bool DUAL = MODE == 3;
   constexpr bool PH = MODE == 1 || MODE == 3;
-  constexpr int BM = 256, BN = 128, MT = 4, NT = 8;
+  constexpr int BM = 256, MT = 4, NT = BN / 16;
   const int lr = lane & 15, lq = lane >> 4;
   auto out_pixel = [&](int m) -> int {
     const int ty_l = m >> lgTW, tx_l = m & (p.TW - 1);
@@ -122,6 +122,22 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][8], char*
       const int ch = go + n0 + oc * 8 + e;
       bsc[e] = p.bwd_scale[ch]; bsh[e] = p.bwd_shift[ch]; bmu[e] = p.bwd_mean[ch]; biv[e] = p.bwd_inv[ch];
       bs[e] = bsx[e] = 0.f;
+    }
+  }
+  if constexpr (MODE == 2) {
+    if (p.pool) {     // 2x2 / stride-2 max pool of the staged (activated) 8 x 32 patch: 4 x 16 output pixels of (Hs/2) x (Ws/2)
+      constexpr int RPQ = 256 / CPRO;
+#pragma unroll
+      for (int k = 0; k < 64 / RPQ; ++k) {
+        const int r = tid / CPRO + k * RPQ;                 // pooled pixel of the patch: (r >> 4, r & 15)
+        const int m = (2 * (r >> 4)) * 32 + 2 * (r & 15);   // its top-left source row (TW = 32)
+        const char* sp = (const char*)stg + ((int64_t)m * SLD + oc * 8) * 2;
+        const h8_t a = *(const h8_t*)sp, b = *(const h8_t*)(sp + SLD * 2), c = *(const h8_t*)(sp + 32 * SLD * 2), d = *(const h8_t*)(sp + 33 * SLD * 2);
+        const h8_t v = __builtin_elementwise_max(__builtin_elementwise_max(a, b), __builtin_elementwise_max(c, d));
+        const int64_t opx = ((int64_t)img * (p.Hs >> 1) + (y0 >> 1) + (r >> 4)) * (p.Ws >> 1) + (x0 >> 1) + (r & 15);
+        *(h8_t*)(p.out + (opx * p.ldout + n0 + oc * 8) * 2) = v;
+      }
+      return;
     }
   }
   // a thread copies 16 rows (one 16-byte chunk each), eight at a time: all global loads of the eight rows (fused mask, second
@@ -208,8 +224,9 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][8], char*
 
 // DBG (builds with -DGI_ABLATION only, WRONG results, timing experiments): 1 no LDS-DMA in the loop, 2 no MFMA, 4 no fragment
 // reads, 8 no ReLU on the fragments, 16 no per-step barrier, 32 no epilogue
-template <int MODE, bool RELU, int DBG = 0>
+template <int MODE, bool RELU, int DBG = 0, int BN = 128>
 __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
+  static_assert(BN == 128 || (BN == 64 && MODE == 2), "64-column tiles: the 3x3 mode only (VGG conv1_2)");
   static_assert(MODE >= 0 && MODE <= 3, "modes 0 (stride-2 gather), 1 (phase), 2 (3x3 / s1), 3 (both px phases)");
   static_assert(!(MODE == 2 && RELU), "the 3x3 mode has no fused input ReLU");
   constexpr bool DUAL = MODE == 3;
@@ -217,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   constexpr int NQ = MODE == 0 ? 4 : 1;                 // halo groups (parity classes) per channel chunk
   constexpr int NTAP = MODE == 2 ? 9 : 4;               // taps (steps) per halo group
   constexpr int PADX = (DUAL || MODE == 2) ? 2 : 1, PADY = MODE == 2 ? 2 : 1;
-  constexpr int BN = 128, BK = 32, NW = 4;
+  constexpr int BK = 32, NW = 4;
   constexpr int AJ = MODE == 2 ? 6 : 5;                 // halo pieces (16 rows x 64 B) per wave and group
   // MODE 2: the 10 x 34 halo is 340 rows = 22 pieces; waves 2, 3 issue their fifth piece twice so that every wave counts the
   // same number of loads (piece index = j * 4 + wave there, wave * AJ + j in the 4-tap modes)
@@ -226,8 +243,9 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   constexpr int A_BYTES = APIECES * 1024;               // 20 (22) KiB per buffer
   constexpr int B_BYTES = BN * 64;                      // 8 KiB per stage
   constexpr int A_OFF = 0, B_OFF = 2 * A_BYTES;         // + 4 ring stages: 72 (76) KiB
-  constexpr int BJ = (BN / 16) / NW;                    // weight-slice pieces per wave and step (2)
-  constexpr int MT = 4, NT = 8, NH = 4;                 // NH: column tiles per half step
+  constexpr int BJ = (BN / 16) / NW;                    // weight-slice pieces per wave and step (2; 1 with 64 columns)
+  constexpr int MT = 4, NT = BN / 16, NH = NT / 2;      // NH: column tiles per half step
+  constexpr int SP = NT == 8 ? 2 : 1;                   // a fragment read behind every SP-th MFMA
   constexpr unsigned OOB = 0x80000000u;                 // beyond any tensor (sizes are checked < 2^31 bytes): reads as zeros
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -386,7 +404,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   //   not DUAL: fa[tap & 1] = this step's pixels (both halves), fa[(tap & 1) ^ 1] receives the next step's during H1
   //   DUAL:     fa[0] = px 0 rows (H0; refilled with the next step's during H1), fa[1] = px 1 rows (read during H0, used in H1)
   h8_t fa[2][MT], fb[NT];
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the last slice issued (BJ = 2 pieces)
+  if constexpr (BJ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // all but the last slice issued (BJ pieces)
+  else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -416,7 +435,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
       // MODE 2: one in each of taps 0..5)
       constexpr int ptap = (tap + NTAP - 1) % NTAP;
       constexpr int nwait = BJ + (MODE == 2 ? (ptap < AJ ? 1 : 0) : (ptap == 0 ? 3 : (ptap == 1 ? 2 : 0)));
-      if constexpr (nwait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if constexpr (nwait == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if constexpr (nwait == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if constexpr (nwait == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       else if constexpr (nwait == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -466,8 +486,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
         if constexpr (nt == 0) relu_a(fa[CUR][mt], rmin);
         if constexpr ((DBG & 2) != 0) { asm volatile("" :: "v"(fa[CUR][mt])); asm volatile("" :: "v"(fb[nt])); }
         else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[CUR][mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
-        if constexpr ((idx & 1) == 0) {
-          constexpr int k = idx / 2;                   // read slot 0 .. 7
+        if constexpr (idx % SP == 0) {
+          constexpr int k = idx / SP;                  // read slot 0 .. 7
           if constexpr (!DUAL) {
             if constexpr (k < NH) fb[NH + k] = ldsr(rdBs + (NH + k) * 1024);
           } else {
@@ -487,8 +507,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
         if constexpr (DUAL && nt == NH) relu_a(fa[1][mt], rmin);
         if constexpr ((DBG & 2) != 0) { asm volatile("" :: "v"(fa[HS][mt])); asm volatile("" :: "v"(fb[nt])); }
         else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[nt], fa[HS][mt], acc[mt][nt], 0, 0, 0);
-        if constexpr ((idx & 1) == 0) {
-          constexpr int k = idx / 2;
+        if constexpr (idx % SP == 0) {
+          constexpr int k = idx / SP;
           constexpr int NXT = DUAL ? 0 : OTH;          // DUAL: fa[0] is free after H0
           constexpr int ntap = (tap + 1) % NTAP;
           constexpr int nbuf = tap < NTAP - 1 ? BUF : (BUF ^ 1);
@@ -497,7 +517,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
           //  b[0..3] are free after H0)
           if constexpr (k == 0) fa[NXT][0] = ldsr(addrA(0, NT_{}) + nbuf * A_BYTES);
           else if constexpr (k <= NH) fb[k - 1] = ldsr(rdBn + (k - 1) * 1024);
-          else fa[NXT][k - NH] = ldsr(addrA(k - NH, NT_{}) + nbuf * A_BYTES);
+          else if constexpr (k < NH + MT) fa[NXT][k - NH] = ldsr(addrA(k - NH, NT_{}) + nbuf * A_BYTES);
         }
         issue_piece(std::integral_constant<int, idx + MT * NH>{});
         __builtin_amdgcn_sched_barrier(0);
@@ -524,13 +544,22 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
     if (t == 12345.678f) p.out[0] = 1;
     return;
   }
-  epilogue8<MODE>(p, acc, smem, tid, lane, wave, mt_idx, ph, py, px, n0, img, y0, x0, lgTW);
+  epilogue8<MODE, BN>(p, acc, smem, tid, lane, wave, mt_idx, ph, py, px, n0, img, y0, x0, lgTW);
 }
 
 }  // namespace
 
 // Launched by op_igemm5 (igemm5.hip) with the kernel arguments it has prepared; grid as igemm6's.
-int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp) {
+int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp, int bn) {
+  if (mode == 2 && bn == 64) {      // VGG conv1_2: 64 output channels
+    static bool attr64 = false;
+    const int lds64 = 2 * 22528 + 4 * 4096;
+    if (!attr64) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<2, false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64)); attr64 = true; }
+    hipLaunchKernelGGL((igemm8_kernel<2, false, 0, 64>), dim3(grid), dim3(256), lds64, st, kp);
+    gi_note_kernel("igemm8<2,64>");
+    GI_LAUNCH_CHECK();
+    return GI_OK;
+  }
   const int LDS = (mode == 2 ? 2 * 22528 : 2 * 20480) + 4 * 8192;   // 4-tap modes: = the epilogue's 256 x 136 halves + 4 x 128 x 2 floats
   static bool attr[8] = {false, false, false, false, false, false, false, false};
   const int v = mode == 2 ? 6 : (dual ? 2 : mode) * 2 + (relu ? 1 : 0);

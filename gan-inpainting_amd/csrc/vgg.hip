@@ -8,9 +8,10 @@
 //            a 1->64 conv with the weights summed over the input channel: one HBM-bound VALU kernel;
 //   12 more  3x3/s1/p1 convolutions + bias + ReLU: igemm3 mode 2 (fp16 MFMA implicit GEMM, LDS-DMA ring);
 //   2x2 max pooling: 16-byte NHWC kernel;
-//   taps     perceptual term mean((F_o - F_t)^2) (fp32 partials, fixed-order finish) and the Gram matrices
-//            F^T F / (H W C) as an MFMA GEMM with K = pixels (both operands pixel-major: transposing LDS
-//            reads as in wgrad.hip), then mean((G_o - G_t)^2).
+//   taps     perceptual term mean((F_o - F_t)^2) and the Gram matrices F^T F / (H W C) (MFMA GEMM with K = pixels,
+//            both operands pixel-major: transposing LDS reads as in wgrad.hip) in ONE pass per tap over the
+//            image pairs (gram2_kernel: partial tiles, no atomics), then mean((G_o - G_t)^2) from the
+//            partial tiles in a fixed order; one finish launch for all ten terms.
 #include <new>
 
 #include "common.h"
@@ -84,6 +85,74 @@ __global__ void __launch_bounds__(256) vgg_conv1_kernel(const float* __restrict_
   }
 }
 
+// The same on the matrix cores: D[channel][pixel] = A[channel][tap] * B[tap][pixel] with K = 9 taps padded to 16
+// (v_mfma_f32_16x16x16_f16, fp32 accumulate; image and summed weights rounded to fp16 - the layer's output is stored in fp16
+// anyway). A wave owns 16 consecutive pixels of an image row; lane (pixel, k-chunk kq) loads taps 4 kq .. 4 kq + 3 from clamped
+// addresses (selects, no divergent branches; the group index is wave-uniform: scalar 32-bit index arithmetic). Channel order per
+// tile as in c1_gather_mfma_kernel: two 16-byte stores per lane, 64 contiguous bytes per pixel and instruction. The VALU form
+// above ran at 2 TB/s of stores (72 FMAs and 9 guarded loads per 16 output bytes); this layer is 537 MB of stores at 512x512.
+__global__ void __launch_bounds__(256) vgg_conv1_mfma_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int n, int H, int W,
+                                                             const float* __restrict__ w1, const float* __restrict__ bias,
+                                                             half_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  h4_t af[4];
+  float br[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int ch = ((mt >> 1) & 1) * 32 + (lr >> 2) * 8 + (mt & 1) * 4 + (lr & 3);     // A row lr of tile mt
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int t = 4 * kq + j; af[mt][j] = t < 9 ? (half_t)w1[ch * 9 + t] : (half_t)0.f; }
+    // D row i = 4 kq + r of tile mt is channel ((mt >> 1) & 1) * 32 + kq * 8 + (mt & 1) * 4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) br[mt][r] = bias[((mt >> 1) & 1) * 32 + kq * 8 + (mt & 1) * 4 + r];
+  }
+  const int gpr = W >> 4;                                   // 16-pixel groups per image row
+  const int ngroups = 2 * n * H * gpr;                      // < 2^31 (host check)
+  const int wave = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const int nwaves = (int)gridDim.x * 4;
+  int dy[4], dx[4];                                         // this lane's taps: (ky, kx) - 1, or far outside for the padding of K
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = 4 * kq + j;
+    dy[j] = t < 9 ? t / 3 - 1 : -(1 << 20);
+    dx[j] = t < 9 ? t % 3 - 1 : 0;
+  }
+  auto load_b = [&](int g, float (&bv)[4]) {
+    const int rowi = g / gpr;                               // wave-uniform
+    const int x = (g - rowi * gpr) * 16 + lr;
+    const int img = rowi / H, y = rowi - img * H;
+    const float* src = img < n ? xa + (int64_t)img * H * W : xb + (int64_t)(img - n) * H * W;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int iy = y + dy[j], ix = x + dx[j];
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float v = src[ok ? iy * W + ix : 0];
+      bv[j] = ok ? v : 0.f;
+    }
+  };
+  float bv[4], bn[4];
+  int g = wave;
+  if (g < ngroups) load_b(g, bv);
+  for (; g < ngroups; g += nwaves) {
+    if (g + nwaves < ngroups) load_b(g + nwaves, bn);
+    const h4_t bf = {(half_t)bv[0], (half_t)bv[1], (half_t)bv[2], (half_t)bv[3]};
+    h8_t o[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      f4_t acc = {br[mt][0], br[mt][1], br[mt][2], br[mt][3]};
+      acc = __builtin_amdgcn_mfma_f32_16x16x16f16(af[mt], bf, acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[mt >> 1][(mt & 1) * 4 + r] = (half_t)fmaxf(acc[r], 0.f);
+    }
+    half_t* dst = out + ((int64_t)g * 16 + lr) * 64;
+    *(h8_t*)(dst + kq * 8) = o[0];
+    *(h8_t*)(dst + 32 + kq * 8) = o[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = bn[j];
+  }
+}
+
 // NHWC fp16 2x2 / stride 2 max pooling, 8 channels per thread
 __global__ void __launch_bounds__(256) maxpool2_kernel(const half_t* __restrict__ in, half_t* __restrict__ out, int nimg, int Ho, int Wo,
                                                        int C) {
@@ -103,61 +172,83 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const half_t* __restrict_
   }
 }
 
-// ---- Gram: G[img][c1][c2] += scale * sum_p F[img][p][c1] * F[img][p][c2] --------------------------------
-struct GramP {
-  const char* F;     // [nimg][HW][C] fp16
-  float* G;          // [nimg][C][C]
-  int C, HW, tiles_per_split;
-  float scale;
+__device__ __forceinline__ double blk_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+// ---- Gram + perceptual term in one pass over a tap's feature maps (deterministic) ------------------------------------------------
+// A workgroup owns one (c1 block, c2 block) tile of the Gram matrix (blocks of BLK = 2 WT channels, c1 block <= c2 block: the matrix
+// is symmetric), one pixel range (split) and one image PAIR (output image i, target image i + n): per 32-pixel step it stages the
+// 32 x BLK slices of both images (one slice on diagonal tiles), multiplies both Grams on the matrix cores (four waves, WT x WT each,
+// transposing LDS reads as in the kernel above) and - on diagonal tiles, where every channel slice passes exactly once - adds up
+// (F_o - F_t)^2 from the staging registers. Partial Grams go to P[pair][o|t][tile][split][BLK*BLK] with plain stores;
+// gram2_diff_kernel adds the splits in a fixed order and reduces (G_o - G_t)^2 (off-diagonal tiles count twice). No atomics, no
+// memset, the feature maps are read C / BLK (+1) / 2 times instead of 2 C / 64 times + once more for the perceptual term.
+struct Gram2P {
+  const char* F;      // [2n][HW][C] fp16
+  float* P;           // partial Grams
+  double* sq;         // [pairs][nblk][split] partial sums of (F_o - F_t)^2
+  int C, HW, n, nblk, ntile, split, steps_per_split;
 };
-// 64 x 64 output tile, K tile = 64 pixels, 4 waves as 2x2 of 32x32
-__global__ void __launch_bounds__(256) gram_kernel(GramP p) {
-  constexpr int LROW = 128 + 32;       // 64 channels of fp16 + 32 B pad (conflict-free transposing reads)
-  constexpr int OPB = 64 * LROW;
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * OPB];
+template <int WT>
+__global__ void __launch_bounds__(256) gram2_kernel(Gram2P p) {
+  constexpr int BLK = 2 * WT, ROWB = BLK * 2, LROW = ROWB + 32, SL = 32 * LROW;   // one staged slice: 32 pixels
+  constexpr int CPR = ROWB / 16, RPP = 256 / CPR, NL = 32 / RPP;                  // 16-byte chunks per row, rows per pass, passes
+  constexpr int MT = WT / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];                     // [2 stages][o c1, o c2, t c1, t c2][SL]
+  __shared__ double shd[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ct = p.C / 64;
-  const int c1 = (blockIdx.x / ct) * 64, c2 = (blockIdx.x % ct) * 64;
-  const int img = blockIdx.z;
-  const char* F = p.F + (int64_t)img * p.HW * p.C * 2;
-  const int t_total = (p.HW + 63) / 64;
-  const int t_begin = blockIdx.y * p.tiles_per_split;
-  const int t_end = min(t_total, t_begin + p.tiles_per_split);
-  const int chunk = tid & 7, rbase = tid >> 3;   // 8 chunks of 16 B per 64-channel row, 32 rows per pass
-
-  u4_t ra[2], rb[2];
-  auto gload = [&](int t) {
+  int bi = 0, bj = 0;
+  { int t = blockIdx.x; for (bi = 0; t >= p.nblk - bi; ++bi) t -= p.nblk - bi; bj = bi + t; }   // tile index -> (bi <= bj)
+  const bool diag = bi == bj;
+  const int pair = blockIdx.z, sp = blockIdx.y;
+  const char* Fo = p.F + (int64_t)pair * p.HW * p.C * 2;
+  const char* Ft = p.F + (int64_t)(pair + p.n) * p.HW * p.C * 2;
+  const int steps = (p.HW + 31) / 32;
+  const int s0 = sp * p.steps_per_split, s1 = min(steps, s0 + p.steps_per_split);
+  const int chunk = tid % CPR, rbase = tid / CPR;
+  u4_t r[4][NL];      // [o c1, o c2, t c1, t c2]
+  auto gload = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int pix = t * 64 + rbase + 32 * i;
-      u4_t va = u4_t{0u, 0u, 0u, 0u}, vb = u4_t{0u, 0u, 0u, 0u};
-      if (pix < p.HW) {
-        va = *(const u4_t*)(F + ((int64_t)pix * p.C + c1 + chunk * 8) * 2);
-        vb = *(const u4_t*)(F + ((int64_t)pix * p.C + c2 + chunk * 8) * 2);
-      }
-      ra[i] = va;
-      rb[i] = vb;
+    for (int i = 0; i < NL; ++i) {
+      const int pix = st * 32 + rbase + RPP * i;
+      const bool ok = pix < p.HW;
+      const int64_t o1 = ((int64_t)pix * p.C + bi * BLK + chunk * 8) * 2, o2 = ((int64_t)pix * p.C + bj * BLK + chunk * 8) * 2;
+      const u4_t z = u4_t{0u, 0u, 0u, 0u};
+      r[0][i] = ok ? *(const u4_t*)(Fo + o1) : z;
+      r[2][i] = ok ? *(const u4_t*)(Ft + o1) : z;
+      if (!diag) { r[1][i] = ok ? *(const u4_t*)(Fo + o2) : z; r[3][i] = ok ? *(const u4_t*)(Ft + o2) : z; }
     }
   };
+  float sq = 0.f;
   auto lds_store = [&](int stage) {
-    char* sA = smem + stage * 2 * OPB;
-    char* sB = sA + OPB;
+    char* base = smem + stage * 4 * SL;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = rbase + 32 * i;
-      *(u4_t*)(sA + r * LROW + chunk * 16) = ra[i];
-      *(u4_t*)(sB + r * LROW + chunk * 16) = rb[i];
+    for (int i = 0; i < NL; ++i) {
+      const int off = (rbase + RPP * i) * LROW + chunk * 16;
+      *(u4_t*)(base + 0 * SL + off) = r[0][i];
+      *(u4_t*)(base + 2 * SL + off) = r[2][i];
+      if (!diag) { *(u4_t*)(base + 1 * SL + off) = r[1][i]; *(u4_t*)(base + 3 * SL + off) = r[3][i]; }
+      else {
+        const h8_t a = __builtin_bit_cast(h8_t, r[0][i]), b = __builtin_bit_cast(h8_t, r[2][i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)a[e] - (float)b[e]; sq = fmaf(d, d, sq); }
+      }
     }
   };
-  f4_t acc[2][2];
+  f4_t acc[2][MT][MT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
-
-  auto frag = [&](const char* base, int ch) -> h8_t {
-    // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(channel) block (see wgrad.hip)
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[q][i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  auto frag = [&](const char* base, int ch) -> h8_t {      // 32 (k = pixels) x 16 (channels ch ..) as an MFMA operand
     const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3;
     const char* lo_p = base + (8 * g + q) * LROW + (ch + 4 * pp) * 2;
     const char* hi_p = base + (8 * g + 4 + q) * LROW + (ch + 4 * pp) * 2;
@@ -167,94 +258,113 @@ __global__ void __launch_bounds__(256) gram_kernel(GramP p) {
     return h8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
   };
   auto compute = [&](int stage) {
-    const char* sA = smem + stage * 2 * OPB;
-    const char* sB = sA + OPB;
+    const char* base = smem + stage * 4 * SL;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      h8_t af[2], bf[2];
+    for (int q = 0; q < 2; ++q) {       // output image, target image
+      const char* sA = base + (2 * q) * SL;
+      const char* sB = diag ? sA : sA + SL;
+      h8_t af[MT], bf[MT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) af[mt] = frag(sA + ks * 32 * LROW, wm * 32 + mt * 16);
+      for (int mt = 0; mt < MT; ++mt) af[mt] = frag(sA, wm * WT + mt * 16);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) bf[nt] = frag(sB + ks * 32 * LROW, wn * 32 + nt * 16);
+      for (int nt = 0; nt < MT; ++nt) bf[nt] = frag(sB, wn * WT + nt * 16);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < MT; ++nt) acc[q][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[q][mt][nt], 0, 0, 0);
     }
   };
-  if (t_begin < t_end) {
-    gload(t_begin);
+  // (a second register set holding step st + 2 while st + 1 waits was measured slower: 54 -> 87 us average on the 128-channel taps)
+  if (s0 < s1) {
+    gload(s0);
     lds_store(0);
     __syncthreads();
     int stage = 0;
-    for (int t = t_begin; t < t_end; ++t) {
-      const bool more = t + 1 < t_end;
-      if (more) gload(t + 1);
+    for (int st = s0; st < s1; ++st) {
+      const bool more = st + 1 < s1;
+      if (more) gload(st + 1);
       compute(stage);
       if (more) lds_store(stage ^ 1);
       __syncthreads();
       stage ^= 1;
     }
-    float* G = p.G + (int64_t)img * p.C * p.C;
+  }
+  // partial Grams: P[((pair * 2 + q) * ntile + tile) * split + sp][BLK][BLK]
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+  for (int q = 0; q < 2; ++q) {
+    float* P = p.P + ((((int64_t)pair * 2 + q) * p.ntile + blockIdx.x) * p.split + sp) * (BLK * BLK);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = c1 + wm * 32 + mt * 16 + (lane >> 4) * 4 + r;
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int col = c2 + wn * 32 + nt * 16 + (lane & 15);
-          atomicAdd(G + (int64_t)row * p.C + col, acc[mt][nt][r] * p.scale);
-        }
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = wm * WT + mt * 16 + (lane >> 4) * 4 + rr;
+#pragma unroll
+        for (int nt = 0; nt < MT; ++nt) P[row * BLK + wn * WT + nt * 16 + (lane & 15)] = acc[q][mt][nt][rr];
       }
   }
-}
-
-__device__ __forceinline__ double blk_sum(double v, double* sh) {
+  if (diag) {
+    double s = (double)sq;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-  __syncthreads();
-  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) shd[wave] = s;
+    __syncthreads();
+    if (tid == 0) p.sq[((int64_t)pair * p.nblk + bi) * p.split + sp] = (shd[0] + shd[1]) + (shd[2] + shd[3]);
+  }
 }
-// partial[b] = sum over the first `half` elements of (a[i] - a[i + half])^2
-template <typename T>
-__global__ void __launch_bounds__(256) sqdiff_halves_kernel(const T* __restrict__ a, int64_t half, double* __restrict__ partial) {
+// partial[block] = sum over the block's groups of 64 Gram elements (grid-stride) of w * ((sum_s P_o - sum_s P_t) * scale)^2: thread
+// (element, part) adds a quarter of the splits (contiguous range, ascending), the four parts are added in ascending order; w = 2 on
+// off-diagonal tiles (their mirror images are never computed). bb = BLK * BLK is a multiple of 64: a group lies inside one tile.
+__global__ void __launch_bounds__(256) gram2_diff_kernel(const float* __restrict__ P, int n, int nblk, int ntile, int split, int bb,
+                                                         float scale, double* __restrict__ partial) {
+  __shared__ float red[2][3][64];
   __shared__ double sh[4];
+  const int e64 = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int64_t per_pair = (int64_t)ntile * bb;
+  const int64_t groups = (int64_t)n * per_pair / 64;
+  const int per = (split + 3) / 4, k0 = part * per, k1 = min(split, k0 + per);
   double s = 0.0;
-  if constexpr (std::is_same<T, half_t>::value) {
-    const int64_t n8 = half / 8;   // half is a multiple of 8 (channels >= 64)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-      const h8_t x = *(const h8_t*)(a + i * 8), y = *(const h8_t*)(a + half + i * 8);
-      float acc = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = (float)x[e] - (float)y[e]; acc = fmaf(d, d, acc); }
-      s += (double)acc;
-    }
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < half; i += (int64_t)gridDim.x * 256) {
-      const float d = a[i] - a[i + half];
-      s += (double)d * d;
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+    const int64_t i = g * 64 + e64;
+    const int pair = (int)(i / per_pair);
+    const int64_t rem = i - (int64_t)pair * per_pair;
+    const int tile = (int)(rem / bb), e = (int)(rem - (int64_t)tile * bb);
+    const float* po = P + ((((int64_t)pair * 2 + 0) * ntile + tile) * split) * bb + e;
+    const float* pt = P + ((((int64_t)pair * 2 + 1) * ntile + tile) * split) * bb + e;
+    float go = 0.f, gt = 0.f;
+    for (int k = k0; k < k1; ++k) { go += po[(int64_t)k * bb]; gt += pt[(int64_t)k * bb]; }
+    __syncthreads();                 // the previous group's sums have been read
+    if (part > 0) { red[0][part - 1][e64] = go; red[1][part - 1][e64] = gt; }
+    __syncthreads();
+    if (part == 0) {
+      go = ((go + red[0][0][e64]) + red[0][1][e64]) + red[0][2][e64];
+      gt = ((gt + red[1][0][e64]) + red[1][1][e64]) + red[1][2][e64];
+      int t = tile, bi = 0;
+      for (; t >= nblk - bi; ++bi) t -= nblk - bi;
+      const double d = (double)(go * scale) - (double)(gt * scale);
+      s += (t == 0 ? 1.0 : 2.0) * d * d;
     }
   }
   s = blk_sum(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-__global__ void __launch_bounds__(256) sqdiff_final_kernel(const double* __restrict__ partial, int nb, double inv_count, float* __restrict__ out) {
+struct VggFinP { int nb[10]; double inv[10]; };
+// per_tap[k] = inv[k] * sum of the nb[k] partials of term k (ascending), then out2 = (wp * sum of the 5 perceptual terms, ws * sum of the 5 style terms)
+__global__ void __launch_bounds__(256) vgg_finish_kernel(const double* __restrict__ partial, VggFinP f, float* __restrict__ per_tap, float wp, float ws,
+                                                         float* __restrict__ out2) {
   __shared__ double sh[4];
-  double s = 0.0;
-  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
-  s = blk_sum(s, sh);
-  if (threadIdx.x == 0) out[0] = (float)(s * inv_count);
-}
-// out2[0] = wp * sum_t per_tap[t] ; out2[1] = ws * sum_t per_tap[5 + t]   (loss.py:106-115)
-__global__ void vgg_combine_kernel(const float* __restrict__ per_tap, float wp, float ws, float* __restrict__ out2) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    float p = 0.f, s = 0.f;
-    for (int t = 0; t < 5; ++t) { p += per_tap[t]; s += per_tap[5 + t]; }
-    out2[0] = wp * p;
-    out2[1] = ws * s;
+  __shared__ float terms[10];
+  for (int k = 0; k < 10; ++k) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < f.nb[k]; i += 256) s += partial[k * 1024 + i];
+    s = blk_sum(s, sh);
+    if (threadIdx.x == 0) { terms[k] = (float)(s * f.inv[k]); per_tap[k] = terms[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float pp = 0.f, ss = 0.f;
+    for (int t = 0; t < 5; ++t) { pp += terms[t]; ss += terms[5 + t]; }
+    out2[0] = wp * pp;
+    out2[1] = ws * ss;
   }
 }
 // NHWC fp16 feature map -> NCHW fp32 (parity / debugging)
@@ -290,8 +400,10 @@ struct gi_vgg {
   half_t* act[2];
   half_t* wpk[NCONV];     // [1..12] packed fp16 weights
   float* w1;              // conv1_1 summed weights [64][9]
-  float* gram;            // [2n][512][512] max
-  double* partial;        // 1024 doubles
+  float* gram;            // partial Gram tiles (gram2_kernel): gram_bytes
+  int64_t gram_bytes;
+  double* partial;        // [10 terms][1024] doubles
+  VggFinP fin;            // per term: partial count and 1 / element count (filled by vgg_run)
   float* per_tap;         // 10 floats
   bool bound, synced;
 };
@@ -307,8 +419,10 @@ int64_t vgg_ws_layout(gi_vgg* v, char* base) {
   v->wpk[0] = nullptr;
   for (int i = 1; i < NCONV; ++i) v->wpk[i] = (half_t*)take((int64_t)kCout[i] * 9 * kCin[i] * 2);
   v->w1 = (float*)take(64 * 9 * 4);
-  v->gram = (float*)take((int64_t)2 * v->max_pairs * 512 * 512 * 4);
-  v->partial = (double*)take(1024 * 8);
+  v->gram_bytes = (int64_t)2 * v->max_pairs * 10 * 65536;          // one split of the widest tap (ten 128 x 128 tiles per image)
+  if (v->gram_bytes < (32ll << 20)) v->gram_bytes = 32ll << 20;
+  v->gram = (float*)take(v->gram_bytes);
+  v->partial = (double*)take(10 * 1024 * 8);
   v->per_tap = (float*)take(64);
   return off;
 }
@@ -317,10 +431,15 @@ int vgg_run(gi_vgg* v, const float* xa, const float* xb, int n, int stop_tap, fl
   hipStream_t st = v->ctx->stream;
   const int nimg = 2 * n;
   int H = v->H, W = v->W, cur = 0;
-  hipLaunchKernelGGL(vgg_conv1_kernel, dim3(nblk((int64_t)nimg * H * W, 32, 256 * 16)), dim3(256), 0, st, xa, xb, n, H, W, v->w1,
-                     v->params + v->boff[0], v->act[0]);
+  if (W % 16 == 0 && (int64_t)nimg * H * (W / 16) < (1ll << 31))
+    hipLaunchKernelGGL(vgg_conv1_mfma_kernel, dim3(nblk((int64_t)nimg * H * (W / 16), 4, 256 * 8)), dim3(256), 0, st, xa, xb, n, H, W, v->w1,
+                       v->params + v->boff[0], v->act[0]);
+  else
+    hipLaunchKernelGGL(vgg_conv1_kernel, dim3(nblk((int64_t)nimg * H * W, 32, 256 * 16)), dim3(256), 0, st, xa, xb, n, H, W, v->w1,
+                       v->params + v->boff[0], v->act[0]);
   GI_LAUNCH_CHECK();
   for (int i = 0; i < NCONV; ++i) {
+    bool pooled = false;
     if (i > 0) {
       IgemmArgs a = {};
       a.in = v->act[cur]; a.w = v->wpk[i]; a.out = v->act[cur ^ 1];
@@ -329,8 +448,12 @@ int vgg_run(gi_vgg* v, const float* xa, const float* xb, int n, int stop_tap, fl
       a.cin = kCin[i]; a.ldin = kCin[i]; a.coffin = 0;
       a.cout = kCout[i]; a.ldout = kCout[i]; a.coffout = 0;
       a.relu_in = 0; a.relu_cend = 0; a.act_out = GI_ACT_RELU; a.force_splitk = 0;
+      // the pooled layers (conv1_2, conv2_2, conv3_4, conv4_4) are never taps: where the kernel can, it stores the 2x2 max pool of
+      // its tile and the full-resolution map is never written
+      a.pool2 = (kPoolAfter[i] && kTapAfter[i] < 0) ? 1 : 0;
       GI_TRY(op_igemm3(st, 2, a));
       cur ^= 1;
+      pooled = a.pool_applied != 0;
     }
     const int C = kCout[i];
     const int tap = kTapAfter[i];
@@ -343,36 +466,43 @@ int vgg_run(gi_vgg* v, const float* xa, const float* xb, int n, int stop_tap, fl
         return GI_OK;
       }
       if (!feat_out) {
-        // perceptual term: mean over (n, C, H, W) of (F_o - F_t)^2
-        const int64_t half = (int64_t)n * HW * C;
-        const int nb = nblk(half / 8, 256 * 4, 1024);
-        hipLaunchKernelGGL(sqdiff_halves_kernel<half_t>, dim3(nb), dim3(256), 0, st, F, half, v->partial);
-        GI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sqdiff_final_kernel, dim3(1), dim3(256), 0, st, v->partial, nb, 1.0 / (double)half, v->per_tap + tap);
-        GI_LAUNCH_CHECK();
-        // style term: Gram matrices of all 2n images, then mean over (n, C, C) of (G_o - G_t)^2
-        GI_HIP(hipMemsetAsync(v->gram, 0, (size_t)nimg * C * C * 4, st));
-        GramP gp;
-        gp.F = (const char*)F; gp.G = v->gram; gp.C = C; gp.HW = (int)HW;
-        gp.scale = (float)(1.0 / ((double)HW * C));
-        const int tiles = (C / 64) * (C / 64) * nimg;
-        const int ktiles = (int)((HW + 63) / 64);
-        int split = (1024 + tiles - 1) / tiles;
-        if (split > ktiles / 8) split = ktiles / 8;
+        // perceptual term mean over (n, C, H, W) of (F_o - F_t)^2 and style term mean over (n, C, C) of (G_o - G_t)^2, G = F^T F / (HW C):
+        // one pass over the tap's feature maps (gram2_kernel) + the fixed-order reduction of its partial tiles
+        const int BLK = C >= 128 ? 128 : 64, nb_ = C / BLK, ntile = nb_ * (nb_ + 1) / 2;
+        const int steps = (int)((HW + 31) / 32);
+        int split = (512 + n * ntile - 1) / (n * ntile);
+        if (split > steps / 4) split = steps / 4;
+        while (split > 1 && ((int64_t)2 * n * ntile * split * BLK * BLK * 4 > v->gram_bytes || n * nb_ * split > 1024)) --split;
         if (split < 1) split = 1;
-        gp.tiles_per_split = (ktiles + split - 1) / split;
-        split = (ktiles + gp.tiles_per_split - 1) / gp.tiles_per_split;
-        hipLaunchKernelGGL(gram_kernel, dim3((C / 64) * (C / 64), split, nimg), dim3(256), 0, st, gp);
+        GI_REQUIRE((int64_t)2 * n * ntile * split * BLK * BLK * 4 <= v->gram_bytes && n * nb_ * split <= 1024, "vgg19: %d pairs exceed the Gram workspace", n);
+        Gram2P gp;
+        gp.F = (const char*)F; gp.P = v->gram; gp.sq = v->partial + tap * 1024;
+        gp.C = C; gp.HW = (int)HW; gp.n = n; gp.nblk = nb_; gp.ntile = ntile;
+        gp.steps_per_split = (steps + split - 1) / split;
+        split = (steps + gp.steps_per_split - 1) / gp.steps_per_split;
+        gp.split = split;
+        if (BLK == 128) {
+          static bool attr = false;
+          if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)gram2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 288)); attr = true; }
+          hipLaunchKernelGGL(gram2_kernel<64>, dim3(ntile, split, n), dim3(256), 2 * 4 * 32 * 288, st, gp);
+        } else {
+          hipLaunchKernelGGL(gram2_kernel<32>, dim3(ntile, split, n), dim3(256), 2 * 4 * 32 * 160, st, gp);
+        }
         GI_LAUNCH_CHECK();
-        const int64_t ghalf = (int64_t)n * C * C;
-        const int nb2 = nblk(ghalf, 256 * 4, 1024);
-        hipLaunchKernelGGL(sqdiff_halves_kernel<float>, dim3(nb2), dim3(256), 0, st, (const float*)v->gram, ghalf, v->partial);
+        v->fin.nb[tap] = n * nb_ * split;
+        v->fin.inv[tap] = 1.0 / (double)((int64_t)n * HW * C);
+        const int nb2 = nblk((int64_t)n * ntile * BLK * BLK / 64, 1, 1024);
+        hipLaunchKernelGGL(gram2_diff_kernel, dim3(nb2), dim3(256), 0, st, (const float*)v->gram, n, nb_, ntile, split, BLK * BLK,
+                           (float)(1.0 / ((double)HW * C)), v->partial + (5 + tap) * 1024);
         GI_LAUNCH_CHECK();
-        hipLaunchKernelGGL(sqdiff_final_kernel, dim3(1), dim3(256), 0, st, v->partial, nb2, 1.0 / (double)ghalf, v->per_tap + 5 + tap);
-        GI_LAUNCH_CHECK();
+        v->fin.nb[5 + tap] = nb2;
+        v->fin.inv[5 + tap] = 1.0 / (double)((int64_t)n * C * C);
       }
     }
-    if (kPoolAfter[i]) {
+    if (kPoolAfter[i] && pooled) {
+      H /= 2;
+      W /= 2;
+    } else if (kPoolAfter[i]) {
       hipLaunchKernelGGL(maxpool2_kernel, dim3(nblk((int64_t)nimg * (H / 2) * (W / 2) * (C / 8), 256, 8192)), dim3(256), 0, st, v->act[cur],
                          v->act[cur ^ 1], nimg, H / 2, W / 2, C);
       GI_LAUNCH_CHECK();
@@ -451,7 +581,7 @@ int gi_vgg19_perceptual_style(gi_vgg* v, const float* output, const float* targe
   GI_REQUIRE(v && v->bound && v->synced, "vgg19_perceptual_style: bind + sync_weights first");
   GI_REQUIRE(output && target && out2 && n > 0 && n <= v->max_pairs, "vgg19_perceptual_style: n=%d (max %d)", n, v->max_pairs);
   GI_TRY(vgg_run(v, output, target, n, -1, nullptr));
-  hipLaunchKernelGGL(vgg_combine_kernel, dim3(1), dim3(64), 0, v->ctx->stream, v->per_tap, weight_p, weight_s, out2);
+  hipLaunchKernelGGL(vgg_finish_kernel, dim3(1), dim3(256), 0, v->ctx->stream, (const double*)v->partial, v->fin, v->per_tap, weight_p, weight_s, out2);
   GI_LAUNCH_CHECK();
   if (per_tap10) GI_HIP(hipMemcpyAsync(per_tap10, v->per_tap, 10 * sizeof(float), hipMemcpyDeviceToDevice, v->ctx->stream));
   return GI_OK;
