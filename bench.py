@@ -337,7 +337,7 @@ def vgg_workload(args, dev):
             "config": {"workload": "perceptual_and_style_loss 512x512, 8 pairs (wgan_perceptual_style_faceparsing.py:216), random-init VGG-19"},
             "roofline": {"bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                          "frac": flop / (ms * 1e-3) / 1e12 / PEAK_F16_TFLOPS, "traffic": None,
-                         "note": "whole call (13 convolutions + pools + 5 Gram GEMMs + reductions), conv FLOP only"},
+                         "note": "whole call (13 convolutions with the pools in their epilogues + 5 Gram / perceptual passes + reductions), conv FLOP only"},
             "losses": {"perceptual": float(r[0]), "style": float(r[1])}}
 
 
