@@ -226,7 +226,7 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
 // reads, 8 no ReLU on the fragments, 16 no per-step barrier, 32 no epilogue
 template <int MODE, bool RELU, int DBG = 0, int BN = 128>
 __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
-  static_assert(BN == 128 || (BN == 64 && MODE == 2), "64-column tiles: the 3x3 mode only (VGG conv1_2)");
+  static_assert(BN == 128 || (BN == 64 && MODE != 3), "64-column tiles: not with both px phases in one tile");
   static_assert(MODE >= 0 && MODE <= 3, "modes 0 (stride-2 gather), 1 (phase), 2 (3x3 / s1), 3 (both px phases)");
   static_assert(!(MODE == 2 && RELU), "the 3x3 mode has no fused input ReLU");
   constexpr bool DUAL = MODE == 3;
@@ -552,6 +552,8 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
 // Launched by op_igemm5 (igemm5.hip) with the kernel arguments it has prepared; grid as igemm6's.
 int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, const KP5& kp, int bn) {
   if (mode == 2 && bn == 64) {      // VGG conv1_2: 64 output channels
+    // (64-column tiles were also measured on the 4-tap layers whose 128-column grid is one workgroup per CU - d3, u4, critic conv4:
+    //  twice the workgroups, two per CU - and ran 6 - 10 % SLOWER than igemm6 there: twice the halo DMA per MAC; not instantiated)
     static bool attr64 = false;
     const int lds64 = 2 * 22528 + 4 * 4096;
     if (!attr64) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<2, false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64)); attr64 = true; }
