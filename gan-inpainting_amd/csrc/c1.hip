@@ -580,7 +580,9 @@ __global__ void __launch_bounds__(256) c1_scatter_kernel(const char* X, const fl
 template <typename T>
 __global__ void __launch_bounds__(256) c1_wgrad_kernel(const char* X, const float* __restrict__ img, float* dW, int n,
                                                        int Hs, int Ws, int c, int ldx, int coffx, int relu_in,
-                                                       float scale, float img_scale, int pix_per_block) {
+                                                       float scale, float img_scale, int pix_per_block, float* __restrict__ part) {
+  // part != null: the block's sums go to part[block][c*16] and c1_wgrad_reduce_kernel adds the blocks in a fixed order (bit-reproducible,
+  // and no queue at the atomic unit: 1024 blocks x 1024 float atomics on the same 64 lines took most of this kernel's 130 us)
   constexpr int EPC = 16 / (int)sizeof(T);
   extern __shared__ float sred[];  // [pl][c][4] per round
   const int LPP = c / EPC;
@@ -638,7 +640,8 @@ __global__ void __launch_bounds__(256) c1_wgrad_kernel(const char* X, const floa
       float s = 0.f;
       for (int k = 0; k < gpb; ++k) s += sred[k * c * 4 + idx];
       const int ch = idx >> 2, q = idx & 3;
-      atomicAdd(dW + ch * 16 + rnd * 4 + q, s * scale);
+      if (part) part[(int64_t)blockIdx.x * (c * 16) + ch * 16 + rnd * 4 + q] = s * scale;
+      else atomicAdd(dW + ch * 16 + rnd * 4 + q, s * scale);
     }
   }
 }
@@ -1391,13 +1394,18 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
   if (ppb < gpb) ppb = gpb;
   const int grid = (int)((total + ppb - 1) / ppb);
   const size_t lds = (size_t)gpb * c * 4 * 4;
+  float* part = (scratch && scratch_floats >= (int64_t)grid * c * 16) ? scratch : nullptr;   // deterministic two-stage sum
   if (dtype == GI_F16)
     hipLaunchKernelGGL(c1_wgrad_kernel<half_t>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, c,
-                       ldx, coffx, relu_in, scale, img_scale, ppb);
+                       ldx, coffx, relu_in, scale, img_scale, ppb, part);
   else
     hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(grid), dim3(256), lds, st, (const char*)X, img, dW, n, Hs, Ws, c, ldx,
-                       coffx, relu_in, scale, img_scale, ppb);
+                       coffx, relu_in, scale, img_scale, ppb, part);
   GI_LAUNCH_CHECK();
+  if (part) {
+    hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((c * 16 + 15) / 16), dim3(256), 0, st, (const float*)part, dW, c * 16, grid);
+    GI_LAUNCH_CHECK();
+  }
   return GI_OK;
 }
 

@@ -1325,7 +1325,7 @@ int unet_backward_plain(gi_net* net, int s, const float* dy, float* dx, int need
       hipLaunchKernelGGL(sum_part_kernel, dim3(256), dim3(256), 0, st, G0, npx, (double*)net->shared(net->oPart));
       hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)net->shared(net->oPart), 256, net->grads + net->up[1].bias_off, iLS);
       GI_LAUNCH_CHECK();
-      GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, nullptr));
+      GI_TRY(op_c1_wgrad(st, dt, C(1), G0, net->grads + net->up[1].w_off, n, net->Hk[1], net->Wk[1], c1, c1, 0, 1, iLS, 1.f, nullptr, (float*)net->shared(net->oPart), net->part_floats));
     }
     if (net->out_c == 1) {
       GI_TRY(op_c1_gather(st, dt, G0, net->params + net->up[1].w_off, gC(1), n, net->Hk[1], net->Wk[1], c1, c1, 0, GI_ACT_NONE, 1.f));
@@ -1388,7 +1388,7 @@ int unet_backward_plain(gi_net* net, int s, const float* dy, float* dx, int need
     GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
     if (need_wgrad) {
       GI_TRY(bias_grad(net, net->conv[1], D, pix, c));
-      GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c, 0, 0, iLS, 1.f));
+      GI_TRY(op_c1_wgrad(st, dt, D, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c, 0, 0, iLS, 1.f, nullptr, (float*)net->shared(net->oPart), net->part_floats));
     }
     if (dx) GI_TRY(op_c1_scatter(st, dt, D, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS, net->shared(net->oCol)));
   }
@@ -1603,9 +1603,9 @@ int patchgan_gradient_penalty(gi_net* net, const float* xhat, int n, float lam, 
     GI_TRY(act_bn_bwd(net, s, G2(1, 0), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D2, pix, 64, GI_ACT_LRELU, 1.f, nullptr, 0));
     GI_TRY(act_bn_bwd(net, s, G2(1, 1), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D2 + half, pix, 64, GI_ACT_LRELU, 1.f,
                       nullptr, 0));
-    GI_TRY(op_c1_wgrad(st, dt, D2, vimg, net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, 1.f, 1.f));
+    GI_TRY(op_c1_wgrad(st, dt, D2, vimg, net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, 1.f, 1.f, nullptr, (float*)net->shared(net->oPart), net->part_floats));
     GI_TRY(op_c1_wgrad(st, dt, D2 + half, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0,
-                       1.f, 1.f));
+                       1.f, 1.f, nullptr, (float*)net->shared(net->oPart), net->part_floats));
   }
   return GI_OK;
 }
