@@ -28,7 +28,7 @@ run gfwd rocprofv3 --kernel-trace --output-format csv -d $OUT/gfwd -- python3 $R
 run step_critic rocprofv3 --kernel-trace --output-format csv -d $OUT/step_critic -- python3 $R/tools/step_chain.py 4 critic
 run step_gen rocprofv3 --kernel-trace --output-format csv -d $OUT/step_gen -- python3 $R/tools/step_chain.py 4 gen
 # F. secondary workloads: the plain line (no profiler) and the kernel statistics
-for wl in wgan_gp_128 dual_d_256 config5_512; do
+for wl in wgan_gp_128 dual_d_256 config5_512 vgg_512; do
   run line_$wl python3 $R/bench.py --workload $wl --steps 20 --warmup 5 --preheat 50 --no-cpu-baseline
   run stats_$wl rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 5 --preheat 10 --no-cpu-baseline
 done

@@ -142,7 +142,7 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
     # F. secondary workloads
     out.write("## E. Secondary workloads (plain lines, then kernel statistics)\n\n")
     lines = {}
-    for wl in ("headline", "wgan_gp_128", "dual_d_256", "config5_512"):
+    for wl in ("headline", "wgan_gp_128", "dual_d_256", "config5_512", "vgg_512"):
         f = f"{src}/line_{wl}.log"
         if os.path.exists(f):
             j = last_json(f)
@@ -151,7 +151,7 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
                 out.write(f"* `{wl}`: **{j['value']:.0f} {j['unit']}**, {j['ms_per_step']:.3f} ms/step ({j['config']['workload'][:110]})\n")
     out.write("\n")
     json.dump(lines, open(f"profiles/{tag}_bench_lines.json", "w"), indent=1)
-    for wl in ("wgan_gp_128", "dual_d_256", "config5_512"):
+    for wl in ("wgan_gp_128", "dual_d_256", "config5_512", "vgg_512"):
         p = newest(f"{src}/stats_{wl}/*/*_kernel_stats.csv")
         if p:
             stats_table(p, f"E.{wl}: `python bench.py --workload {wl} --steps 10 --warmup 5 --preheat 10 --no-cpu-baseline`", out, 16)
