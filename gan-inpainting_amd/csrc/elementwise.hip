@@ -1189,10 +1189,24 @@ __global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n,
 // guard (may be null): guard[1] != 0 means "the gradients of this update hold inf/NaN" (gi_check_finite): skip it whole
 // omb1 / omb2 / step_size: 1 - beta1, 1 - beta2 and lr / bias_correction1 are formed in double on the host and rounded once,
 // as torch.optim does with its Python floats (1.f - 0.999f differs from float(1 - 0.999) by 1e-4 relative)
+// seen >= 0 (with a guard): the host's step count still includes the updates skipped since its last poll (guard[0] - seen of them):
+// the bias corrections are formed here from step - (guard[0] - seen), in double by one thread, so a skipped update never advances them
 __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t count, float step_size,
                                                    float b1, float b2, float eps, float omb1, float omb2, float sqrt_bc2, float gs,
-                                                   const int* guard) {
+                                                   const int* guard, int step, int seen, double lrd, double b1d, double b2d) {
   if (guard && guard[1]) return;
+  if (guard && seen >= 0) {
+    __shared__ float s_ss, s_sq;
+    if (threadIdx.x == 0) {
+      int st = step - (guard[0] - seen);
+      if (st < 1) st = 1;
+      s_ss = (float)(lrd / (1.0 - pow(b1d, (double)st)));
+      s_sq = (float)sqrt(1.0 - pow(b2d, (double)st));
+    }
+    __syncthreads();
+    step_size = s_ss;
+    sqrt_bc2 = s_sq;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const float gg = g[i] * gs;
     const float mm = b1 * m[i] + omb1 * gg;
@@ -1826,6 +1840,10 @@ int gi_adam_step(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int6
 }
 int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                          float eps, int step, float grad_scale, const int* guard) {
+  return gi_adam_step_guarded2(ctx, p, g, m, v, count, lr, beta1, beta2, eps, step, -1, grad_scale, guard);
+}
+int gi_adam_step_guarded2(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                          float eps, int step, int skipped_seen, float grad_scale, const int* guard) {
   GI_REQUIRE(step >= 1, "adam: step=%d must be >= 1", step);
   // torch.optim forms 1 - beta and lr / bias_correction1 from Python floats (doubles) and rounds once. The hyper-parameters
   // arrive here as C floats (0.999f = 0.99900001...): recover the decimal the caller wrote (7 significant digits) first
@@ -1833,7 +1851,7 @@ int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float*
   const double b1 = py(beta1), b2 = py(beta2), lrd = py(lr);
   const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, m, v, count, (float)(lrd / bc1), beta1, beta2, eps,
-                     (float)(1.0 - b1), (float)(1.0 - b2), (float)sqrt(bc2), grad_scale, guard);
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)sqrt(bc2), grad_scale, guard, step, guard ? skipped_seen : -1, lrd, b1, b2);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

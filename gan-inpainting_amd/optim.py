@@ -81,14 +81,16 @@ class Adam(_FlatOptimizer):
         guard = self._guard_ptr()
         for n, st in zip(self.nets, self.state):
             p, g = n.flat_params(), n.flat_grads()
-            B.check(lib.gi_adam_step_guarded(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
-                                             self.lr, self.betas[0], self.betas[1], self.eps, self.t, self.grad_scale, guard))
+            # self.t still counts the updates skipped since the last poll_skipped(); the kernel subtracts them (device count - _seen)
+            B.check(lib.gi_adam_step_guarded2(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
+                                              self.lr, self.betas[0], self.betas[1], self.eps, self.t, self._seen if guard else -1,
+                                              self.grad_scale, guard))
         self._done()
 
     def poll_skipped(self):
         new = super().poll_skipped()
-        self.t -= new     # one per skipped UPDATE (shared verdict): skipped updates do not advance the bias correction
-        #                   (applied when the host learns of them, i.e. at the plugins' logging cadence)
+        self.t -= new     # one per skipped UPDATE (shared verdict): skipped updates do not advance the bias correction (the kernel
+        #                   already left them out - device count minus _seen - so nothing changes for the updates in between)
         return new
 
 

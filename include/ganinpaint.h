@@ -239,6 +239,11 @@ int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3)
 int gi_check_finite_finish(gi_ctx* ctx, int* flag3);
 int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
                          float beta1, float beta2, float eps, int step, float grad_scale, const int* guard);
+/* skipped_seen >= 0: `step` counts every call since the start minus the skipped updates the host has already learned of
+ * (skipped_seen of them, read back from guard[0] at its own cadence); the kernel subtracts the rest, guard[0] - skipped_seen,
+ * before it forms the bias corrections, so a skipped update never advances them whenever the host polls. < 0: `step` as is. */
+int gi_adam_step_guarded2(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
+                          float beta1, float beta2, float eps, int step, int skipped_seen, float grad_scale, const int* guard);
 int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr,
                             float alpha, float eps, float clamp, float grad_scale, const int* guard);
 /* mean(|g|) of `nseg` segments [off[i], off[i]+len[i]) of g -> out[i]

@@ -159,6 +159,38 @@ def test_optimizer_objects_on_a_network_vs_torch_optim():
             assert e <= 1e-6 * float(q.detach().abs().max()) + 1e-9, (kind, name, e)
 
 
+def test_adam_skipped_update_never_advances_the_bias_correction():
+    """fp16 networks run the overflow guard: an update whose gradients hold inf is skipped whole. The host counts every step() and
+    learns of skips only when it polls; the kernel forms the bias corrections from the device's own count, so the updates BETWEEN a
+    skip and the next poll equal torch.optim.Adam over the non-skipped gradients (the advisor's off-by-one), and polling changes nothing."""
+    for poll_at in (None, 2):
+        torch.manual_seed(5)
+        D = networks.PatchGANDiscriminator(sigmoid=False, image_size=64, dtype="fp16").cuda()
+        ref = {k: v.detach().cpu().clone().contiguous() for k, v in D.named_parameters()}
+        ps = [torch.nn.Parameter(v) for v in ref.values()]
+        o, t = optim.Adam(D.parameters(), lr=0.0002, betas=(0.5, 0.999)), torch.optim.Adam(ps, lr=0.0002, betas=(0.5, 0.999))
+        assert o.guard
+        gen = torch.Generator().manual_seed(9)
+        for it in range(5):
+            bad = it == 1
+            for (name, p), q in zip(D.named_parameters(), ps):
+                g = torch.randn(q.shape, generator=gen) * 0.01
+                p.grad.copy_(g.cuda())
+                if bad and name.endswith("model.0.weight"):
+                    p.grad.view(-1)[3] = float("inf")
+                q.grad = g.clone()
+            o.step()
+            if not bad:
+                t.step()
+            if poll_at == it:
+                assert o.poll_skipped() == 1
+        assert o.poll_skipped() == (1 if poll_at is None else 0)
+        assert o.t == 4
+        for (name, p), q in zip(D.named_parameters(), ps):
+            e = float((p.detach().cpu() - q.detach()).abs().max())
+            assert e <= 1e-6 * float(q.detach().abs().max()) + 1e-9, (poll_at, name, e)
+
+
 def test_clamp_parameters_is_the_reference_loop():
     """util.clamp_parameters == `for p in net_D.parameters(): p.data.clamp_(-0.01, 0.01)` (wgan_l1.py:151-153), BN affine
     and Linear included; gi_clamp bit-exact."""
