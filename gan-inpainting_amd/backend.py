@@ -46,6 +46,7 @@ PROTOTYPES = {
     "gi_net_set_dropout_seed": (_i, [_vp, _u64]),
     "gi_net_dropout_mask": (_i, [_vp, _i, _i, _vp, _i64]),
     "gi_net_saved_activation": (_i, [_vp, _i, _i, _i, _vp, _i64]),
+    "gi_net_debug_nonzero_tickets": (_i, [_vp, _vp]),
     "gi_net_set_dropout_mask": (_i, [_vp, _i, _i, _vp]),
     "gi_net_forward": (_i, [_vp, _i, _vp, _vp, _i]),
     "gi_net_backward": (_i, [_vp, _i, _vp, _vp, _i]),

@@ -1664,6 +1664,20 @@ __global__ void __launch_bounds__(256) export_act_kernel(const T* __restrict__ s
 }
 }  // namespace
 
+// Debug: the split-K tile tickets of this network (igemm7 / igemm fix-up hand-off) that are NOT zero. Every launch leaves them zero (the
+// last arriver of a tile resets its ticket); a non-zero ticket between launches means a launch was cut short and the next split-K
+// layer would mis-count its arrivals. Synchronises the context's stream.
+extern "C" int gi_net_debug_nonzero_tickets(gi_net* net, int* count) {
+  GI_REQUIRE(net && net->bound && count, "debug_nonzero_tickets: net not bound / null output");
+  *count = 0;
+  if (net->oTickets < 0) return GI_OK;
+  std::vector<unsigned> h(GI_IGEMM_TICKETS);
+  GI_HIP(hipMemcpyAsync(h.data(), net->shared(net->oTickets), (size_t)GI_IGEMM_TICKETS * 4, hipMemcpyDeviceToHost, net->ctx->stream));
+  GI_HIP(hipStreamSynchronize(net->ctx->stream));
+  for (unsigned v : h) *count += v != 0;
+  return GI_OK;
+}
+
 extern "C" int gi_net_saved_activation(gi_net* net, int slot, int kind, int level, float* out_nchw, int64_t count) {
   GI_REQUIRE(net && net->bound && out_nchw, "saved_activation: net not bound / null output");
   GI_REQUIRE(slot >= 0 && slot < net->n_slots && net->slot_n[slot] > 0, "saved_activation: slot %d holds no forward", slot);

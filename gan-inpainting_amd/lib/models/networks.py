@@ -352,6 +352,13 @@ class HipNet(nn.Module):
         B.check(B.lib().gi_net_saved_activation(self._handle, slot, kind, level, B.ptr(out), out.numel()))
         return out
 
+    def nonzero_tickets(self):
+        """Debug: split-K tile tickets that are not zero between launches (gi_net_debug_nonzero_tickets; must be 0)."""
+        import ctypes as C
+        n = C.c_int()
+        B.check(B.lib().gi_net_debug_nonzero_tickets(self._handle, C.byref(n)))
+        return n.value
+
     def forward(self, x):
         if torch.is_grad_enabled() and (self.training or x.requires_grad):
             return _NetFunction.apply(x, self._anchor, self)

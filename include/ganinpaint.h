@@ -147,6 +147,9 @@ int gi_net_set_dropout_mask(gi_net* net, int slot, int level, const uint8_t* mas
  * ReLU(dropout(norm(up_{k+1}(.)))) concatenated beside it (:289, :324). Discriminator, kind 0, level i = 1..4:
  * LeakyReLU(BatchNorm(conv_i(.))) (:335-345). count = N*C*h*w. */
 int gi_net_saved_activation(gi_net* net, int slot, int kind, int level, float* out_nchw, int64_t count);
+/* Debug: number of split-K tile tickets of this network that are not zero between launches (must be 0: every launch leaves
+ * them zero; anything else means a launch was cut short). Synchronises the stream. */
+int gi_net_debug_nonzero_tickets(gi_net* net, int* count);
 
 /* forward: x (n,1,H,W) fp32 -> y: generator (n,1,H,W) fp32, discriminator (n,1) fp32 */
 int gi_net_forward(gi_net* net, int slot, const float* x, float* y, int n);

@@ -238,8 +238,9 @@ def test_unet_forward_and_gradients_are_reproducible(dtype):
     """Split-K layers reduce inside the GEMM kernel (whichever workgroup arrives last adds the splits in split order), the
     BatchNorm statistics go through exact integer accumulators, weight gradients are summed from partial tiles in a fixed order
     (the single-channel layers d1 / u1 and the u1 bias included: c1_wgrad_reduce_kernel, sum_finish_kernel) - so the forward
-    output, the running statistics, the input gradient and, in fp16 (the benchmarked path), EVERY parameter gradient repeat BIT
-    FOR BIT from run to run. (fp32: the VALU form of the single-channel weight gradient still adds with float atomics.)"""
+    output, the running statistics, the input gradient and EVERY parameter gradient repeat BIT FOR BIT from run to run, in fp16 (the
+    benchmarked path) and in fp32 (whose single-channel weight gradient went from float atomics to partial sums in round 3). The
+    split-K tile tickets are all zero again after the backward (gi_net_debug_nonzero_tickets)."""
     nd, N, HW = 7, 3, 128
     P = op.make_unet_params(777, num_downs=nd)
     ground, mask = op.synth_batch(778, N, HW, HW)
@@ -250,6 +251,7 @@ def test_unet_forward_and_gradients_are_reproducible(dtype):
         x = torch.from_numpy(ground * (1 - mask)).cuda().requires_grad_(True)
         y = net(x)
         y.sum().backward()
+        assert net.nonzero_tickets() == 0
         stats = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if "running" in k}
         grads = {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters()}
         runs.append((y.detach().cpu().clone(), x.grad.detach().cpu().clone(), stats, grads))
@@ -259,8 +261,7 @@ def test_unet_forward_and_gradients_are_reproducible(dtype):
         for k in runs[0][2]:
             assert torch.equal(runs[0][2][k], r[2][k]), k
         for k in runs[0][3]:
-            if dtype == "fp16" or k not in ("model.model.0.weight", "model.model.3.weight"):   # (fp32: d1 / u1 weights, see above)
-                assert torch.equal(runs[0][3][k], r[3][k]), f"parameter gradient {k} differs between runs"
+            assert torch.equal(runs[0][3][k], r[3][k]), f"parameter gradient {k} differs between runs"
 
 
 @pytest.mark.parametrize("dtype", ["fp16"])
