@@ -48,49 +48,13 @@ __global__ void __launch_bounds__(256) sum_cin_kernel(const float* __restrict__ 
   w1[i] = s;
 }
 
-// out[img,y,x,0:64] = relu(b + sum_tap w1[.][tap] * x[img, y-1+ky, x-1+kx]); images [0,n) from xa, [n,2n) from xb
-__global__ void __launch_bounds__(256) vgg_conv1_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int n, int H, int W,
-                                                        const float* __restrict__ w1, const float* __restrict__ bias,
-                                                        half_t* __restrict__ out) {
-  const int grp = threadIdx.x & 7;   // 8 channels each: their 72 weights and 8 biases stay in registers
-  float wr[8][9], br[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    br[c] = bias[grp * 8 + c];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) wr[c][k] = w1[(grp * 8 + c) * 9 + k];
-  }
-  const int64_t npix = (int64_t)2 * n * H * W;
-  for (int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += (int64_t)gridDim.x * 32) {
-    const int x = (int)(pix % W);
-    const int64_t t = pix / W;
-    const int y = (int)(t % H);
-    const int img = (int)(t / H);
-    const float* src = (img < n ? xa + (int64_t)img * H * W : xb + (int64_t)(img - n) * H * W);
-    float v[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int iy = y - 1 + k / 3, ix = x - 1 + k % 3;
-      v[k] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? src[(int64_t)iy * W + ix] : 0.f;
-    }
-    h8_t o;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      float s = br[c];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s = fmaf(wr[c][k], v[k], s);
-      o[c] = (half_t)(s > 0.f ? s : 0.f);
-    }
-    *(h8_t*)(out + pix * 64 + grp * 8) = o;
-  }
-}
-
-// The same on the matrix cores: D[channel][pixel] = A[channel][tap] * B[tap][pixel] with K = 9 taps padded to 16
+// out[img,y,x,0:64] = relu(b + sum_tap w1[.][tap] * x[img, y-1+ky, x-1+kx]); images [0,n) from xa, [n,2n) from xb.
+// On the matrix cores: D[channel][pixel] = A[channel][tap] * B[tap][pixel] with K = 9 taps padded to 16
 // (v_mfma_f32_16x16x16_f16, fp32 accumulate; image and summed weights rounded to fp16 - the layer's output is stored in fp16
 // anyway). A wave owns 16 consecutive pixels of an image row; lane (pixel, k-chunk kq) loads taps 4 kq .. 4 kq + 3 from clamped
 // addresses (selects, no divergent branches; the group index is wave-uniform: scalar 32-bit index arithmetic). Channel order per
-// tile as in c1_gather_mfma_kernel: two 16-byte stores per lane, 64 contiguous bytes per pixel and instruction. The VALU form
-// above ran at 2 TB/s of stores (72 FMAs and 9 guarded loads per 16 output bytes); this layer is 537 MB of stores at 512x512.
+// tile as in c1_gather_mfma_kernel: two 16-byte stores per lane, 64 contiguous bytes per pixel and instruction. The VALU form of
+// rounds 1-2 ran at 2 TB/s of stores (72 FMAs and 9 guarded loads per 16 output bytes); this layer is 537 MB of stores at 512x512.
 __global__ void __launch_bounds__(256) vgg_conv1_mfma_kernel(const float* __restrict__ xa, const float* __restrict__ xb, int n, int H, int W,
                                                              const float* __restrict__ w1, const float* __restrict__ bias,
                                                              half_t* __restrict__ out) {
@@ -431,12 +395,9 @@ int vgg_run(gi_vgg* v, const float* xa, const float* xb, int n, int stop_tap, fl
   hipStream_t st = v->ctx->stream;
   const int nimg = 2 * n;
   int H = v->H, W = v->W, cur = 0;
-  if (W % 16 == 0 && (int64_t)nimg * H * (W / 16) < (1ll << 31))
-    hipLaunchKernelGGL(vgg_conv1_mfma_kernel, dim3(nblk((int64_t)nimg * H * (W / 16), 4, 256 * 8)), dim3(256), 0, st, xa, xb, n, H, W, v->w1,
-                       v->params + v->boff[0], v->act[0]);
-  else
-    hipLaunchKernelGGL(vgg_conv1_kernel, dim3(nblk((int64_t)nimg * H * W, 32, 256 * 16)), dim3(256), 0, st, xa, xb, n, H, W, v->w1,
-                       v->params + v->boff[0], v->act[0]);
+  // (W % 16 == 0 and 2 n H W 64 < 2^31 are conditions of gi_vgg19_create)
+  hipLaunchKernelGGL(vgg_conv1_mfma_kernel, dim3(nblk((int64_t)nimg * H * (W / 16), 4, 256 * 8)), dim3(256), 0, st, xa, xb, n, H, W, v->w1,
+                     v->params + v->boff[0], v->act[0]);
   GI_LAUNCH_CHECK();
   for (int i = 0; i < NCONV; ++i) {
     bool pooled = false;
