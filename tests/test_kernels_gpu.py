@@ -38,6 +38,11 @@ CONV_CASES = [
     (5, 2, 2, 512, 512, 2),          # 1x1 output
     (32, 16, 16, 512, 512, 2),       # the generator's d5 at the headline configuration (M = 2048, K = 8192)
     (4, 32, 32, 64, 64, 2),          # 64 output channels: 256 x 64 tiles
+    # rectangular maps (the C-ABI takes H and W separately; the networks of the reference are square)
+    (16, 128, 256, 64, 128, False),  # 64 x 128 output maps, 512 tiles: igemm8's stride-2 gather on 8 x 32 patches
+    (8, 256, 64, 64, 128, False),    # 128 x 32 output maps: 256 tiles (igemm6)
+    (3, 16, 64, 128, 256, 2),        # 8 x 32 maps, split-K
+    (2, 48, 16, 64, 128, False),     # 24 x 8 maps: not a power of two in one direction
 ]
 
 
@@ -99,6 +104,11 @@ CONVT_CASES = [
     (2, 4, 4, 1024, 512, 2),
     (2, 8, 8, 1024, 256, 2),
     (2, 16, 16, 512, 128, 2),
+    # rectangular maps
+    (16, 32, 64, 256, 128, False),  # 512 tiles x 4 phases: igemm8's phase mode on 8 x 32 patches
+    (8, 64, 16, 128, 64, False),    # 64-channel layer: both px phases per workgroup (16-wide patches)
+    (3, 4, 16, 512, 256, 2),        # split-K
+    (2, 24, 8, 128, 128, False),    # 24 rows: not a power of two
     (2, 32, 32, 256, 64, 2),        # 64 output channels: 256 x 64 tiles
     (32, 4, 4, 1024, 512, 2),       # the generator's u6 at the headline configuration
 ]
@@ -132,7 +142,20 @@ WGRAD_CASES = [
     (3, 2, 2, 512, 256, 0),
     (2, 1, 1, 512, 512, 1),
     (4, 32, 32, 128, 64, 0),     # many K tiles -> split over pixel ranges
+    (8, 16, 64, 128, 64, 0),     # rectangular: 4 x 16 pixel tiles of the halo kernels (wgrad3 / wgrad2)
+    (8, 64, 8, 128, 64, 1),      # 8-wide maps: 8 x 8 pixel tiles
+    (2, 32, 8, 256, 128, 0),     # 32 x 8 maps
 ]
+
+
+def test_wgrad_s2_refuses_maps_that_are_not_powers_of_two():
+    """The weight-gradient kernels index pixels with shifts: a 24 x 8 map is refused loudly (the forward / input-gradient GEMMs
+    take it, see the rectangular cases above); the networks of the reference's configurations (128 / 256 / 512 inputs) never hit it."""
+    S = torch.zeros((2, 24, 8, 256), dtype=torch.float16, device="cuda")
+    L = torch.zeros((2, 48, 16, 128), dtype=torch.float16, device="cuda")
+    dW = torch.zeros((256, 4, 4, 128), dtype=torch.float32, device="cuda")
+    with pytest.raises(B.BackendError, match="powers of two"):
+        B.check(B.lib().gi_wgrad_s2(B.get_ctx(), B.GI_F16, B.ptr(S), B.ptr(L), B.ptr(dW), 2, 24, 8, 256, 256, 128, 128, 0, 1.0))
 
 
 @pytest.mark.parametrize("code", [B.GI_F32, B.GI_F16])
