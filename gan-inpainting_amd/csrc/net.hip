@@ -193,8 +193,9 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
                       "unet_create: ngf=%d ch1=%d: every level needs a multiple of 64 channels (ngf a multiple of 64, or of 32 with ch1)", ngf, ch1);
   else GI_REQUIRE(ngf % 8 == 0 && ngf >= 8, "unet_create: ngf=%d must be a multiple of 8 (inventory-only handle)", ngf);
   GI_REQUIRE(out_c >= 1 && out_c <= 64, "unet_create: out_c=%d (1..64)", out_c);
-  GI_REQUIRE(gi_is_pow2(H) && gi_is_pow2(W) && (H >> num_downs) >= 1 && (W >> num_downs) >= 1,
-             "unet_create: H=%d W=%d must be powers of two >= 2^num_downs", H, W);
+  // (powers of two take the halo-resident kernels; other multiples of 2^num_downs - 192, 384 - fall back to the gather kernels)
+  GI_REQUIRE(H >= (1 << num_downs) && W >= (1 << num_downs) && H % (1 << num_downs) == 0 && W % (1 << num_downs) == 0,
+             "unet_create: H=%d W=%d must be multiples of 2^num_downs = %d", H, W, 1 << num_downs);
   GI_REQUIRE(max_n >= 1 && n_slots >= 1 && n_slots <= 8, "unet_create: max_n=%d n_slots=%d", max_n, n_slots);
   gi_net* net = new gi_net();
   net->ctx = ctx; net->kind = 0; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;
@@ -368,7 +369,7 @@ extern "C" int gi_unet_create(gi_ctx* ctx, int num_downs, int ngf, float dropout
 extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int max_n, int dtype, int n_slots, gi_net** out) {
   GI_REQUIRE(out, "patchgan_create: null argument");  // ctx may be null: inventory-only handle
   GI_REQUIRE(dtype == GI_F16 || dtype == GI_F32, "patchgan_create: dtype=%d", dtype);
-  GI_REQUIRE(gi_is_pow2(H) && gi_is_pow2(W) && H >= 64 && W >= 64, "patchgan_create: H=%d W=%d must be powers of two >= 64", H, W);
+  GI_REQUIRE(H >= 64 && W >= 64 && H % 16 == 0 && W % 16 == 0, "patchgan_create: H=%d W=%d must be multiples of 16, >= 64", H, W);
   GI_REQUIRE(max_n >= 1 && n_slots >= 1 && n_slots <= 8, "patchgan_create: max_n=%d n_slots=%d", max_n, n_slots);
   gi_net* net = new gi_net();
   net->ctx = ctx; net->kind = 1; net->dtype = dtype; net->H = H; net->W = W; net->max_n = max_n; net->n_slots = n_slots;

@@ -22,7 +22,7 @@ struct WP {
   float* part;       // non-null: split ks writes its tile to part[ks][ca][16*cb] with plain stores (no atomics)
   int direct;        // 1: a single split owns every output element: dW += acc without atomics
   int P;             // pixels = n*Hs*Ws
-  int lgWs, lgHs;    // Hs, Ws powers of two
+  int lgWs, lgHs;    // log2 of Ws, Hs when both are powers of two, else -1 (divisions in the loader)
   int Hs, Ws, HL, WL;
   int ca, ldS, coffS;
   int cb, lgcb, ldL, coffL;
@@ -89,9 +89,17 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
       u4_t vs = u4_t{0u, 0u, 0u, 0u}, vl = u4_t{0u, 0u, 0u, 0u};
       if (pix < p.P) {
         vs = *(const u4_t*)(p.S + ((int64_t)pix * p.ldS + p.coffS + a0 + chunk * EPC) * (int64_t)sizeof(T));
-        const int x = pix & (p.Ws - 1);
-        const int y = (pix >> p.lgWs) & (p.Hs - 1);
-        const int n = pix >> (p.lgWs + p.lgHs);
+        int x, y, n;
+        if (p.lgWs >= 0) {
+          x = pix & (p.Ws - 1);
+          y = (pix >> p.lgWs) & (p.Hs - 1);
+          n = pix >> (p.lgWs + p.lgHs);
+        } else {      // maps that are not powers of two (e.g. 192 x 192 inputs): three integer divisions per 16-byte load
+          const int t = pix / p.Ws;
+          x = pix - t * p.Ws;
+          n = t / p.Hs;
+          y = t - n * p.Hs;
+        }
         const int iy = 2 * y - 1 + ky, ix = 2 * x - 1 + kx;
         if (iy >= 0 && iy < p.HL && ix >= 0 && ix < p.WL)
           vl = *(const u4_t*)(p.L + ((int64_t)((n * p.HL + iy) * p.WL + ix) * p.ldL + p.coffL + bch) * (int64_t)sizeof(T));
@@ -260,13 +268,14 @@ int run(hipStream_t st, const WgradArgs& a) {
   constexpr int EPC = 16 / (int)sizeof(T);
   GI_REQUIRE(a.ca % 128 == 0, "wgrad: ca=%d must be a multiple of 128", a.ca);
   GI_REQUIRE(gi_is_pow2(a.cb) && a.cb >= EPC && (16 * a.cb) % 128 == 0, "wgrad: cb=%d must be a power of two >= 8", a.cb);
-  GI_REQUIRE(gi_is_pow2(a.Hs) && gi_is_pow2(a.Ws), "wgrad: Hs=%d Ws=%d must be powers of two", a.Hs, a.Ws);
   GI_REQUIRE(a.ldS % EPC == 0 && a.coffS % EPC == 0 && a.ldL % EPC == 0 && a.coffL % EPC == 0,
              "wgrad: leading dims / channel offsets must be 16-byte aligned");
   WP p;
   p.S = (const char*)a.S; p.L = (const char*)a.L; p.dW = a.dW;
   p.P = a.n * a.Hs * a.Ws;
-  p.Hs = a.Hs; p.Ws = a.Ws; p.lgHs = gi_ilog2(a.Hs); p.lgWs = gi_ilog2(a.Ws);
+  p.Hs = a.Hs; p.Ws = a.Ws;
+  const bool p2 = gi_is_pow2(a.Hs) && gi_is_pow2(a.Ws);
+  p.lgHs = p2 ? gi_ilog2(a.Hs) : -1; p.lgWs = p2 ? gi_ilog2(a.Ws) : -1;
   p.HL = 2 * a.Hs; p.WL = 2 * a.Ws;
   p.ca = a.ca; p.ldS = a.ldS; p.coffS = a.coffS;
   p.cb = a.cb; p.lgcb = gi_ilog2(a.cb); p.ldL = a.ldL; p.coffL = a.coffL;

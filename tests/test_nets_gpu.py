@@ -49,7 +49,7 @@ def make_d(P, HW, sigmoid, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-@pytest.mark.parametrize("cfg", [(6, 2, 64), (7, 2, 128), (7, 1, 256), (7, 2, 512)])   # 512: config 5's size (TW = 32 patch tiles, 256-wide maps)
+@pytest.mark.parametrize("cfg", [(6, 2, 64), (7, 2, 128), (7, 1, 256), (7, 2, 512), (6, 2, 192)])   # 512: config 5's size (TW = 32 patch tiles, 256-wide maps); 192: maps that are not powers of two (gather kernels)
 def test_unet_forward_backward_vs_oracle(dtype, cfg):
     """ONE fixed seed per case, strict on every tensor: forward output and running statistics against the fp32 oracle,
     every parameter gradient and the input gradient against the kink-aware fp64 reference (oracle/kink.py: the oracle
@@ -208,7 +208,7 @@ def test_unet_train_vs_golden_with_imposed_masks(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-@pytest.mark.parametrize("cfg", [(128, 3, True), (128, 3, False), (64, 2, True), (256, 2, False), (512, 2, True)])   # 512: sliced head forward
+@pytest.mark.parametrize("cfg", [(128, 3, True), (128, 3, False), (64, 2, True), (256, 2, False), (512, 2, True), (192, 2, False)])   # 512: sliced head forward; 192: not a power of two
 def test_patchgan_vs_oracle(dtype, cfg):
     """As test_unet_forward_backward_vs_oracle: one seed, strict on every tensor, kink-aware reference."""
     HW, N, sig = cfg
