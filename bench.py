@@ -509,7 +509,7 @@ def main():
                                        "global/local RMSE + frozen face-parsing U-Net (ngf=32, random init) + VGG-19 perceptual/style "
                                        "(random init) + TV; G update every 5th batch"}, "losses": losses,
                 "roofline": roofline_of(dominant_kernel(args.kernel_iters, "fp16", BS, 64), "fp16")}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline("config5_512", full=False)
         print(json.dumps(line))
         return
@@ -520,7 +520,7 @@ def main():
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "wgan_l1 128x128 bs=16 fp32 + WGAN-GP (BASELINE.json configs[1])"}, "losses": losses,
                 "roofline": roofline_of(dominant_kernel(args.kernel_iters, "fp32", BS, 16), "fp32")}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline("wgan_gp_128", full=False)
         print(json.dumps(line))
         return
@@ -598,7 +598,7 @@ def main():
     }
     if args.dtype == "fp16":   # the short-K layer family with the most kernel time of the benchmark, beside the dominant kernel
         out["roofline_short_k"] = roofline_of(critic_conv2_kernel(args.kernel_iters), "fp16")
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # (the CPU restatement is timed at N = 1 only)
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
 
