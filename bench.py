@@ -396,6 +396,7 @@ def main():
     ap.add_argument("--overlap", type=int, default=int(os.environ.get("GI_BENCH_OVERLAP", "1")),
                     help="1: critic on a side HIP stream (trainer.WGANStep overlap=True)")
     ap.add_argument("--kernel-only", action="store_true")
+    ap.add_argument("--short-k", action="store_true", help="with --kernel-only: the critic's conv2 (roofline_short_k) instead of the dominant kernel")
     ap.add_argument("--kernel-iters", type=int, default=50)
     args = ap.parse_args()
 
@@ -440,7 +441,7 @@ def main():
         return
 
     if args.kernel_only:
-        k = dominant_kernel(args.kernel_iters)
+        k = critic_conv2_kernel(args.kernel_iters) if args.short_k else dominant_kernel(args.kernel_iters)
         print(json.dumps(dict(kernel=k["name"], avg_ms=k["ms"], tflops=k["flop"] / k["ms"] / 1e9)))
         return
 
@@ -597,7 +598,16 @@ def main():
         "roofline": roofline_of(k, "fp16" if args.dtype == "fp16" else "fp32", traffic, traffic_src),
     }
     if args.dtype == "fp16":   # the short-K layer family with the most kernel time of the benchmark, beside the dominant kernel
-        out["roofline_short_k"] = roofline_of(critic_conv2_kernel(args.kernel_iters), "fp16")
+        t2, t2_src = None, None
+        tp2 = os.path.join(ROOT, "profiles", "short_k_kernel_traffic.json")
+        if os.path.exists(tp2):
+            try:
+                tj = json.load(open(tp2))
+                t2 = tj.get("hbm_bytes_per_launch")
+                t2_src = f"profiles/short_k_kernel_traffic.json (round {tj.get('round')}, kernel {tj.get('kernel')}, commit {tj.get('commit')})"
+            except Exception:
+                t2 = None
+        out["roofline_short_k"] = roofline_of(critic_conv2_kernel(args.kernel_iters), "fp16", t2, t2_src)
     if not args.no_cpu_baseline and world == 1:   # (the CPU restatement is timed at N = 1 only)
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))

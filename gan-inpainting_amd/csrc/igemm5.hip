@@ -808,7 +808,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   // 256 workgroups, 10 - 16 % slower than igemm6; every layer with >= 512 workgroups 3 - 16 % faster), 2 every eligible layer
   const int use8 = gi_opt(GI_OPT_IGEMM8);
   // (the 3x3 mode: 128-column tiles on 32-wide patches, no fused input ReLU; VGG-19 from conv2_1 to conv4_4)
-  if (use8 && (mode != 2 || (TW == 32 && !a.relu_in)) && (dual || BN == 128 || mode == 2) && a.cin % 32 == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
+  if (use8 && (mode != 2 || (TW == 32 && !a.relu_in)) && (dual || BN == 128 || mode == 2) && a.cin % (mode == 0 ? 64 : 32) == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
       (int64_t)a.cout * (mode == 1 ? 4 : (mode == 2 ? 9 : 16)) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&
       (use8 >= 2 || grid >= gi_tune("GI_IGEMM8_MINGRID", 512))) {
     if (mode == 2 && a.pool2 && !a.mask && !a.stat_acc && !a.partials) {   // the pooled store: igemm8's 3x3 mode only

@@ -416,13 +416,13 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   // One halo group = four steps of straight-line code (igemm6's structure): every step issues the same number of LDS-DMA pieces
   // (beyond the end of the K loop with out-of-range offsets), so the counted waits are immediates. GI = group index modulo 2
   // (modes 1, 3) or 4 (mode 0): halo buffer GI & 1, parity class GI (mode 0).
-  auto group = [&](int c, auto GIc) {
+  // c = sequential group index; Q / QN = parity class of this group / of the next one (MODE 0), chunk / chunk_n their channel chunks
+  auto group = [&](int c, auto GIc, auto Qc, auto QNc, int chunk, int chunk_n) {
     constexpr int GI = decltype(GIc)::value;
-    constexpr int BUF = GI & 1, Q = MODE == 0 ? GI : 0, QN = MODE == 0 ? ((GI + 1) & 3) : 0;
+    constexpr int BUF = GI & 1, Q = decltype(Qc)::value, QN = decltype(QNc)::value;
     constexpr int PAR0 = (MODE == 2) ? (GI & 1) : 0;             // nine taps per group: the fragment-set parity alternates per group
     using QT = std::integral_constant<int, Q>;
     using QNT = std::integral_constant<int, QN>;
-    const int chunk = c / NQ, chunk_n = (c + 1) / NQ;            // channel chunk of this group / of the next one
     const int rmin = rmin_of(chunk);
     const bool next_a = c + 1 < ngroups;
     unsigned va[AJ];                                            // the next group's halo pieces (none after the last group)
@@ -526,11 +526,21 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
   };
 
   if constexpr (MODE == 0) {
-    for (int c = 0; c < ngroups; c += 4) { group(c, I0{}); group(c + 1, I1{}); group(c + 2, I2{}); group(c + 3, I3{}); }
+    // Group order: per PAIR of 32-channel chunks (one 128-byte line of a pixel row with 64-channel granularity) the four parity classes,
+    // each with both chunks back to back. A 64-byte request makes the memory side fetch the whole 128-byte line (measured:
+    // tools/micro/stream_bw.hip, half-line reads run at half the useful bandwidth); with the chunk-major order of the first version the
+    // line's other half was requested 16 steps later, after the line had left L2 - the critic's conv2 read its input 2.2 times.
+    for (int cp = 0; 2 * cp < nchunk; ++cp) {     // nchunk is even (cin % 64 == 0, checked by the host)
+      const int c = cp * 8, a = 2 * cp, b = 2 * cp + 1;
+      group(c + 0, I0{}, I0{}, I0{}, a, b); group(c + 1, I1{}, I0{}, I1{}, b, a);
+      group(c + 2, I0{}, I1{}, I1{}, a, b); group(c + 3, I1{}, I1{}, I2{}, b, a);
+      group(c + 4, I0{}, I2{}, I2{}, a, b); group(c + 5, I1{}, I2{}, I3{}, b, a);
+      group(c + 6, I0{}, I3{}, I3{}, a, b); group(c + 7, I1{}, I3{}, I0{}, b, a + 2);
+    }
   } else {
     int c = 0;
-    for (; c + 1 < ngroups; c += 2) { group(c, I0{}); group(c + 1, I1{}); }
-    if (c < ngroups) group(c, I0{});
+    for (; c + 1 < ngroups; c += 2) { group(c, I0{}, I0{}, I0{}, c, c + 1); group(c + 1, I1{}, I0{}, I0{}, c + 1, c + 2); }
+    if (c < ngroups) group(c, I0{}, I0{}, I0{}, c, c + 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

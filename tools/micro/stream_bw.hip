@@ -59,6 +59,19 @@ __global__ void __launch_bounds__(256) fill_kernel(char* out, long total, unsign
   }
 }
 
+// FETCH_SIZE calibration for 64-byte sector reads: every group of four lanes reads the FIRST (or second) 64 bytes of a 128-byte line and
+// skips the other half; the line's other half is never touched by this launch. If the memory side fetched whole 128-byte lines the pass
+// would move 2x its useful bytes and take as long as reading everything; if it fetches 64-byte sectors it takes half as long.
+__global__ void __launch_bounds__(256) half_line_kernel(const char* a, unsigned* sink, long lines, int half) {
+  const long stride = (long)gridDim.x * 64;       // lines per trip (a thread quad per line)
+  unsigned acc = 0;
+  for (long l = (long)blockIdx.x * 64 + (threadIdx.x >> 2); l < lines; l += stride) {
+    const u4_t v = *(const u4_t*)(a + l * 128 + half * 64 + (threadIdx.x & 3) * 16);
+    acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
 template <int R, int U, bool NT>
 float run(const char* a, const char* b, const char* c, char* out, long total, int cpp, int ldf, int blocks, int iters) {
   hipEvent_t e0, e1;
@@ -81,6 +94,37 @@ int main(int argc, char** argv) {
   hipMemset(a, 1, 2 * bytes); hipMemset(b, 2, bytes); hipMemset(c, 3, bytes); hipMemset(o, 0, bytes);
   // a spacer buffer the passes alternate with, so that nothing survives in the 256 MiB Infinity Cache between iterations
   printf("stream %ld MiB per tensor; columns: R reads + 1 write, U chunks in flight, blocks/CU, layout, policy -> us, GB/s total\n", mb);
+  {   // half-line reads over a buffer far larger than the caches (1 GiB): useful bytes = 512 MiB per pass
+    const long big = 1l << 30;
+    char* g; unsigned* sink;
+    hipMalloc(&g, big); hipMalloc(&sink, 64);
+    hipMemset(g, 1, big);
+    for (int half = 0; half < 2; ++half) {
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      hipLaunchKernelGGL(half_line_kernel, dim3(256 * 16), dim3(256), 0, 0, g, sink, big / 128, half);
+      hipEventRecord(e0);
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(half_line_kernel, dim3(256 * 16), dim3(256), 0, 0, g, sink, big / 128, (half + i) & 1);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      ms /= 5;
+      printf("half-line reads (64 B of every 128-B line, alternating halves per pass), 1 GiB buffer: %7.1f us  %7.0f GB/s of useful bytes\n", ms * 1e3, 0.5 * big / ms / 1e6);
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((pass_kernel<1, 4, false>), dim3(256 * 8), dim3(256), 0, 0, g, g, g, g + (big / 2), big / 2 / 16, 16, 1);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((pass_kernel<1, 4, false>), dim3(256 * 8), dim3(256), 0, 0, g, g, g, g + (big / 2), big / 2 / 16, 16, 1);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    printf("full-line copy 512 MiB -> 512 MiB of the same buffer: %7.1f us  %7.0f GB/s total\n", ms * 1e3, (double)big / ms / 1e6);
+    hipFree(g); hipFree(sink);
+  }
   const int cpp = 16;   // 128 channels fp16
   for (int bpc : {2, 8, 32}) {
     hipEvent_t e0, e1;
