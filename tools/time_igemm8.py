@@ -61,23 +61,21 @@ def timeit(args, iters=20):
 # argv[2] = the GI_IGEMM8 value of the second arm (default 2: every eligible layer on 128-column igemm8 tiles; 3: also the layers with
 # fewer than 512 workgroups, on 64-column tiles); the first arm is GI_IGEMM8 = 0 (igemm6)
 arm = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-# argv[3] = "igemm9": the first arm is the default dispatch (igemm8 where it applies), the second GI_IGEMM9 = arm
-NINE = len(sys.argv) > 3 and sys.argv[3] == "igemm9"
 print(f"{'layer':22s} {'igemm6 us':>10s} {'igemm8 us':>10s} {'ratio':>6s} {'TF/s 6':>8s} {'TF/s 8':>8s}   kernels")
 for name, kind, n, H, cin, cout, relu, cend in LAYERS:
     x, wp, out, flop = make(kind, n, H, cin, cout)
     args = (kind, x, wp, out, n, H, cin, cout, relu, cend)
     t6, t8, k6, k8 = [], [], "", ""
     for _ in range(rounds):
-        B.set_option("GI_IGEMM9" if NINE else "GI_IGEMM8", 0)
+        B.set_option("GI_IGEMM8", 0)
         t6.append(timeit(args)); k6 = B.last_kernel()
-        B.set_option("GI_IGEMM9" if NINE else "GI_IGEMM8", arm)
+        B.set_option("GI_IGEMM8", arm)
         t8.append(timeit(args)); k8 = B.last_kernel()
-    B.set_option("GI_IGEMM9" if NINE else "GI_IGEMM8", -1)
+    B.set_option("GI_IGEMM8", -1)
     a, b = sorted(t6)[len(t6) // 2], sorted(t8)[len(t8) // 2]
     # parity of the two arms on the same inputs (fp32 accumulation in a different K order)
-    B.set_option("GI_IGEMM9" if NINE else "GI_IGEMM8", 0); launch(*args); o6 = out.float().clone()
-    B.set_option("GI_IGEMM9" if NINE else "GI_IGEMM8", arm); launch(*args); o8 = out.float()
-    B.set_option("GI_IGEMM9" if NINE else "GI_IGEMM8", -1)
+    B.set_option("GI_IGEMM8", 0); launch(*args); o6 = out.float().clone()
+    B.set_option("GI_IGEMM8", arm); launch(*args); o8 = out.float()
+    B.set_option("GI_IGEMM8", -1)
     rel = float((o6 - o8).norm() / o6.norm())
     print(f"{name:22s} {a:10.1f} {b:10.1f} {b / a:6.2f} {flop / a / 1e6:8.0f} {flop / b / 1e6:8.0f}   {k6} | {k8}   rel diff {rel:.1e}")
