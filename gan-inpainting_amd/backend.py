@@ -22,6 +22,7 @@ PROTOTYPES = {
     "gi_set_option": (_i, [C.c_char_p, _i]),
     "gi_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "gi_debug_last_kernel": (C.c_char_p, []),
+    "gi_debug_fold_count": (_i, []),
     "gi_ctx_create": (_i, [_i, _vp, C.POINTER(_vp)]),
     "gi_ctx_destroy": (_i, [_vp]),
     "gi_ctx_sync": (_i, [_vp]),

@@ -20,10 +20,12 @@ struct OptDesc { const char* name; int dflt; int value; int state; };   // state
 OptDesc g_opts[GI_OPT_COUNT] = {
   {"GI_IGEMM5", 7, 0, 0}, {"GI_IGEMM6", 1, 0, 0}, {"GI_IGEMM7", 1, 0, 0}, {"GI_IGEMM_FIXUP", 1, 0, 0}, {"GI_IGEMM_VARIANT", 3, 0, 0},
   {"GI_BN_ACC", 1, 0, 0}, {"GI_FUSE_HEAD", 1, 0, 0}, {"GI_HEAD_FAST", 1, 0, 0}, {"GI_BN_BWD_FUSE", 1, 0, 0}, {"GI_BN_BWD_SMALL", 512, 0, 0},
-  {"GI_WGRAD2", 1, 0, 0}, {"GI_WGRAD3", 1, 0, 0}, {"GI_IGEMM8", 1, 0, 0},
+  {"GI_WGRAD2", 1, 0, 0}, {"GI_WGRAD3", 1, 0, 0}, {"GI_IGEMM8", 1, 0, 0}, {"GI_BN_FOLD", 1, 0, 0},
 };
 const char* g_last_kernel = "";
+int g_fold_count = 0;
 }  // namespace
+void gi_note_fold() { ++g_fold_count; }
 
 int gi_opt(int id) {
   OptDesc& o = g_opts[id];
@@ -57,6 +59,7 @@ int gi_get_option(const char* name, int* value) {
   return GI_ERR_INVALID;
 }
 const char* gi_debug_last_kernel(void) { return g_last_kernel; }
+int gi_debug_fold_count(void) { return g_fold_count; }
 
 const char* gi_last_error(void) { return g_err; }
 int gi_version(void) { return 100; }

@@ -23,12 +23,13 @@ void gi_set_error(const char* fmt, ...);
 // once per process), else the default. include/ganinpaint.h documents each; tests/test_options_gpu.py runs every alternative.
 enum gi_opt_id {
   GI_OPT_IGEMM5 = 0, GI_OPT_IGEMM6, GI_OPT_IGEMM7, GI_OPT_IGEMM_FIXUP, GI_OPT_IGEMM_VARIANT, GI_OPT_BN_ACC, GI_OPT_FUSE_HEAD,
-  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_COUNT
+  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_COUNT
 };
 int gi_opt(int id);
 // name of the GEMM / weight-gradient kernel a dispatcher has just launched (gi_debug_last_kernel: tests assert which kernel
 // served a shape)
 void gi_note_kernel(const char* name);
+void gi_note_fold();   // a GEMM launch took an IgemmFold (gi_debug_fold_count)
 // tuning constants: fixed in the shipped library, read from the environment only by the ablation build (build.sh -DGI_ABLATION)
 #ifdef GI_ABLATION
 #include <stdlib.h>
@@ -45,6 +46,39 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
     static_for<N - 1>(f);
     f(std::integral_constant<int, N - 1>{});
   }
+}
+
+// ---- pieces shared by the GEMM epilogues (igemm3 / 5 / 6 / 7 / 8) -----------------------------------------------------------
+// The output activation is the same for every element of a launch. Written as `act == RELU ? .. : act == LRELU ? ..` inside the
+// unrolled accumulator loops, hipcc kept the test PER ELEMENT as scalar compares and branches (round 3's igemm8<1,true>: 256 s_cmp
+// + 650 s_cbranch per wave in the epilogue, three of them taken per element on the BatchNorm layers' act = none path). gi_with_act
+// runs the body once per launch with the activation as a compile-time constant instead.
+template <int ACT>
+__device__ __forceinline__ float gi_act_c(float v) {
+  if constexpr (ACT == GI_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  else return v;
+}
+template <typename F>
+__device__ __forceinline__ void gi_with_act(int act, F&& f) {
+  if (act == GI_ACT_NONE) f(std::integral_constant<int, GI_ACT_NONE>{});
+  else if (act == GI_ACT_RELU) f(std::integral_constant<int, GI_ACT_RELU>{});
+  else f(std::integral_constant<int, GI_ACT_LRELU>{});
+}
+// Sum over the 16 lanes of a DPP row (lane & 15 = the pixel row of a 16x16 MFMA tile), every lane receives the total. The same
+// additions in the same order as the xor butterfly `v += __shfl_xor(v, 1 / 2 / 4 / 8)` it replaces (quad_perm = xor 1, xor 2; after
+// those a quad holds one value, so row_half_mirror pairs quads like xor 4 and row_mirror pairs the 8-lane halves like xor 8) -
+// bit-identical results - as four v_add_f32 with DPP operands instead of four ds_bpermute_b32 + waits + adds per value.
+template <int CTRL>
+__device__ __forceinline__ float gi_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float gi_row16_sum(float v) {
+  v += gi_dpp<0xB1>(v);    // quad_perm:[1,0,3,2]
+  v += gi_dpp<0x4E>(v);    // quad_perm:[2,3,0,1]
+  v += gi_dpp<0x141>(v);   // row_half_mirror
+  v += gi_dpp<0x140>(v);   // row_mirror
+  return v;
 }
 
 #define GI_HIP(expr)                                                                  \
@@ -101,6 +135,7 @@ static inline bool gi_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // Implicit-GEMM geometry shared by the strided conv ("CONV": gathers a 4x4 window of the
 // large-resolution tensor) and the transposed conv ("PHASE": four 2x2 sub-pixel convolutions of
 // the small-resolution tensor). Rows of the GEMM are always small-resolution pixels (n,y,x).
+struct IgemmFold;       // below BnAccArgs
 struct IgemmArgs {
   const void* in;      // CONV: large tensor (n,2Hs,2Ws,cin) ; PHASE: small tensor (n,Hs,Ws,cin)
   const void* w;       // CONV: T [cout][16*cin] ; PHASE: T [4][cout][4*cin]
@@ -147,6 +182,9 @@ struct IgemmArgs {
   int pool2, pool_applied;
   int stat_used;   // (returned) 1: the statistics went to stat_acc; 0: to `partials` (split-K layers: their finish pass
                    // has few rows per block, the partial rows + finalize launch are cheaper there than 4 atomics per channel)
+  // optional (with stat_acc): the normalisation pass that would follow, folded into this launch (IgemmFold below). A kernel that
+  // takes it sets fold_applied = 1 and the caller launches no bn_apply for the layer.
+  const IgemmFold* fold; int fold_applied;
 };
 constexpr int GI_IGEMM_TICKETS = 1024;
 int op_igemm(hipStream_t st, int dtype, int phase_mode, IgemmArgs& a);
@@ -215,6 +253,18 @@ struct BnAccArgs {
   unsigned long long* zero_next; int zero_words;   // optional: a region the pass clears for the layer's next use (ping-pong)
 };
 int op_bn_finalize_acc(hipStream_t st, int c, const BnAccArgs& b);
+// BatchNorm (train mode, one population) + activation + dropout of a small layer inside the GEMM that produces it (igemm7.hip): the
+// workgroup that completes the LAST tile of a channel column (all M tiles and sub-pixel phases of an N tile; a second ticket per
+// column, no grid barrier, no spin) derives that column's scale / shift from the exact accumulators, moves the running statistics,
+// saves the backward's vectors, clears the column's share of the layer's other accumulator region and writes act(fma(x, scale,
+// shift)) [* dropout] of the column into dst - the same fp32 expressions, the same fp16 rounding and the same dropout hash as
+// bn_apply_kernel, so results are bit-identical to the separate pass. The raw tensor is still written (the backward reads it).
+struct IgemmFold {
+  BnAccArgs bn;                      // groups == 1; acc == IgemmArgs::stat_acc
+  void* dst; int lddst, coffdst;     // (out pixels, lddst) + coffdst: the concat-buffer half
+  int act;                           // gi_act
+  uint8_t* drop_mask; float drop_scale; uint64_t drop_seed; float drop_p;   // as op_bn_apply_acc
+};
 // finalize + normalise + activation (+ dropout) in ONE pass: no launch between the GEMM and this one. drop_mask non-null
 // with drop_p > 0: the keep-mask is drawn in the pass (seed drop_seed) and stored there; drop_p == 0: the mask is read.
 int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy, int act,

@@ -8,6 +8,7 @@
 
 #include "common.h"
 #include "stat_acc.h"
+#include "bn_acc.h"
 
 namespace {
 
@@ -106,44 +107,6 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* partials,
   }
 }
 
-// The same from the exact accumulators (stat_acc.h) the GEMM epilogues added their tile sums to: acc[group][c][4].
-// Called by one thread per channel; `write` (one block per launch) also stores the vectors the backward needs and
-// moves the running statistics, population by population in the order separate calls would.
-struct BnAccP {
-  const unsigned long long* acc;   // accumulator block (stat_acc.h)
-  int reps;
-  const float* gamma; const float* beta;
-  float* rmean; float* rvar;
-  float* scale; float* shift; float* smean; float* sinv;   // [groups] x out_stride floats apart
-  double count;                    // pixels per population
-  float momentum, eps;
-  int groups, out_stride;
-  unsigned long long* zero_next;   // the layer's OTHER accumulator region: cleared here for its next use (ping-pong), so
-  int zero_words;                  // no memset launch is needed; nothing else touches it while this kernel runs
-};
-__device__ __forceinline__ void zero_words64(unsigned long long* p, int n) {
-  for (int i = threadIdx.x; i < n; i += 256) p[i] = 0ull;
-}
-__device__ __forceinline__ void bn_from_acc(const BnAccP& a, int c, int ch, int j, bool write, float& sc_out, float& sh_out) {
-  const double m = gi_stat_read(a.acc, c, a.reps, j, 0, ch) / a.count;
-  double v = gi_stat_read(a.acc, c, a.reps, j, 1, ch) / a.count - m * m;
-  if (v < 0.0) v = 0.0;
-  const float mean = (float)m, var = (float)v;
-  const float inv = 1.0f / sqrtf(var + a.eps);
-  const float sc = a.gamma[ch] * inv;
-  sc_out = sc;
-  sh_out = a.beta[ch] - mean * sc;
-  if (write) {
-    const float unbiased = a.count > 1.0 ? (float)(v * a.count / (a.count - 1.0)) : var;
-    a.rmean[ch] = (1.f - a.momentum) * a.rmean[ch] + a.momentum * mean;
-    a.rvar[ch] = (1.f - a.momentum) * a.rvar[ch] + a.momentum * unbiased;
-    const int o = j * a.out_stride + ch;
-    a.scale[o] = sc;
-    a.shift[o] = sh_out;
-    a.smean[o] = mean;
-    a.sinv[o] = inv;
-  }
-}
 // stand-alone form (consumers that apply the affine map themselves: C1Affine, HeadArgs::scale4)
 __global__ void __launch_bounds__(256) bn_finalize_acc_kernel(BnAccP a, int c) {
   if (blockIdx.x == 0 && a.zero_next) zero_words64(a.zero_next, a.zero_words);
@@ -151,15 +114,6 @@ __global__ void __launch_bounds__(256) bn_finalize_acc_kernel(BnAccP a, int c) {
   if (ch >= c) return;
   float sc, sh;
   for (int j = 0; j < a.groups; ++j) bn_from_acc(a, c, ch, j, true, sc, sh);
-}
-
-// dropout keep-mask of element i under `seed` (splitmix64 of a counter), keep with probability 1 - p
-__device__ __forceinline__ uint8_t dropout_keep(uint64_t seed, int64_t i, uint32_t thresh) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return ((uint32_t)(z >> 32) >= thresh) ? 1 : 0;
 }
 
 // grid-stride is a multiple of the chunks-per-pixel (a power of two <= 256), so a thread's channel
@@ -1421,11 +1375,7 @@ int op_bn_finalize(hipStream_t st, const float* partials, int rows, int c, int64
   return GI_OK;
 }
 
-static uint32_t dropout_thresh(float p) {   // keep when the 32-bit draw >= thresh
-  const double t = (double)p * 4294967296.0;
-  const uint32_t thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-  return thresh ? thresh : 1u;
-}
+static uint32_t dropout_thresh(float p) { return gi_dropout_thresh(p); }
 
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
                 const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale, int64_t pg,
@@ -1444,12 +1394,7 @@ int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixel
   return GI_OK;
 }
 
-static void fill_acc_params(BnAccP& fa, const BnAccArgs& b) {
-  fa.acc = b.acc; fa.reps = b.reps > 0 ? b.reps : 1; fa.gamma = b.gamma; fa.beta = b.beta; fa.rmean = b.running_mean; fa.rvar = b.running_var;
-  fa.scale = b.scale; fa.shift = b.shift; fa.smean = b.save_mean; fa.sinv = b.save_invstd;
-  fa.count = (double)b.count; fa.momentum = b.momentum; fa.eps = b.eps; fa.groups = b.groups; fa.out_stride = b.out_stride;
-  fa.zero_next = b.zero_next; fa.zero_words = b.zero_words;
-}
+static void fill_acc_params(BnAccP& fa, const BnAccArgs& b) { gi_fill_acc_params(fa, b); }
 
 int op_bn_finalize_acc(hipStream_t st, int c, const BnAccArgs& b) {
   GI_REQUIRE(b.groups == 1 || b.groups == 2, "bn_finalize_acc: groups=%d", b.groups);

@@ -35,11 +35,6 @@ struct KP3 {
   int dbg;            // timing-only ablations (GI_IGEMM3_DBG): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads
 };
 
-__device__ __forceinline__ float act3(float v, int act) {
-  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
-  return v;
-}
 
 __device__ __forceinline__ h8_t relu_h8(h8_t v) {
   typedef short s8_t __attribute__((ext_vector_type(8)));
@@ -300,39 +295,40 @@ __global__ void __launch_bounds__(NW * 64, NW / 4) igemm3_kernel(KP3 p) {
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
+  const bool stats = p.partials || p.stat_acc;
+  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+    constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = wn * WN + nt * 16 + 4 * lq;           // this lane's 4 consecutive channels
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = wn * WN + nt * 16 + 4 * lq;         // this lane's 4 consecutive channels
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      h4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[mt][nt][r] + bs[r];
-        s[r] += v;
-        q[r] += v * v;
-        o[r] = (half_t)act3(v, p.act_out);
+        for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
       }
-      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
-    }
-    if (p.partials || p.stat_acc) {   // sum over the 16 pixels held by lanes with equal lq (xor 1,2,4,8)
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int mt = 0; mt < MT; ++mt) {
+        h4_t o;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[mt][nt][r] + bs[r];
+          s[r] += v;
+          q[r] += v * v;
+          o[r] = (half_t)gi_act_c<ACT>(v);
+        }
+        *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (lr == 0) {
+      if (stats) {   // sum over the 16 pixels held by lanes with equal lq
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+        for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
+        if (lr == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+        }
       }
     }
-  }
+  });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {   // (NTHREADS >= 256 >= BN)
     float s = 0.f, q = 0.f;

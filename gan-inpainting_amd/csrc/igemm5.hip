@@ -31,11 +31,6 @@ int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, c
 
 namespace {
 
-__device__ __forceinline__ float act5(float v, int act) {
-  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
-  return v;
-}
 __device__ __forceinline__ h8_t relu5(h8_t v) {
   typedef short s8_t __attribute__((ext_vector_type(8)));
   s8_t h = __builtin_bit_cast(s8_t, v);
@@ -80,39 +75,40 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
+  const bool stats = p.partials || p.stat_acc;
+  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+    constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = wn * WN + nt * 16 + 4 * lq;           // column of the tile (DUAL: px * 64 + channel)
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = wn * WN + nt * 16 + 4 * lq;         // column of the tile (DUAL: px * 64 + channel)
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      h4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[mt][nt][r] + bs[r];
-        s[r] += v;
-        q[r] += v * v;
-        o[r] = (half_t)act5(v, p.act_out);
+        for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
       }
-      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
-    }
-    if (p.partials || p.stat_acc) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int mt = 0; mt < MT; ++mt) {
+        h4_t o;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[mt][nt][r] + bs[r];
+          s[r] += v;
+          q[r] += v * v;
+          o[r] = (half_t)gi_act_c<ACT>(v);
+        }
+        *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (lr == 0) {
+      if (stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+        for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
+        if (lr == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+        }
       }
     }
-  }
+  });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
     float s = 0.f, q = 0.f;
@@ -806,7 +802,8 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   // igemm8 (igemm8.hip): the same tile on four waves, two workgroups per CU. GI_IGEMM8: 0 off, 1 (default) layers whose grid
   // gives every CU at least two workgroups (with one per CU half the wave slots stay empty: measured d3 / u4 / critic conv4,
   // 256 workgroups, 10 - 16 % slower than igemm6; every layer with >= 512 workgroups 3 - 16 % faster), 2 every eligible layer
-  const int use8 = gi_opt(GI_OPT_IGEMM8);
+  // GI_IGEMM6=0 (the first-generation halo kernels: no buffer-descriptor LDS-DMA anywhere) switches igemm8 off as well
+  const int use8 = gi_opt(GI_OPT_IGEMM6) ? gi_opt(GI_OPT_IGEMM8) : 0;
   // (the 3x3 mode: 128-column tiles on 32-wide patches, no fused input ReLU; VGG-19 from conv2_1 to conv4_4)
   if (use8 && (mode != 2 || (TW == 32 && !a.relu_in)) && (dual || BN == 128 || mode == 2) && a.cin % (mode == 0 ? 64 : 32) == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
       (int64_t)a.cout * (mode == 1 ? 4 : (mode == 2 ? 9 : 16)) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&

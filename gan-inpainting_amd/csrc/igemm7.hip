@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "stat_acc.h"
+#include "bn_acc.h"
 
 namespace {
 
@@ -36,13 +37,14 @@ struct KP7 {
   int relu_in, act_out, relu_cend;
   int Hin, Win, Hout, Wout;
   int mtiles, ntiles;
+  // folded normalisation (IgemmFold, common.h): fold != 0 -> the last finisher of a channel column normalises the column
+  int fold;
+  unsigned* col_tickets;             // [ntiles], zero before the launch and left zero
+  BnAccP fa;
+  char* fdst; int flddst, fcoffdst, fact;
+  uint8_t* fdrop; float fdrop_scale; uint64_t fdrop_seed; uint32_t fdrop_thresh;
 };
 
-__device__ __forceinline__ float act7(float v, int act) {
-  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
-  return v;
-}
 __device__ __forceinline__ h8_t relu7(h8_t v) {
   typedef short s8_t __attribute__((ext_vector_type(8)));
   s8_t h = __builtin_bit_cast(s8_t, v);
@@ -314,39 +316,40 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [2][BN][2]
+  const bool stats = p.partials || p.stat_acc;
+  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+    constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = wn * WN + nt * 16 + 4 * lq;           // this lane's 4 consecutive channels
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = wn * WN + nt * 16 + 4 * lq;         // this lane's 4 consecutive channels
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      h4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = acc[mt][nt][r] + bs[r];
-        s[r] += v;
-        q[r] += v * v;
-        o[r] = (half_t)act7(v, p.act_out);
+        for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
       }
-      *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
-    }
-    if (p.partials || p.stat_acc) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int mt = 0; mt < MT; ++mt) {
+        h4_t o;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[mt][nt][r] + bs[r];
+          s[r] += v;
+          q[r] += v * v;
+          o[r] = (half_t)gi_act_c<ACT>(v);
+        }
+        *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (lr == 0) {
+      if (stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+        for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
+        if (lr == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { red[(wm * BN + ch + r) * 2] = s[r]; red[(wm * BN + ch + r) * 2 + 1] = q[r]; }
+        }
       }
     }
-  }
+  });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
     const float s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
@@ -362,12 +365,102 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row
   const int oc = tid % CPRO;
+  if (!p.fold) {
+#pragma unroll 1
+    for (int r = tid / CPRO; r < BM; r += 256 / CPRO) {
+      const int m = m0 + r;
+      if (m < p.M) {
+        const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
+        *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+      }
+    }
+    return;
+  }
+
+  // ---- folded normalisation: BatchNorm + activation (+ dropout) of this channel column by the workgroup that completes it ------
+  // Hand-off, the form of the split-K fix-up above (guides/MI355X_MICROARCH.md, hand-off table, rows 1 and 3): every raw row is a
+  // 16-byte sc1 (write-through) buffer store, the column sums are agent-scope integer atomics (gi_stat_add); every wave drains its
+  // stores and atomics (s_waitcnt vmcnt(0)), a workgroup barrier, then ONE lane's agent-scope atomic add on the column's ticket.
+  // The workgroup whose add returned (tiles of the column) - 1 reads the accumulators with agent-scope atomic loads and every raw
+  // row with 16-byte sc1 buffer loads to registers. No workgroup waits for another one: nothing spins.
+  const int out_pixels = (PHASE == 1 ? 4 : 1) * p.M;
+  const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)((int64_t)out_pixels * p.ldout * 2), 0x00020000);
 #pragma unroll 1
   for (int r = tid / CPRO; r < BM; r += 256 / CPRO) {
     const int m = m0 + r;
     if (m < p.M) {
-      const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
-      *(u4_t*)(p.out + o * 2) = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+      const unsigned o = (unsigned)(out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8) * 2u;
+      __builtin_amdgcn_raw_buffer_store_b128(*(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2), rsO, o, 0, 16);   // sc1
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned need = (unsigned)(p.mtiles * nph);
+    const unsigned tk = __hip_atomic_fetch_add(p.col_tickets + nt_idx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (tk == need - 1u) ? 1 : 0;
+    if (s_last) __hip_atomic_store(p.col_tickets + nt_idx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  float* aff = (float*)smem;   // [2][BN]: scale, shift of this column (the staged tile has been stored)
+  if (tid < BN) {
+    float sc, sh;
+    bn_from_acc<true>(p.fa, p.cout, n0 + tid, 0, true, sc, sh);
+    aff[tid] = sc;
+    aff[BN + tid] = sh;
+  }
+  if (p.fa.zero_next) {        // this column's words of the layer's other accumulator region (rows of cout words: stat_acc.h)
+    const int rows = p.fa.zero_words / p.cout;
+    for (int i = tid; i < rows * BN; i += 256) p.fa.zero_next[(int64_t)(i / BN) * p.cout + n0 + (i % BN)] = 0ull;
+  }
+  __syncthreads();
+  float fsc[8], fsh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { fsc[e] = aff[oc * 8 + e]; fsh[e] = aff[BN + oc * 8 + e]; }
+  constexpr int RPP = 256 / CPRO, NR = 8;   // rows per pass of the workgroup; loads in flight per thread
+  const int ch0 = n0 + oc * 8;
+#pragma unroll 1
+  for (int r0 = tid / CPRO; r0 < out_pixels; r0 += RPP * NR) {
+    u4_t raw[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = r0 + k * RPP;
+      const unsigned o = r < out_pixels ? (unsigned)(r * p.ldout + p.coffout + ch0) * 2u : 0x80000000u;   // out of range: zeros
+      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rsO, o, 0, 16);                                      // sc1
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = r0 + k * RPP;
+      if (r >= out_pixels) break;
+      const h8_t h = __builtin_bit_cast(h8_t, raw[k]);
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {        // bn_apply_kernel's arithmetic (elementwise.hip)
+        float t = fmaf((float)h[e], fsc[e], fsh[e]);
+        if (p.fact == GI_ACT_RELU) t = t > 0.f ? t : 0.f;
+        else if (p.fact == GI_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
+        v[e] = t;
+      }
+      if (p.fdrop) {
+        const int64_t e0 = (int64_t)r * p.cout + ch0;
+        if (p.fdrop_thresh) {
+          uint8_t kp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) kp[e] = dropout_keep(p.fdrop_seed, e0 + e, p.fdrop_thresh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = kp[e] ? v[e] * p.fdrop_scale : 0.f;
+          *(uint2*)(p.fdrop + e0) = uint2{(unsigned)kp[0] | ((unsigned)kp[1] << 8) | ((unsigned)kp[2] << 16) | ((unsigned)kp[3] << 24),
+                                          (unsigned)kp[4] | ((unsigned)kp[5] << 8) | ((unsigned)kp[6] << 16) | ((unsigned)kp[7] << 24)};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = p.fdrop[e0 + e] ? v[e] * p.fdrop_scale : 0.f;
+        }
+      }
+      h8_t o8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = (half_t)v[e];
+      *(h8_t*)(p.fdst + ((int64_t)r * p.flddst + p.fcoffdst + ch0) * 2) = o8;
     }
   }
 }
@@ -402,6 +495,17 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   int kps = (nk + splitk - 1) / splitk;
   splitk = (nk + kps - 1) / kps;
   if (splitk > 1 && (!a.tickets || !a.ws || tiles > GI_IGEMM_TICKETS || a.ws_bytes < (int64_t)splitk * tiles * 128 * BN * 4)) return GI_ERR_UNSUPPORTED;
+  // Folded normalisation (IgemmFold): taken when ONE workgroup can normalise a channel column in about the time the separate pass
+  // spends before its first byte moves (a dependent launch + the accumulator reads: ~5 us): the column finisher reads and writes
+  // out_pixels x BN halves at 60 - 100 GB/s (one CU, other workgroups' rows: guides/MI355X_MICROARCH.md "handoff-payload"), i.e.
+  // ~1.5 us per 64 KiB each way. The column tickets are the last 32 of the GI_IGEMM_TICKETS words.
+  constexpr int COL_TICKETS = 32;
+  const int64_t out_pixels = (int64_t)M * nph;
+  const int64_t col_bytes = out_pixels * BN * 2;
+  const bool fold = a.fold && gi_opt(GI_OPT_BN_FOLD) && a.stat_acc && a.fold->bn.groups == 1 && a.fold->bn.acc == a.stat_acc && a.tickets &&
+                    ntiles <= COL_TICKETS && tiles <= GI_IGEMM_TICKETS - COL_TICKETS && col_bytes <= (int64_t)gi_tune("GI_FOLD_MAX_KB", 256) * 1024 &&
+                    out_pixels * a.ldout * 2 < (1ll << 31) && out_pixels * a.fold->lddst * 2 < (1ll << 31) && a.ldout % 8 == 0 && a.coffout % 8 == 0 &&
+                    a.fold->lddst % 8 == 0 && a.fold->coffdst % 8 == 0 && (a.fold->act == GI_ACT_RELU || a.fold->act == GI_ACT_LRELU || a.fold->act == GI_ACT_NONE);
   int dev = 0;
   GI_HIP(hipGetDevice(&dev));
   const char* zero = gi_igemm3_zero_page(dev);
@@ -424,6 +528,20 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
              "igemm7: tensor too large for 32-bit offsets");
   kp.mtiles = mtiles; kp.ntiles = ntiles;
+  kp.fold = fold ? 1 : 0;
+  a.fold_applied = kp.fold;
+  if (fold) {
+    gi_note_fold();
+    const IgemmFold& f = *a.fold;
+    gi_fill_acc_params(kp.fa, f.bn);
+    kp.col_tickets = a.tickets + (GI_IGEMM_TICKETS - COL_TICKETS);
+    kp.fdst = (char*)f.dst; kp.flddst = f.lddst; kp.fcoffdst = f.coffdst; kp.fact = f.act;
+    kp.fdrop = f.drop_mask; kp.fdrop_scale = f.drop_scale; kp.fdrop_seed = f.drop_seed;
+    kp.fdrop_thresh = f.drop_p > 0.f ? gi_dropout_thresh(f.drop_p) : 0u;
+  } else {
+    kp.col_tickets = nullptr; kp.fa = BnAccP{}; kp.fdst = nullptr; kp.flddst = kp.fcoffdst = kp.fact = 0;
+    kp.fdrop = nullptr; kp.fdrop_scale = 1.f; kp.fdrop_seed = 0; kp.fdrop_thresh = 0;
+  }
   const int nyz = ntiles * nph * splitk;
   const int grid = mtiles >= 8 ? ((mtiles + 7) / 8) * 8 * nyz : mtiles * nyz;
   const int ring = 4 * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
@@ -439,7 +557,8 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
     case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
     default: hipLaunchKernelGGL((igemm7_kernel<1, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
   }
-  { static const char* nm[4] = {"igemm7<0,128>", "igemm7<1,128>", "igemm7<0,64>", "igemm7<1,64>"}; gi_note_kernel(nm[vi]); }
+  { static const char* nm[8] = {"igemm7<0,128>", "igemm7<1,128>", "igemm7<0,64>", "igemm7<1,64>",
+                                "igemm7<0,128>+bn", "igemm7<1,128>+bn", "igemm7<0,64>+bn", "igemm7<1,64>+bn"}; gi_note_kernel(nm[vi + (fold ? 4 : 0)]); }
   GI_LAUNCH_CHECK();
   a.ntiles_out = mtiles * nph;
   return GI_OK;

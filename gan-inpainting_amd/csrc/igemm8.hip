@@ -34,11 +34,6 @@
 
 namespace {
 
-__device__ __forceinline__ float act8(float v, int act) {
-  if (act == GI_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == GI_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
-  return v;
-}
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, int soff, char* lds_wave_base) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -61,39 +56,40 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4 waves][BN][2]
+  const bool stats = p.partials || p.stat_acc;
+  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+    constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int ch = nt * 16 + 4 * lq;                     // column of the tile (DUAL: px * 64 + channel)
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ch = nt * 16 + 4 * lq;                   // column of the tile (DUAL: px * 64 + channel)
+      float bs[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      h4_t o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[mt][nt][r] + bs[r];
-        s[r] += v;
-        q[r] += v * v;
-        o[r] = (half_t)act8(v, p.act_out);
+        for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
       }
-      *(h4_t*)(stg + (wave * 64 + mt * 16 + lr) * SLD + ch) = o;
-    }
-    if (p.partials || p.stat_acc) {
+      float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int mt = 0; mt < MT; ++mt) {
+        h4_t o;
 #pragma unroll
-        for (int off = 1; off < 16; off <<= 1) { s[r] += __shfl_xor(s[r], off); q[r] += __shfl_xor(q[r], off); }
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[mt][nt][r] + bs[r];
+          s[r] += v;
+          q[r] += v * v;
+          o[r] = (half_t)gi_act_c<ACT>(v);
+        }
+        *(h4_t*)(stg + (wave * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (lr == 0) {
+      if (stats) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { red[(wave * BN + ch + r) * 2] = s[r]; red[(wave * BN + ch + r) * 2 + 1] = q[r]; }
+        for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
+        if (lr == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { red[(wave * BN + ch + r) * 2] = s[r]; red[(wave * BN + ch + r) * 2 + 1] = q[r]; }
+        }
       }
     }
-  }
+  });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
     float s = 0.f, q = 0.f;

@@ -649,6 +649,26 @@ StatPlan stat_plan(const gi_net* net, const BN& b, int64_t gemm_rows, int64_t ti
   return sp;
 }
 
+// the accumulator-path arguments of a layer's normalisation (pg pixels per population, g populations), and the state change of
+// the layer's ping-pong accumulator regions once a launch that consumes them has been issued
+BnAccArgs bn_acc_args(const gi_net* net, int slot, const BN& b, const StatPlan& sp, int64_t pg, int g) {
+  BNPtrs p = bn_ptrs(net, slot, b, 0);
+  BnAccArgs a;
+  a.acc = sp.acc; a.gamma = net->params + b.gamma_off; a.beta = net->params + b.beta_off;
+  a.running_mean = net->buffers + b.rmean_off; a.running_var = net->buffers + b.rvar_off;
+  a.scale = p.scale; a.shift = p.shift; a.save_mean = p.mean; a.save_invstd = p.inv;
+  a.count = pg; a.momentum = 0.1f; a.eps = 1e-5f; a.groups = g; a.out_stride = 4 * b.c;
+  a.zero_next = sp.zero_words > 0 ? sp.zero_next : nullptr; a.zero_words = sp.zero_words;
+  a.reps = sp.reps;
+  return a;
+}
+void bn_acc_commit(gi_net* net, int slot, const BN& b, const StatPlan& sp) {
+  b.dirty[b.fwd_par ^ 1] = 0;
+  b.dirty[b.fwd_par] = sp.reps;
+  b.fwd_par ^= 1;
+  if (b.id >= 0) net->eval_gen[slot][b.id] = 0;
+}
+
 // drop_p > 0 with the accumulator path: the keep-mask is drawn inside the normalisation pass (seed drop_seed) and
 // stored at `drop`; otherwise `drop` (if any) is read.
 int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixels, int ntiles, void* dst, int ldy,
@@ -659,18 +679,8 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
   const int64_t pg = pixels / g;
   const size_t T = net->tsz();
   if (sp && sp->use) {
-    BNPtrs p = bn_ptrs(net, slot, b, 0);
-    BnAccArgs a;
-    a.acc = sp->acc; a.gamma = net->params + b.gamma_off; a.beta = net->params + b.beta_off;
-    a.running_mean = net->buffers + b.rmean_off; a.running_var = net->buffers + b.rvar_off;
-    a.scale = p.scale; a.shift = p.shift; a.save_mean = p.mean; a.save_invstd = p.inv;
-    a.count = pg; a.momentum = 0.1f; a.eps = 1e-5f; a.groups = g; a.out_stride = 4 * b.c;
-    a.zero_next = sp->zero_words > 0 ? sp->zero_next : nullptr; a.zero_words = sp->zero_words;
-    a.reps = sp->reps;
-    b.dirty[b.fwd_par ^ 1] = 0;
-    b.dirty[b.fwd_par] = sp->reps;
-    b.fwd_par ^= 1;
-    if (b.id >= 0) net->eval_gen[slot][b.id] = 0;
+    const BnAccArgs a = bn_acc_args(net, slot, b, *sp, pg, g);
+    bn_acc_commit(net, slot, b, *sp);
     if (apply) return op_bn_apply_acc(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, act, (uint8_t*)drop, drop_scale, drop_seed, drop_p, a);
     return op_bn_finalize_acc(st, b.c, a);
   }
@@ -746,10 +756,11 @@ BwdFuse bwd_fuse_plan(gi_net* net, int slot, const BN& bn, const void* x, int64_
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
-          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr, BwdFuse* bf = nullptr) {
+          const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr, BwdFuse* bf = nullptr,
+          const IgemmFold* fold = nullptr, int* fold_applied = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
-  if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; a.stat_reps = sp->reps; }
+  if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; a.stat_reps = sp->reps; a.fold = fold; }
   if (bf && bf->planned) {
     a.bwd_x = bf->x; a.bwd_ldx = bf->ldx; a.bwd_scale = bf->scale; a.bwd_shift = bf->shift; a.bwd_mean = bf->mean; a.bwd_inv = bf->inv;
     a.bwd_stride = bf->stride; a.bwd_slope = bf->slope; a.bwd_acc = bf->acc; a.bwd_reps = bf->reps_gemm; a.bwd_pg = bf->pg;
@@ -768,6 +779,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   a.relu_in = relu_in; a.act_out = act_out;
   GI_TRY(op_igemm(net->ctx->stream, net->dtype, phase, a));
   if (mask_applied) *mask_applied = a.mask_applied;
+  if (fold_applied) *fold_applied = a.fold_applied;
   if (bf && bf->planned) bf->applied = a.bwd_applied != 0;
   if (sp && sp->use && !a.stat_used) sp->use = false;
   if (ntiles) *ntiles = a.ntiles_out;
@@ -1028,9 +1040,19 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     if (k < nd) {
       void* R = net->slot(s, net->oR[k]);
       StatPlan sp = stat_plan(net, net->dnorm[k], pix, (pix + 127) / 128, train);
+      // small layers: the GEMM's last finisher per channel column normalises the column itself (IgemmFold; igemm7 decides)
+      IgemmFold fold;
+      int folded = 0;
+      if (sp.use && dt == GI_F16) {
+        fold.bn = bn_acc_args(net, s, net->dnorm[k], sp, pix, 1);
+        fold.dst = C(k); fold.lddst = 2 * net->ch[k]; fold.coffdst = 0; fold.act = GI_ACT_LRELU;
+        fold.drop_mask = nullptr; fold.drop_scale = 1.f; fold.drop_seed = 0; fold.drop_p = 0.f;
+      }
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), R, net->ch[k],
-                   net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
-      GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train, true, &sp));
+                   net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp, nullptr,
+                   (sp.use && dt == GI_F16) ? &fold : nullptr, &folded));
+      if (folded) bn_acc_commit(net, s, net->dnorm[k], sp);
+      else GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train, true, &sp));
     } else {  // innermost: no down-norm; uprelu follows directly (networks.py:299-305)
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), net->slot(s, net->oE),
                    net->ch[k], net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_RELU, false, nullptr));
@@ -1057,8 +1079,19 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
       drop = m;
     }
     const bool fused = (k == 2) && fuse_u2;
+    IgemmFold fold;
+    int folded = 0;
+    const bool offer = sp.use && dt == GI_F16 && !fused;
+    if (offer) {
+      fold.bn = bn_acc_args(net, s, net->unorm[k], sp, opix, 1);
+      fold.dst = C(k - 1); fold.lddst = 2 * co; fold.coffdst = co; fold.act = GI_ACT_RELU;
+      fold.drop_mask = (uint8_t*)drop; fold.drop_scale = drop ? 1.f / (1.f - net->dropout_p) : 1.f;
+      fold.drop_seed = drop_seed; fold.drop_p = (drop && !net->ext_mask[s][k]) ? net->dropout_p : 0.f;
+    }
     GI_TRY(igemm(net, 1, in, cin, cin, 0, phase_ptr(net, net->up[k]), U, co, co, 0, n, net->Hk[k], net->Wk[k], k < nd ? 1 : 0,
-                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
+                 GI_ACT_NONE, true, &nt, k < nd ? net->ch[k] : 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp, nullptr, offer ? &fold : nullptr,
+                 &folded));
+    if (folded) { bn_acc_commit(net, s, net->unorm[k], sp); continue; }
     if (drop && !net->ext_mask[s][k]) {
       if (sp.use) drop_p = net->dropout_p;      // drawn (same hash, same masks) inside the normalisation pass
       else GI_TRY(op_fill_dropout(st, (uint8_t*)drop, opix * co, drop_seed, net->dropout_p));

@@ -46,13 +46,22 @@ __device__ __forceinline__ void gi_stat_add(unsigned long long* base, int c, int
   atomicAdd(lo, (unsigned long long)l);
 }
 
-// total of quantity q of channel ch over `reps` replicas
+// total of quantity q of channel ch over `reps` replicas. COHERENT: the adds came from other workgroups of the SAME launch; the
+// words are then read with agent-scope relaxed atomic loads (sc1), not plain ones that this CU's L1 may serve
+template <bool COHERENT = false>
 __device__ __forceinline__ double gi_stat_read(const unsigned long long* base, int c, int reps, int group, int q, int ch) {
   unsigned long long hi = 0, lo = 0, bad = 0;
   for (int r = 0; r < reps; ++r) {
     const unsigned long long* p = base + ((long long)(r * 2 + group) * GI_STAT_WORDS + 2 * q) * c + ch;
-    const unsigned long long l = p[c];
-    hi += p[0];
+    unsigned long long l, h0;
+    if constexpr (COHERENT) {
+      l = __hip_atomic_load(p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      h0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      l = p[c];
+      h0 = p[0];
+    }
+    hi += h0;
     lo += l & 0x7FFFFFFFFFFFFFFFull;
     bad |= l >> 63;
   }

@@ -52,7 +52,7 @@ int gi_version(void);
  * agree to rounding (tests/test_options_gpu.py runs each). value < 0 restores the default, which is the environment
  * variable of the same name if set (read once), else the number in brackets. Nothing here exists in the reference.
  *   GI_IGEMM5 [7]         bit 0 / 1 / 2: halo-resident implicit GEMM for sub-pixel phases / 4x4-s2 gather / 3x3-s1 (else igemm3)
- *   GI_IGEMM6 [1]         0: first-generation halo kernels (igemm5) instead of the buffer-descriptor LDS-DMA ones
+ *   GI_IGEMM6 [1]         0: first-generation halo kernels (igemm5) instead of the buffer-descriptor LDS-DMA ones (igemm6 AND igemm8)
  *   GI_IGEMM8 [1]         0: never the four-wave / two-workgroups-per-CU halo kernel (igemm8); 1: on layers with >= 512
  *                         workgroups; 2: on every eligible layer
  *   GI_IGEMM7 [1]         0: small-M layers on the generic kernel (igemm.hip) instead of the four-stage ring kernel
@@ -64,12 +64,16 @@ int gi_version(void);
  *   GI_BN_BWD_FUSE [1]    0: BatchNorm-backward reduction as its own launch instead of the producing GEMM's epilogue
  *   GI_BN_BWD_SMALL [512] largest pixel count served by the one-launch BatchNorm backward (0: never)
  *   GI_WGRAD2 [1]         0: weight gradients on the register-staged kernel (wgrad.hip) only
- *   GI_WGRAD3 [1]         0: the unpipelined two-tap-row weight-gradient kernel instead of wgrad3 */
+ *   GI_WGRAD3 [1]         0: the unpipelined two-tap-row weight-gradient kernel instead of wgrad3
+ *   GI_BN_FOLD [1]        0: the BatchNorm + activation (+ dropout) pass of the generator's small layers as its own launch instead of
+ *                         inside the GEMM that produces the layer (igemm7's last finisher per channel column); bit-identical results */
 int gi_set_option(const char* name, int value);
 int gi_get_option(const char* name, int* value);
 /* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.
  * "igemm6<1,128,relu>", "igemm7<0,64>", "wgrad3<4>" (tests assert which kernel served a shape); "" before the first. */
 const char* gi_debug_last_kernel(void);
+/* number of GEMM launches of this process that normalised their own output (GI_BN_FOLD; tests count folded layers with it) */
+int gi_debug_fold_count(void);
 
 /* ---- context ------------------------------------------------------------------------------ */
 int gi_ctx_create(int device_id, void* hip_stream, gi_ctx** out);
