@@ -57,21 +57,36 @@ def launch_ranks(n, argv):
     (they print nothing by contract), stderr is shared. A rank that fails takes the others down (exact PIDs)."""
     import socket
     import subprocess
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # watchdog: every rank drops rank<r>.ready into this directory once the process group exists (parallel.init_from_env); ranks
+    # that have not after GI_RENDEZVOUS_TIMEOUT + 30 s are named and the run ends non-zero (the ranks' own watchdogs fire first)
+    status = tempfile.mkdtemp(prefix="gi_ranks_")
+    limit = float(os.environ.get("GI_RENDEZVOUS_TIMEOUT", "120")) + 30.0
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), GI_RANK_STATUS_DIR=status)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
     live = list(procs)
+    t_start, all_up = time.monotonic(), False
     while live:
         time.sleep(0.05)
+        if not all_up and rc == 0:
+            up = [os.path.exists(os.path.join(status, f"rank{r}.ready")) for r in range(n)]
+            all_up = all(up)
+            if not all_up and time.monotonic() - t_start > limit:
+                stuck = [r for r in range(n) if not up[r]]
+                print(f"bench.py: ranks {stuck} of {n} have not joined the process group after {limit:.0f} s; stopping the run", file=sys.stderr)
+                rc = 4
+                for q in live:
+                    q.terminate()
         for p in list(live):
             c = p.poll()
             if c is None:
@@ -87,6 +102,8 @@ def launch_ranks(n, argv):
             p.wait(timeout=30)
         except subprocess.TimeoutExpired:
             p.kill()
+    import shutil
+    shutil.rmtree(status, ignore_errors=True)
     return rc
 
 

@@ -32,18 +32,24 @@ __device__ __forceinline__ void zero_words64(unsigned long long* p, int n) {
 // agent-scope atomic adds (MI355X_MICROARCH.md, hand-off table, third row). Same arithmetic either way.
 template <bool COHERENT = false>
 __device__ __forceinline__ void bn_from_acc(const BnAccP& a, int c, int ch, int j, bool write, float& sc_out, float& sh_out) {
-  const double m = gi_stat_read<COHERENT>(a.acc, c, a.reps, j, 0, ch) / a.count;
-  double v = gi_stat_read<COHERENT>(a.acc, c, a.reps, j, 1, ch) / a.count - m * m;
+  // the parameters are requested before the accumulator words are waited for (one memory round trip, not two)
+  const float gam = a.gamma[ch], bet = a.beta[ch];
+  float rm = 0.f, rv = 0.f;
+  if (write) { rm = a.rmean[ch]; rv = a.rvar[ch]; }
+  double t0, t1;
+  gi_stat_read2<COHERENT>(a.acc, c, a.reps, j, ch, t0, t1);
+  const double m = t0 / a.count;
+  double v = t1 / a.count - m * m;
   if (v < 0.0) v = 0.0;
   const float mean = (float)m, var = (float)v;
   const float inv = 1.0f / sqrtf(var + a.eps);
-  const float sc = a.gamma[ch] * inv;
+  const float sc = gam * inv;
   sc_out = sc;
-  sh_out = a.beta[ch] - mean * sc;
+  sh_out = bet - mean * sc;
   if (write) {
     const float unbiased = a.count > 1.0 ? (float)(v * a.count / (a.count - 1.0)) : var;
-    a.rmean[ch] = (1.f - a.momentum) * a.rmean[ch] + a.momentum * mean;
-    a.rvar[ch] = (1.f - a.momentum) * a.rvar[ch] + a.momentum * unbiased;
+    a.rmean[ch] = (1.f - a.momentum) * rm + a.momentum * mean;
+    a.rvar[ch] = (1.f - a.momentum) * rv + a.momentum * unbiased;
     const int o = j * a.out_stride + ch;
     a.scale[o] = sc;
     a.shift[o] = sh_out;

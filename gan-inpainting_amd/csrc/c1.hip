@@ -7,6 +7,7 @@
 // These layers carry <1% of the FLOPs and ~45% of the activation bytes, so they are written as
 // vectorised streaming kernels (16-byte feature accesses, weights in registers/LDS), not GEMMs.
 #include "common.h"
+#include "bn_acc.h"
 
 namespace {
 
@@ -152,6 +153,9 @@ __global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __res
 // The first form of this kernel (K padded to 32, half the lanes loading 8 taps behind per-tap bounds branches, 64-bit
 // divisions per group) spent 22 of its 39 us on the critic's conv1 in address arithmetic, measured with loads and stores
 // switched off; the layer is 134 MB of stores.
+// (Measured and dropped in round 4: the same launch also writing the copy of the image that the generator keeps for d1's weight
+//  gradient - lanes kq = 1, 2 hold exactly the 2 x 2 input pixels under their output pixel - made this store-bound kernel 5.6 us
+//  slower, what the separate 8.4 MB device copy costs; the copy now rides in a latency-bound pass instead: bn_apply's side copy.)
 template <int MTC, int ACT>   // MTC = c / 16
 __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              char* out, int n, int Hs, int Ws, int ldout, int coffout,
@@ -243,25 +247,17 @@ __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __rest
 // X2 != null: channels [c/2, c) are not read from X but produced on the fly as relu(fma(X2[p][ch - c/2], sc2, sh2)),
 // the BatchNorm + ReLU of the raw decoder output X2 (dense, ld2): the same fp32 expression and fp16 rounding as the
 // separate apply pass, which then never has to materialise that half of the concat buffer.
+// use_fa: sc2 / sh2 do not exist yet - every workgroup derives them from the layer's exact accumulators (bn_acc.h) into LDS while
+// its first rows are in flight, workgroup 0 publishes them with the backward's vectors and moves the running statistics (the
+// bn_finalize_acc launch between the GEMM and this kernel, 5 us behind a dependent launch, is gone).
 template <int KS>   // KS = c / 32
 __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float* __restrict__ w, half_t* col,
                                                      int64_t P, int ldx, int coffx, int relu_in, const char* X2, int ld2,
-                                                     const float* __restrict__ sc2, const float* __restrict__ sh2) {
+                                                     const float* __restrict__ sc2, const float* __restrict__ sh2, BnAccP fa, int use_fa) {
+  constexpr int KH = KS / 2;
+  __shared__ float aff[2][KH * 32];
   const int lane = threadIdx.x & 63;
   const int tapr = lane & 15, kq = lane >> 4;
-  h8_t af[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) af[ks][j] = (half_t)w[(ks * 32 + kq * 8 + j) * 16 + tapr];
-  constexpr int KH = KS / 2;
-  float s2[KH][8], h2[KH][8];
-  if (X2) {
-#pragma unroll
-    for (int ks = 0; ks < KH; ++ks)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { s2[ks][j] = sc2[ks * 32 + kq * 8 + j]; h2[ks][j] = sh2[ks * 32 + kq * 8 + j]; }
-  }
   const int64_t ngroups = (P + 15) / 16;
   const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
@@ -279,6 +275,33 @@ __global__ void __launch_bounds__(256) c1_col_kernel(const char* X, const float*
   h8_t raw[KS], nxt[KS];
   int64_t g = wave;
   if (g < ngroups) load_g(g, raw);
+  h8_t af[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[ks][j] = (half_t)w[(ks * 32 + kq * 8 + j) * 16 + tapr];
+  float s2[KH][8], h2[KH][8];
+  if (X2) {
+    if (use_fa) {
+      if (threadIdx.x < KH * 32) {
+        float a, b;
+        bn_from_acc(fa, KH * 32, threadIdx.x, 0, blockIdx.x == 0, a, b);
+        aff[0][threadIdx.x] = a;
+        aff[1][threadIdx.x] = b;
+      }
+      if (blockIdx.x == 0 && fa.zero_next) zero_words64(fa.zero_next, fa.zero_words);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s2[ks][j] = aff[0][ks * 32 + kq * 8 + j]; h2[ks][j] = aff[1][ks * 32 + kq * 8 + j]; }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s2[ks][j] = sc2[ks * 32 + kq * 8 + j]; h2[ks][j] = sh2[ks * 32 + kq * 8 + j]; }
+    }
+  }
   for (; g < ngroups; g += nwaves) {
     if (g + nwaves < ngroups) load_g(g + nwaves, nxt);
     const int64_t pix = g * 16 + tapr;
@@ -346,6 +369,131 @@ __global__ void __launch_bounds__(256) c1_col2im_kernel(const half_t* __restrict
       const int64_t oo = ((int64_t)nn * H + 2 * j + py) * W + 2 * i;
       *(float2*)(img + oo) = make_float2(v0 * out_scale, v1 * out_scale);
       if (img2) *(float2*)(img2 + oo) = make_float2(v0 * out_scale, v1 * out_scale);   // the caller's copy of the saved output
+    }
+  }
+}
+
+// ---- the same two steps in ONE launch (round 4) ----------------------------------------------------------------------------
+// A workgroup owns TH rows of one image of the small grid (all Ws columns, so only rows have a halo): it computes col[p][tap] for
+// its TH + 2 rows on the MFMA exactly as c1_col_kernel does (same fragments, same fp16 rounding of col), keeps them in LDS
+// ((TH + 2) x Ws x 32 bytes) and overlap-adds its own TH rows with c1_col2im_kernel's loop order - bit-identical output, the col
+// tensor (16.8 MB written and re-read at the headline shape) and one launch gone; the price is (TH + 2) / TH of the input reads,
+// the extra rows being the neighbour workgroup's (L2). u1 of the generator at 256x256, n = 32: 28.6 + 15.6 us -> see DESIGN.md.
+template <int KS>   // KS = c / 32
+__global__ void __launch_bounds__(256) c1_scatter_fused_kernel(const char* X, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* img, float* img2, int Hs, int Ws, int TH, int ldx, int coffx, int relu_in,
+                                                               const char* X2, int ld2, const float* __restrict__ sc2,
+                                                               const float* __restrict__ sh2, BnAccP fa, int use_fa, int post, float out_scale) {
+  constexpr int KH = KS / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_u1[];
+  half_t* col = (half_t*)smem_u1;                              // [(TH + 2) * Ws][16]
+  float* aff = (float*)(smem_u1 + (int64_t)(TH + 2) * Ws * 32);  // [2][KH * 32]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tapr = lane & 15, kq = lane >> 4;
+  const int bands = (Hs + TH - 1) / TH;
+  const int nn = blockIdx.x / bands, y0 = (blockIdx.x % bands) * TH;
+  const int gpr = Ws >> 4, G = (TH + 2) * gpr;                 // pixel groups of 16 along a row
+  const h8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_g = [&](int g, h8_t (&raw)[KS]) {
+    const int ry = g / gpr, x = (g - ry * gpr) * 16 + tapr, y = y0 - 1 + ry;
+    const bool live = g < G && y >= 0 && y < Hs;
+    const int64_t pix = ((int64_t)nn * Hs + (live ? y : 0)) * Ws + x;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (X2 && ks >= KH) raw[ks] = live ? *(const h8_t*)(X2 + ((pix * ld2 + (ks - KH) * 32 + kq * 8) << 1)) : zero;
+      else raw[ks] = live ? *(const h8_t*)(X + ((pix * ldx + coffx + ks * 32 + kq * 8) << 1)) : zero;
+    }
+  };
+  h8_t raw[KS], nx1[KS], nx2[KS];
+  int g = wave;
+  load_g(g, raw);
+  load_g(g + 4, nx1);
+  h8_t af[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) af[ks][j] = (half_t)w[(ks * 32 + kq * 8 + j) * 16 + tapr];
+  float s2[KH][8], h2[KH][8];
+  if (X2) {
+    if (use_fa) {
+      if (threadIdx.x < KH * 32) {
+        float a, b;
+        bn_from_acc(fa, KH * 32, threadIdx.x, 0, blockIdx.x == 0, a, b);
+        aff[threadIdx.x] = a;
+        aff[KH * 32 + threadIdx.x] = b;
+      }
+      if (blockIdx.x == 0 && fa.zero_next) zero_words64(fa.zero_next, fa.zero_words);
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s2[ks][j] = aff[ks * 32 + kq * 8 + j]; h2[ks][j] = aff[KH * 32 + ks * 32 + kq * 8 + j]; }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KH; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s2[ks][j] = sc2[ks * 32 + kq * 8 + j]; h2[ks][j] = sh2[ks * 32 + kq * 8 + j]; }
+    }
+  }
+  for (; g < G; g += 4) {
+    load_g(g + 8, nx2);
+    const int ry = g / gpr, x = (g - ry * gpr) * 16 + tapr, y = y0 - 1 + ry;
+    const bool live = y >= 0 && y < Hs;
+    h8_t bf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (X2 && ks >= KH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = fmaf((float)raw[ks][j], s2[ks >= KH ? ks - KH : 0][j], h2[ks >= KH ? ks - KH : 0][j]);
+          bf[ks][j] = live ? (half_t)(t > 0.f ? t : 0.f) : (half_t)0.f;
+        }
+      } else {
+        bf[ks] = raw[ks];
+        if (relu_in) bf[ks] = __builtin_elementwise_max(bf[ks], zero);
+      }
+    }
+    f4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks], bf[ks], acc, 0, 0, 0);
+    const h4_t o = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};     // rows outside the image: zeros
+    *(h4_t*)(col + ((int64_t)ry * Ws + x) * 16 + kq * 4) = o;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) { raw[ks] = nx1[ks]; nx1[ks] = nx2[ks]; }
+  }
+  __syncthreads();
+  // overlap-add (c1_col2im_kernel's order of additions): out(2j+py, 2i+px) = post(bias + sum col[(j+py-ty, i+px-tx)][tap])
+  const int H = 2 * Hs, W = 2 * Ws;
+  const float b = bias ? bias[0] : 0.f;
+  for (int p = threadIdx.x; p < TH * Ws; p += 256) {
+    const int jl = p / Ws, i = p - jl * Ws, j = y0 + jl;
+    if (j >= Hs) break;
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int sy = j + dy, sx = i + dx;
+        if (sy < 0 || sy >= Hs || sx < 0 || sx >= Ws) continue;
+        const half_t* cp = col + ((int64_t)(jl + 1 + dy) * Ws + sx) * 16;
+        const h8_t c0 = *(const h8_t*)cp, c1 = *(const h8_t*)(cp + 8);
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px) {
+            const int ty = py - dy, tx = px - dx;
+            if (ty < 0 || ty > 1 || tx < 0 || tx > 1) continue;
+            const int tap = (1 - py + 2 * ty) * 4 + (1 - px + 2 * tx);
+            o[py * 2 + px] += tap < 8 ? (float)c0[tap & 7] : (float)c1[tap & 7];
+          }
+      }
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float v0 = o[py * 2] + b, v1 = o[py * 2 + 1] + b;
+      if (post == 1) { v0 = tanhf(v0); v1 = tanhf(v1); }
+      const int64_t oo = ((int64_t)nn * H + 2 * j + py) * W + 2 * i;
+      *(float2*)(img + oo) = make_float2(v0 * out_scale, v1 * out_scale);
+      if (img2) *(float2*)(img2 + oo) = make_float2(v0 * out_scale, v1 * out_scale);
     }
   }
 }
@@ -917,9 +1065,11 @@ __global__ void __launch_bounds__(256) head_dgrad_kernel(const float* dh, const 
 }
 
 // dw5[tap][c] += sum_{n,p} dh[n,p] * a4[n,p+tap][c]   (grid.y = n, grid.z = output row py)
+// part != null: the (image, row band) blocks store their sums there ([block][16 c]) and head_wgrad_sum_kernel adds them in block
+// order - bit-reproducible (the fp32 critic of BASELINE config 2); part == null: float atomics into dw5
 template <typename T>
 __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const char* a4, float* dw5, int Hh, int Wh,
-                                                         int c) {
+                                                         int c, float* part) {
   constexpr int EPC = 16 / (int)sizeof(T);
   const int Ph = Hh - 3, Pw = Wh - 3;
   const int cpt = c / EPC;
@@ -947,8 +1097,21 @@ __global__ void __launch_bounds__(256) head_wgrad_kernel(const float* dh, const 
       for (int e = 0; e < EPC; ++e) s[e] = fmaf(g, v[e], s[e]);
     }
   }
+  if (part) {
+    float* o = part + ((int64_t)blockIdx.y * gridDim.z + blockIdx.z) * 16 * c + tap * c + cc * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o[e] = s[e];
+    return;
+  }
 #pragma unroll
   for (int e = 0; e < EPC; ++e) atomicAdd(dw5 + tap * c + cc * EPC + e, s[e]);
+}
+__global__ void __launch_bounds__(256) head_wgrad_sum_kernel(const float* part, int nparts, float* dw5, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < nparts; ++k) s += part[(int64_t)k * count + i];
+  dw5[i] += s;
 }
 
 // ---- fp16 head at c = 512 (the PatchGAN of networks.py:331-363): one pixel row = 1 KiB = one wave load --------
@@ -1342,10 +1505,32 @@ int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, cons
     const int ld2 = aff ? aff->ld2 : 0;
     const float* sc2 = aff ? aff->scale : nullptr;
     const float* sh2 = aff ? aff->shift : nullptr;
+    BnAccP fa = {};
+    const int use_fa = (aff && aff->bn) ? 1 : 0;
+    if (use_fa) {
+      GI_REQUIRE(aff->bn->groups == 1, "c1_scatter: one BatchNorm population expected");
+      gi_fill_acc_params(fa, *aff->bn);
+    }
+    // one launch (c1_scatter_fused_kernel) where a band of rows fits LDS; GI_C1_FUSED=0: the col tensor + the overlap-add launch
+    int TH = 1024 / Ws;
+    if (TH < 1) TH = 1;
+    if (TH > Hs) TH = Hs;
+    const size_t lds_f = (size_t)(TH + 2) * Ws * 32 + 2 * (c / 2) * sizeof(float);
+    if (gi_opt(GI_OPT_C1_FUSED) && Ws % 16 == 0 && lds_f <= 64 * 1024 && (int64_t)n * ((Hs + TH - 1) / TH) < (1ll << 31)) {
+      const int gridf = n * ((Hs + TH - 1) / TH);
+      if (c == 128)
+        hipLaunchKernelGGL(c1_scatter_fused_kernel<4>, dim3(gridf), dim3(256), lds_f, st, (const char*)X, w, bias, img, img2, Hs, Ws, TH, ldx, coffx, relu_in,
+                           x2, ld2, sc2, sh2, fa, use_fa, post, out_scale);
+      else
+        hipLaunchKernelGGL(c1_scatter_fused_kernel<2>, dim3(gridf), dim3(256), lds_f, st, (const char*)X, w, bias, img, img2, Hs, Ws, TH, ldx, coffx, relu_in,
+                           x2, ld2, sc2, sh2, fa, use_fa, post, out_scale);
+      GI_LAUNCH_CHECK();
+      return GI_OK;
+    }
     if (c == 128)
-      hipLaunchKernelGGL(c1_col_kernel<4>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in, x2, ld2, sc2, sh2);
+      hipLaunchKernelGGL(c1_col_kernel<4>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in, x2, ld2, sc2, sh2, fa, use_fa);
     else
-      hipLaunchKernelGGL(c1_col_kernel<2>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in, x2, ld2, sc2, sh2);
+      hipLaunchKernelGGL(c1_col_kernel<2>, dim3(grid), dim3(256), 0, st, (const char*)X, w, (half_t*)col_scratch, P, ldx, coffx, relu_in, x2, ld2, sc2, sh2, fa, use_fa);
     GI_LAUNCH_CHECK();
     hipLaunchKernelGGL(c1_col2im_kernel, dim3(grid_for(P, 256, 256 * 8)), dim3(256), 0, st, (const half_t*)col_scratch, bias, img, img2, n, Hs,
                        Ws, post, out_scale);
@@ -1497,11 +1682,17 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
   GI_LAUNCH_CHECK();
   if (a.dw5) {
     dim3 g((16 * (a.c / epc) + 255) / 256, a.n, Ph >= 8 ? 2 : 1);
+    const int nparts = a.n * (int)g.z;
+    float* part = (a.scratch && a.scratch_bytes >= (int64_t)nparts * 16 * a.c * 4) ? a.scratch : nullptr;
     if (dtype == GI_F16)
-      hipLaunchKernelGGL(head_wgrad_kernel<half_t>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
+      hipLaunchKernelGGL(head_wgrad_kernel<half_t>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c, part);
     else
-      hipLaunchKernelGGL(head_wgrad_kernel<float>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c);
+      hipLaunchKernelGGL(head_wgrad_kernel<float>, g, dim3(256), 0, st, a.dh, (const char*)a.a4, a.dw5, a.Hh, a.Wh, a.c, part);
     GI_LAUNCH_CHECK();
+    if (part) {
+      hipLaunchKernelGGL(head_wgrad_sum_kernel, dim3((16 * a.c + 255) / 256), dim3(256), 0, st, part, nparts, a.dw5, 16 * a.c);
+      GI_LAUNCH_CHECK();
+    }
   }
   return GI_OK;
 }

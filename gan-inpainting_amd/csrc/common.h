@@ -23,7 +23,7 @@ void gi_set_error(const char* fmt, ...);
 // once per process), else the default. include/ganinpaint.h documents each; tests/test_options_gpu.py runs every alternative.
 enum gi_opt_id {
   GI_OPT_IGEMM5 = 0, GI_OPT_IGEMM6, GI_OPT_IGEMM7, GI_OPT_IGEMM_FIXUP, GI_OPT_IGEMM_VARIANT, GI_OPT_BN_ACC, GI_OPT_FUSE_HEAD,
-  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_COUNT
+  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_COUNT
 };
 int gi_opt(int id);
 // name of the GEMM / weight-gradient kernel a dispatcher has just launched (gi_debug_last_kernel: tests assert which kernel
@@ -214,7 +214,9 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
 // col_scratch (fp16 path): >= n*Hs*Ws*16 halves; null selects the register-reduction kernel
 // Fused producer for the upper half of a c1 kernel's input channels: relu(fma(x2, scale, shift)) of a dense raw tensor
 // (the BatchNorm + ReLU of the last decoder level), instead of reading that half from X.
-struct C1Affine { const void* x2; int ld2; const float* scale; const float* shift; };
+struct BnAccArgs;
+struct C1Affine { const void* x2; int ld2; const float* scale; const float* shift;
+                  const BnAccArgs* bn = nullptr; };   // non-null (op_c1_scatter): scale / shift are DERIVED by the kernel from the exact accumulators and stored there
 // the 4-channel head of a narrow generator (UnetGenerator(1, 4, 7, ngf=32), fp16, 128 input channels): col GEMM with 64 rows + overlap-add
 // with bias and tanh into (n,4,2Hs,2Ws) fp32 (out2: a second copy, may be null); input gradient of the head from the (n,4,2Hs,2Ws) gradient
 bool op_c1_head4_ok(int dtype, int c, int out_c, int Ws, int ldx, int coffx);
@@ -267,8 +269,11 @@ struct IgemmFold {
 };
 // finalize + normalise + activation (+ dropout) in ONE pass: no launch between the GEMM and this one. drop_mask non-null
 // with drop_p > 0: the keep-mask is drawn in the pass (seed drop_seed) and stored there; drop_p == 0: the mask is read.
+// side (optional): an unrelated device copy of side_bytes (a multiple of 16) carried by the same launch: the pass is bound by its
+// launch and first-load latencies, not by bandwidth, so up to a few MB ride along for free (the generator's saved input)
 int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy, int act,
-                    uint8_t* drop_mask, float drop_scale, uint64_t drop_seed, float drop_p, const BnAccArgs& b);
+                    uint8_t* drop_mask, float drop_scale, uint64_t drop_seed, float drop_p, const BnAccArgs& b,
+                    const void* side_src = nullptr, void* side_dst = nullptr, int64_t side_bytes = 0);
 // pg in (0, pixels): two BatchNorm populations, pixels >= pg use scale/shift + gstride
 int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy,
                 const float* scale, const float* shift, int act, const uint8_t* drop_mask, float drop_scale,

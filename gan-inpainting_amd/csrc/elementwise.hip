@@ -126,8 +126,17 @@ template <typename T, bool G2, bool FUSED>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, int64_t pixels, int c, int ldy, int coffy,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int act, uint8_t* drop, float drop_scale, int64_t pg, int gstride,
-                                                       BnAccP fa, uint64_t drop_seed, uint32_t drop_thresh) {
+                                                       BnAccP fa, uint64_t drop_seed, uint32_t drop_thresh,
+                                                       const u4_t* side_src, u4_t* side_dst, int64_t side_chunks) {
   constexpr int EPC = 16 / (int)sizeof(T);
+  // side copy (op_bn_apply_acc): this thread's 16-byte chunks are requested first and stored after the pass's own first loads
+  u4_t sc_[2] = {u4_t{0u, 0u, 0u, 0u}, u4_t{0u, 0u, 0u, 0u}};
+  const int64_t sid = (int64_t)blockIdx.x * 256 + threadIdx.x, sstride = (int64_t)gridDim.x * 256;
+  if (side_chunks > 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (sid + u * sstride < side_chunks) sc_[u] = side_src[sid + u * sstride];
+  }
   const int cpp = c / EPC;
   const int lg = 31 - __builtin_clz(cpp);
   const int64_t total = pixels * cpp;
@@ -143,6 +152,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
   u4_t r[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) r[u] = full ? *(const u4_t*)(x + (((gid + u * stride) >> lg) * c + cc * EPC) * esz) : u4_t{0u, 0u, 0u, 0u};
+  if (side_chunks > 0) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (sid + u * sstride < side_chunks) side_dst[sid + u * sstride] = sc_[u];
+    for (int64_t i = sid + 2 * sstride; i < side_chunks; i += sstride) side_dst[i] = side_src[i];
+  }
   float sc[EPC], sh[EPC], sc1[G2 ? EPC : 1], sh1[G2 ? EPC : 1];
   if constexpr (FUSED) {
     extern __shared__ __attribute__((aligned(16))) float aff[];   // [groups][2][c]
@@ -495,21 +510,25 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_kernel(BwdP p) {
     const int c = p.c;
     for (int ch = threadIdx.x; ch < c; ch += 256)
       for (int g = 0; g < NG; ++g) {
+        const int so = g * p.stat_stride + ch;
+        // (parameter loads first: they and the accumulator words are one memory round trip, not two)
+        const float iv = p.inv[so], gam = p.gamma[ch], mu = p.mean[so];
+        const float fsc = p.scale ? p.scale[so] : 0.f, fsh = p.scale ? p.shift[so] : 0.f;
         float s1 = 0.f, s2 = 0.f;
         if (p.acc) {
-          s1 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 0, ch);
-          s2 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 1, ch);
+          double t1, t2;
+          gi_stat_read2(p.acc, c, p.acc_reps, g, ch, t1, t2);
+          s1 = (float)t1;
+          s2 = (float)t2;
         }
-        const int so = g * p.stat_stride + ch;
-        const float iv = p.inv[so];
-        const float a1 = p.gamma[ch] * iv;
+        const float a1 = gam * iv;
         const float a2 = -a1 * iv * s2 * p.invM;
         float* o = coef + (int64_t)g * 5 * c;
         o[ch] = a1;
         o[c + ch] = a2;
-        o[2 * c + ch] = -a1 * s1 * p.invM - a2 * p.mean[so];
-        o[3 * c + ch] = p.scale ? p.scale[so] : 0.f;
-        o[4 * c + ch] = p.scale ? p.shift[so] : 0.f;
+        o[2 * c + ch] = -a1 * s1 * p.invM - a2 * mu;
+        o[3 * c + ch] = fsc;
+        o[4 * c + ch] = fsh;
         if (blockIdx.x == 0) {     // parameter gradients accumulate population by population, as separate calls would
           if (p.dbeta) p.dbeta[ch] += s1 * p.inv_loss_scale;
           if (p.dgamma) p.dgamma[ch] += s2 * p.inv_loss_scale;
@@ -611,21 +630,24 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_acc_kernel(BwdP p) {
     if (gid0 + u * stride < total) load(gid0 + u * stride, cur[u]);
   for (int ch = threadIdx.x; ch < c; ch += 256)
     for (int g = 0; g < NG; ++g) {
+      const int so = g * p.stat_stride + ch;
+      const float iv = p.inv[so], gam = p.gamma[ch], mu = p.mean[so];
+      const float fsc = p.scale ? p.scale[so] : 0.f, fsh = p.scale ? p.shift[so] : 0.f;
       float s1 = 0.f, s2 = 0.f;
       if (p.acc) {
-        s1 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 0, ch);
-        s2 = (float)gi_stat_read(p.acc, c, p.acc_reps, g, 1, ch);
+        double t1, t2;
+        gi_stat_read2(p.acc, c, p.acc_reps, g, ch, t1, t2);
+        s1 = (float)t1;
+        s2 = (float)t2;
       }
-      const int so = g * p.stat_stride + ch;
-      const float iv = p.inv[so];
-      const float a1 = p.gamma[ch] * iv;
+      const float a1 = gam * iv;
       const float a2 = -a1 * iv * s2 * p.invM;
       float* o = coef + (int64_t)g * 5 * c;
       o[ch] = a1;
       o[c + ch] = a2;
-      o[2 * c + ch] = -a1 * s1 * p.invM - a2 * p.mean[so];
-      o[3 * c + ch] = p.scale ? p.scale[so] : 0.f;
-      o[4 * c + ch] = p.scale ? p.shift[so] : 0.f;
+      o[2 * c + ch] = -a1 * s1 * p.invM - a2 * mu;
+      o[3 * c + ch] = fsc;
+      o[4 * c + ch] = fsh;
       if (blockIdx.x == 0) {     // parameter gradients accumulate population by population, as separate calls would
         if (p.dbeta) p.dbeta[ch] += s1 * p.inv_loss_scale;
         if (p.dgamma) p.dgamma[ch] += s2 * p.inv_loss_scale;
@@ -1386,7 +1408,7 @@ int op_bn_apply(hipStream_t st, int dtype, const void* x, void* y, int64_t pixel
   const bool g2 = pg > 0 && pg < pixels;
   GI_REQUIRE(!g2 || scale, "bn_apply: two groups need scale/shift");
   BnAccP fa = {};
-#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G, false>), dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, (uint8_t*)drop_mask, drop_scale, pg, gstride, fa, (uint64_t)0, (uint32_t)0)
+#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G, false>), dim3(grid), dim3(256), 0, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, scale, shift, act, (uint8_t*)drop_mask, drop_scale, pg, gstride, fa, (uint64_t)0, (uint32_t)0, (const u4_t*)nullptr, (u4_t*)nullptr, (int64_t)0)
   if (dtype == GI_F16) { if (g2) GI_BN_APPLY(half_t, true); else GI_BN_APPLY(half_t, false); }
   else { if (g2) GI_BN_APPLY(float, true); else GI_BN_APPLY(float, false); }
 #undef GI_BN_APPLY
@@ -1406,7 +1428,9 @@ int op_bn_finalize_acc(hipStream_t st, int c, const BnAccArgs& b) {
 }
 
 int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t pixels, int c, int ldy, int coffy, int act,
-                    uint8_t* drop_mask, float drop_scale, uint64_t drop_seed, float drop_p, const BnAccArgs& b) {
+                    uint8_t* drop_mask, float drop_scale, uint64_t drop_seed, float drop_p, const BnAccArgs& b,
+                    const void* side_src, void* side_dst, int64_t side_bytes) {
+  GI_REQUIRE(side_bytes % 16 == 0 && (side_bytes == 0 || (side_src && side_dst)), "bn_apply_acc: side copy of %lld bytes", (long long)side_bytes);
   const int epc = dtype == GI_F16 ? 8 : 4;
   GI_REQUIRE(c % epc == 0 && gi_is_pow2(c / epc) && c / epc <= 256, "bn_apply_acc: c=%d", c);
   GI_REQUIRE(b.groups == 1 || b.groups == 2, "bn_apply_acc: groups=%d", b.groups);
@@ -1419,7 +1443,7 @@ int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t p
   fill_acc_params(fa, b);
   const size_t lds = (size_t)b.groups * 2 * c * sizeof(float);
   const uint32_t thresh = drop_p > 0.f ? dropout_thresh(drop_p) : 0u;
-#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G, true>), dim3(grid), dim3(256), lds, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, (const float*)nullptr, (const float*)nullptr, act, drop_mask, drop_scale, (int64_t)b.count, 0, fa, drop_seed, thresh)
+#define GI_BN_APPLY(T, G) hipLaunchKernelGGL((bn_apply_kernel<T, G, true>), dim3(grid), dim3(256), lds, st, (const char*)x, (char*)y, pixels, c, ldy, coffy, (const float*)nullptr, (const float*)nullptr, act, drop_mask, drop_scale, (int64_t)b.count, 0, fa, drop_seed, thresh, (const u4_t*)side_src, (u4_t*)side_dst, side_bytes / 16)
   if (dtype == GI_F16) { if (g2) GI_BN_APPLY(half_t, true); else GI_BN_APPLY(half_t, false); }
   else { if (g2) GI_BN_APPLY(float, true); else GI_BN_APPLY(float, false); }
 #undef GI_BN_APPLY

@@ -403,6 +403,15 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   }
   __syncthreads();
   if (!s_last) return;
+  // Everything the column finisher needs from memory is requested at once - its first 16 raw rows, the accumulator words and the
+  // layer's parameters are independent loads - because each dependent round trip costs ~2 us while the other CUs stream weights
+  // (first version: accumulators, then parameters, then two batches of eight rows, one after the other: +12 us per layer).
+  constexpr int RPP = 256 / CPRO, NR = 16;   // rows per pass of the workgroup; loads in flight per thread
+  const int ch0 = n0 + oc * 8;
+  auto row_off = [&](int r) -> unsigned { return r < out_pixels ? (unsigned)(r * p.ldout + p.coffout + ch0) * 2u : 0x80000000u; };   // beyond: zeros
+  u4_t raw[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rsO, row_off(tid / CPRO + k * RPP), 0, 16);   // sc1
   float* aff = (float*)smem;   // [2][BN]: scale, shift of this column (the staged tile has been stored)
   if (tid < BN) {
     float sc, sh;
@@ -418,21 +427,18 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   float fsc[8], fsh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { fsc[e] = aff[oc * 8 + e]; fsh[e] = aff[BN + oc * 8 + e]; }
-  constexpr int RPP = 256 / CPRO, NR = 8;   // rows per pass of the workgroup; loads in flight per thread
-  const int ch0 = n0 + oc * 8;
 #pragma unroll 1
   for (int r0 = tid / CPRO; r0 < out_pixels; r0 += RPP * NR) {
-    u4_t raw[NR];
+    u4_t nxt[NR];
+    const bool more = r0 + RPP * NR < out_pixels;
+    if (more) {
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const int r = r0 + k * RPP;
-      const unsigned o = r < out_pixels ? (unsigned)(r * p.ldout + p.coffout + ch0) * 2u : 0x80000000u;   // out of range: zeros
-      raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rsO, o, 0, 16);                                      // sc1
+      for (int k = 0; k < NR; ++k) nxt[k] = __builtin_amdgcn_raw_buffer_load_b128(rsO, row_off(r0 + RPP * NR + k * RPP), 0, 16);
     }
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
+    for (int k = 0; k < NR; ++k) {   // (no `break` in here: it would keep the loop rolled and send raw[] to scratch memory)
       const int r = r0 + k * RPP;
-      if (r >= out_pixels) break;
+      if (r < out_pixels) {
       const h8_t h = __builtin_bit_cast(h8_t, raw[k]);
       float v[8];
 #pragma unroll
@@ -461,6 +467,11 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o8[e] = (half_t)v[e];
       *(h8_t*)(p.fdst + ((int64_t)r * p.flddst + p.fcoffdst + ch0) * 2) = o8;
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) raw[k] = nxt[k];
     }
   }
 }

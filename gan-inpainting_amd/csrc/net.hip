@@ -673,7 +673,8 @@ void bn_acc_commit(gi_net* net, int slot, const BN& b, const StatPlan& sp) {
 // stored at `drop`; otherwise `drop` (if any) is read.
 int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixels, int ntiles, void* dst, int ldy,
                int coffy, int act, const uint8_t* drop, float drop_scale, int train, bool apply = true,
-               const StatPlan* sp = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0) {
+               const StatPlan* sp = nullptr, float drop_p = 0.f, uint64_t drop_seed = 0,
+               const void* side_src = nullptr, void* side_dst = nullptr, int64_t side_bytes = 0) {   // side copy: accumulator path only
   hipStream_t st = net->ctx->stream;
   const int g = net->kind == 1 ? net->bn_groups : 1;
   const int64_t pg = pixels / g;
@@ -681,7 +682,8 @@ int bn_forward(gi_net* net, int slot, const BN& b, const void* raw, int64_t pixe
   if (sp && sp->use) {
     const BnAccArgs a = bn_acc_args(net, slot, b, *sp, pg, g);
     bn_acc_commit(net, slot, b, *sp);
-    if (apply) return op_bn_apply_acc(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, act, (uint8_t*)drop, drop_scale, drop_seed, drop_p, a);
+    if (apply) return op_bn_apply_acc(st, net->dtype, raw, dst, pixels, b.c, ldy, coffy, act, (uint8_t*)drop, drop_scale, drop_seed, drop_p, a,
+                                      side_src, side_dst, side_bytes);
     return op_bn_finalize_acc(st, b.c, a);
   }
   // the GEMM epilogue's partial rows can be split between the groups when a group is a whole number of tiles
@@ -1030,10 +1032,12 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   const bool fuse_u2 = nd >= 3 && net->out_c == 1 && net->fuse_head && op_c1_affine_ok(dt, 2 * net->ch[1], net->Wk[1], 2 * net->ch[1], 0);
   net->slot_fused_u2[s] = fuse_u2 ? 1 : 0;
   auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
-  GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   // d1: Conv2d(1->ngf) then the next block's in-place LeakyReLU (networks.py:287): the skip IS lrelu(x)
   GI_TRY(op_c1_gather(st, dt, x, net->params + net->conv[1].w_off, C(1), n, net->Hk[1], net->Wk[1], net->ch[1], 2 * net->ch[1], 0,
                       GI_ACT_LRELU, 1.f));
+  // the copy of the input that d1's weight gradient reads (8.4 MB at the headline shape) rides in d2's normalisation pass
+  // (bn_forward's side copy); where that pass does not exist, a device copy
+  bool x_saved = false;
   for (int k = 2; k <= nd; ++k) {
     const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
     int nt = 0;
@@ -1051,13 +1055,19 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), R, net->ch[k],
                    net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE, true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp, nullptr,
                    (sp.use && dt == GI_F16) ? &fold : nullptr, &folded));
-      if (folded) bn_acc_commit(net, s, net->dnorm[k], sp);
-      else GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train, true, &sp));
+      if (folded) { bn_acc_commit(net, s, net->dnorm[k], sp); continue; }
+      const bool side = !x_saved && k == 2 && sp.use && ((int64_t)n * H * W * 4) % 16 == 0;
+      GI_TRY(bn_forward(net, s, net->dnorm[k], R, pix, nt, C(k), 2 * net->ch[k], 0, GI_ACT_LRELU, nullptr, 1.f, train, true, &sp, 0.f, 0,
+                        side ? x : nullptr, side ? net->slot(s, net->oX) : nullptr, side ? (int64_t)n * H * W * 4 : 0));
+      if (side) x_saved = true;
     } else {  // innermost: no down-norm; uprelu follows directly (networks.py:299-305)
       GI_TRY(igemm(net, 0, C(k - 1), net->ch[k - 1], 2 * net->ch[k - 1], 0, packed_ptr(net, net->conv[k]), net->slot(s, net->oE),
                    net->ch[k], net->ch[k], 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_RELU, false, nullptr));
     }
   }
+  BnAccArgs u2_acc;
+  bool u2_deferred = false;
+  if (!x_saved) GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   for (int k = nd; k >= 2; --k) {
     const void* in = (k == nd) ? (const void*)net->slot(s, net->oE) : C(k);
     const int cin = net->up[k].ca;
@@ -1100,6 +1110,12 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     // relu(u) so that consumers need the ReLU on the skip half only; [u > 0] masks are unchanged
     // the last decoder level feeds only the single-channel head: its BatchNorm + ReLU is applied by the head's
     // kernels while they read the raw tensor (C1Affine), so the upper half of C(1) is never written
+    if (fused && sp.use && net->out_c == 1) {   // the head's first kernel derives scale / shift itself (C1Affine::bn): no finalize launch
+      u2_acc = bn_acc_args(net, s, net->unorm[k], sp, opix, 1);
+      bn_acc_commit(net, s, net->unorm[k], sp);
+      u2_deferred = true;
+      continue;
+    }
     GI_TRY(bn_forward(net, s, net->unorm[k], U, opix, nt, C(k - 1), 2 * co, co, GI_ACT_RELU, drop,
                       drop ? 1.f / (1.f - net->dropout_p) : 1.f, train, !fused, &sp, drop_p, drop_seed));
   }
@@ -1109,6 +1125,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
     if (fuse_u2) {
       BNPtrs p = bn_ptrs(net, s, net->unorm[2]);
       aff.x2 = net->slot(s, net->oU[2]); aff.ld2 = net->ch[1]; aff.scale = p.scale; aff.shift = p.shift;
+      if (u2_deferred) aff.bn = &u2_acc;
     }
     GI_TRY(op_c1_scatter(st, dt, C(1), net->params + net->up[1].w_off, net->params + net->up[1].bias_off, osave, n, net->Hk[1],
                          net->Wk[1], 2 * net->ch[1], 2 * net->ch[1], 0, 1, 1, 1.f, net->shared(net->oCol), y, fuse_u2 ? &aff : nullptr));

@@ -46,26 +46,59 @@ __device__ __forceinline__ void gi_stat_add(unsigned long long* base, int c, int
   atomicAdd(lo, (unsigned long long)l);
 }
 
-// total of quantity q of channel ch over `reps` replicas. COHERENT: the adds came from other workgroups of the SAME launch; the
-// words are then read with agent-scope relaxed atomic loads (sc1), not plain ones that this CU's L1 may serve
-template <bool COHERENT = false>
-__device__ __forceinline__ double gi_stat_read(const unsigned long long* base, int c, int reps, int group, int q, int ch) {
-  unsigned long long hi = 0, lo = 0, bad = 0;
-  for (int r = 0; r < reps; ++r) {
-    const unsigned long long* p = base + ((long long)(r * 2 + group) * GI_STAT_WORDS + 2 * q) * c + ch;
-    unsigned long long l, h0;
-    if constexpr (COHERENT) {
-      l = __hip_atomic_load(p + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      h0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      l = p[c];
-      h0 = p[0];
-    }
-    hi += h0;
-    lo += l & 0x7FFFFFFFFFFFFFFFull;
-    bad |= l >> 63;
-  }
+// Totals of channel ch over `reps` replicas. COHERENT: the adds came from other workgroups of the SAME launch; the words are then
+// read with agent-scope relaxed atomic loads (sc1), not plain ones that this CU's L1 may serve.
+// Every word is requested before any is used: the loads of all GI_STAT_MAXREP replicas go out unconditionally (replicas beyond
+// `reps` re-read the last one and are masked out afterwards; a load under a run-time condition would be branched around and
+// waited for one by one). The first form looped over the replicas with a wait per iteration - up to eight dependent memory round
+// trips at the head of every normalisation pass, ~2 us each while other CUs stream.
+template <bool COHERENT>
+__device__ __forceinline__ unsigned long long gi_stat_word(const unsigned long long* p) {
+  if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+__device__ __forceinline__ double gi_stat_total(unsigned long long hi, unsigned long long lo, unsigned long long bad) {
   const long long h = (long long)hi;
   if (bad || h > (1ll << 62) || h < -(1ll << 62)) return __builtin_nan("");   // (2^62 units of 2^-8 = 2^54)
   return ((double)h * 4294967296.0 + (double)lo) * 9.094947017729282e-13;   // * 2^-40
+}
+// both quantities of a channel at once (sixteen independent loads)
+template <bool COHERENT = false>
+__device__ __forceinline__ void gi_stat_read2(const unsigned long long* base, int c, int reps, int group, int ch, double& q0, double& q1) {
+  unsigned long long w[GI_STAT_MAXREP][GI_STAT_WORDS];
+#pragma unroll
+  for (int r = 0; r < GI_STAT_MAXREP; ++r) {
+    const int rr = r < reps ? r : reps - 1;
+    const unsigned long long* p = base + ((long long)(rr * 2 + group) * GI_STAT_WORDS) * c + ch;
+#pragma unroll
+    for (int k = 0; k < GI_STAT_WORDS; ++k) w[r][k] = gi_stat_word<COHERENT>(p + (long long)k * c);
+  }
+  unsigned long long hi0 = 0, lo0 = 0, hi1 = 0, lo1 = 0, bad0 = 0, bad1 = 0;
+#pragma unroll
+  for (int r = 0; r < GI_STAT_MAXREP; ++r) {
+    const unsigned long long m = r < reps ? ~0ull : 0ull;
+    hi0 += w[r][0] & m; lo0 += w[r][1] & m & 0x7FFFFFFFFFFFFFFFull; bad0 |= (w[r][1] & m) >> 63;
+    hi1 += w[r][2] & m; lo1 += w[r][3] & m & 0x7FFFFFFFFFFFFFFFull; bad1 |= (w[r][3] & m) >> 63;
+  }
+  q0 = gi_stat_total(hi0, lo0, bad0);
+  q1 = gi_stat_total(hi1, lo1, bad1);
+}
+// total of quantity q of channel ch
+template <bool COHERENT = false>
+__device__ __forceinline__ double gi_stat_read(const unsigned long long* base, int c, int reps, int group, int q, int ch) {
+  unsigned long long w[GI_STAT_MAXREP][2];
+#pragma unroll
+  for (int r = 0; r < GI_STAT_MAXREP; ++r) {
+    const int rr = r < reps ? r : reps - 1;
+    const unsigned long long* p = base + ((long long)(rr * 2 + group) * GI_STAT_WORDS + 2 * q) * c + ch;
+    w[r][0] = gi_stat_word<COHERENT>(p);
+    w[r][1] = gi_stat_word<COHERENT>(p + c);
+  }
+  unsigned long long hi = 0, lo = 0, bad = 0;
+#pragma unroll
+  for (int r = 0; r < GI_STAT_MAXREP; ++r) {
+    const unsigned long long m = r < reps ? ~0ull : 0ull;
+    hi += w[r][0] & m; lo += w[r][1] & m & 0x7FFFFFFFFFFFFFFFull; bad |= (w[r][1] & m) >> 63;
+  }
+  return gi_stat_total(hi, lo, bad);
 }

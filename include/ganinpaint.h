@@ -66,7 +66,9 @@ int gi_version(void);
  *   GI_WGRAD2 [1]         0: weight gradients on the register-staged kernel (wgrad.hip) only
  *   GI_WGRAD3 [1]         0: the unpipelined two-tap-row weight-gradient kernel instead of wgrad3
  *   GI_BN_FOLD [1]        0: the BatchNorm + activation (+ dropout) pass of the generator's small layers as its own launch instead of
- *                         inside the GEMM that produces the layer (igemm7's last finisher per channel column); bit-identical results */
+ *                         inside the GEMM that produces the layer (igemm7's last finisher per channel column); bit-identical results
+ *   GI_C1_FUSED [1]       0: the single-channel transposed convolution (generator u1, d1's input gradient) as two launches through a
+ *                         col tensor in memory instead of one launch with the col rows in LDS; bit-identical results */
 int gi_set_option(const char* name, int value);
 int gi_get_option(const char* name, int* value);
 /* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.

@@ -46,11 +46,16 @@ def unet_case(seed, nd, N, HW, norm="batch"):
     return {"kind": "unet", "P": P, "x": x, "R": R, "masks": masks, "nd": nd, "norm": norm, "N": N, "HW": HW}
 
 
-def patchgan_case(seed, HW, N, sigmoid):
+def patchgan_case(seed, HW, N, sigmoid, groups=1):
+    """groups = 2: the N images are two consecutive BatchNorm populations of N / 2, i.e. two critic calls on the same parameters
+    (wgan_l1.py:134-135 D(ground), D(inpainted)) whose gradients accumulate; the second half is shifted and scaled so that the
+    two populations have different statistics."""
     P = _p.make_patchgan_params(seed, HW, HW)
     ground, _ = _p.synth_batch(seed + 3, N, HW, HW)
+    if groups == 2:
+        ground[N // 2:] = ground[N // 2:] * 0.5 + 0.2
     r = torch.from_numpy(np.random.Generator(np.random.PCG64(seed + 5)).standard_normal(size=(N, 1), dtype=np.float32))
-    return {"kind": "patchgan", "P": P, "x": torch.from_numpy(ground), "R": r, "sigmoid": sigmoid, "N": N, "HW": HW}
+    return {"kind": "patchgan", "P": P, "x": torch.from_numpy(ground), "R": r, "sigmoid": sigmoid, "N": N, "HW": HW, "groups": groups}
 
 
 def tap_shapes(case):
@@ -78,6 +83,16 @@ def run(case, dtype, taps=None, flips=None, backward=True):
     with torch.set_grad_enabled(backward):
         if case["kind"] == "unet":
             y = _o.unet_forward(OP, x, case["nd"], True, case["masks"], norm=case["norm"], taps=taps, flips=flips)
+        elif case.get("groups", 1) == 2:   # two calls, one per population, in the reference's order (running statistics move twice)
+            h = case["N"] // 2
+            ys, tt = [], [{}, {}]
+            for g in range(2):
+                fl = {k: v[g * h:(g + 1) * h] for k, v in flips.items()} if flips else None
+                ys.append(_o.patchgan_forward(OP, x[g * h:(g + 1) * h], case["sigmoid"], True, taps=tt[g] if taps is not None else None, flips=fl))
+            y = torch.cat(ys)
+            if taps is not None:
+                for k in tt[0]:
+                    taps[k] = torch.cat([tt[0][k], tt[1][k]])
         else:
             y = _o.patchgan_forward(OP, x, case["sigmoid"], True, taps=taps, flips=flips)
         if backward:

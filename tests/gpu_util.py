@@ -77,6 +77,11 @@ def check_grads_vs_kink_reference(what, net, case, dx, dtype, tol_max, tol_l2=No
     print(f"{what}: {rep['units']} kink inputs, {rep['at_risk']} within the band, {rep['flipped']} decided by the HIP forward, "
           f"{rep['outside']} disagreements outside the band (worst {rep['outside_worst']:.2f} band widths)")
     assert rep["outside"] == 0, f"{what}: {rep['outside']} kink decisions differ from the oracle's outside the rounding band"
+    # the band only says where a decision MAY differ; a forward that differs on a large share of the units inside it is wrong all
+    # the same (fp16's band holds several percent of all units: without this bound the test could not see that). Measured on
+    # MI355X: fp32 <= 10 units per case, fp16 3e-4 of the units (round 3, gpurun_out/r3_t1.log).
+    share = rep["flipped"] / max(rep["units"], 1)
+    assert share <= (2e-3 if fp16 else 1e-4), f"{what}: {rep['flipped']} of {rep['units']} kink decisions differ from the oracle's ({share:.2e})"
     bad, worst = [], (0.0, "")
     items = [(n, p.grad.detach().cpu()) for n, p in net.named_parameters() if n not in skip]
     if dx is not None:

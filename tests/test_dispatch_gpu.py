@@ -223,32 +223,68 @@ def test_critic_dgrad_with_fused_batchnorm_backward_reduction(layer, family):
         assert err <= 2e-4, f"critic {layer} population {p}: fused BatchNorm-backward sums off by {err:.2e} of sum|dz|"
 
 
-# weight gradients: the critic's conv2..conv4 at n = 64 (wgrad3<4>: 4 x 16 pixel tiles) and the generator's u5 at n = 32
-# (8 x 8 maps, wgrad3<3>, two pixel-range splits)
-WGRAD = [
-    ("critic conv2", 64, 64, 128, 64, 0, "wgrad3<4>"),
-    ("critic conv3", 64, 32, 256, 128, 0, "wgrad3<4>"),
-    ("critic conv4", 64, 16, 512, 256, 0, "wgrad3<4>"),
-    ("u5", 32, 8, 1024, 512, 1, "wgrad3<3>"),
-    ("d5", 32, 8, 512, 512, 0, "wgrad<f16>"),
-    ("u6", 32, 4, 1024, 512, 1, "wgrad<f16>"),
+# The generator's input gradients at n = 32 as unet_backward issues them (csrc/net.hip): a decoder level's is the 4x4 / s2 gather on
+# its ConvTranspose2d weights (u2: 64 -> 256 channels onto the 64x64 grid, u3, u4), an encoder level's the sub-pixel phases on its
+# Conv2d weights (d3: 256 -> 128 channels onto the 64x64 grid, d4); networks.py:285-309 builds the layers.
+DGRAD = [
+    ("u2 dgrad", "conv", 32, 128, 64, 256, "igemm6<0,128>"),
+    ("u3 dgrad", "conv", 32, 64, 128, 512, "igemm6<0,128>"),
+    ("u4 dgrad", "conv", 32, 32, 256, 1024, "igemm6<0,128>"),
+    ("d3 dgrad", "convT", 32, 32, 256, 128, "igemm6<1,128>"),
+    ("d4 dgrad", "convT", 32, 16, 512, 256, "igemm6<1,128>"),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD, ids=[c[0] for c in DGRAD])
+def test_generator_input_gradients_at_headline_shapes(case, family):
+    name, kind, n, HW, cin, cout, kernel = case
+    if kind == "conv":
+        wgs = n * (HW // 2) ** 2 // 256 * (cout // 128)
+        out, ref = _conv(n, HW, HW, cin, cout, seed=61)
+    else:
+        wgs = n * HW * HW // 256 * (4 * cout // 128)
+        out, ref = _convT(n, HW, HW, cin, cout, seed=63)
+    assert B.last_kernel() == family(kernel, wgs), (name, B.last_kernel(), wgs)
+    ok, msg = report(f"{name} [{B.last_kernel()}]", from_nhwc(out), ref, TOL)
+    assert ok, msg
+
+
+# weight gradients: the critic's conv2..conv4 at n = 64 (wgrad3<4>: 4 x 16 pixel tiles) and the generator's layers at n = 32 with
+# the operands unet_backward passes (csrc/net.hip): a decoder level's S is the whole concat buffer read through the parent's in-place
+# ReLU (relu_S = 1, networks.py:289), an encoder level's L is the lower half of a concat buffer, i.e. rows 2 * cb channels apart
+# (the upper half is NaN here: it must not be read). u5: 8 x 8 maps, wgrad3<3>, two pixel-range splits.
+WGRAD = [   # (name, n, Hs, ca, cb, relu_S, ldL / cb, kernel)
+    ("critic conv2", 64, 64, 128, 64, 0, 1, "wgrad3<4>"),
+    ("critic conv3", 64, 32, 256, 128, 0, 1, "wgrad3<4>"),
+    ("critic conv4", 64, 16, 512, 256, 0, 1, "wgrad3<4>"),
+    ("u2", 32, 64, 256, 64, 1, 1, "wgrad3<4>"),
+    ("u3", 32, 32, 512, 128, 1, 1, "wgrad3<4>"),
+    ("u4", 32, 16, 1024, 256, 1, 1, "wgrad3<4>"),
+    ("u5", 32, 8, 1024, 512, 1, 1, "wgrad3<3>"),
+    ("u6", 32, 4, 1024, 512, 1, 1, "wgrad<f16>"),
+    ("d2", 32, 64, 128, 64, 0, 2, "wgrad3<4>"),
+    ("d3", 32, 32, 256, 128, 0, 2, "wgrad3<4>"),
+    ("d4", 32, 16, 512, 256, 0, 2, "wgrad3<4>"),
+    ("d5", 32, 8, 512, 512, 0, 2, "wgrad3<3>"),
 ]
 
 
 @pytest.mark.parametrize("case", WGRAD, ids=[c[0] for c in WGRAD])
 def test_weight_gradients_at_headline_shapes(case):
-    name, n, Hs, ca, cb, relu_S, kernel = case
+    name, n, Hs, ca, cb, relu_S, ldm, kernel = case
     S = quant(_rand((n, ca, Hs, Hs), 7, 0.5), F16)
     L = quant(_rand((n, cb, 2 * Hs, 2 * Hs), 8, 0.5), F16)
     ref = torch.nn.grad.conv2d_weight(L, (ca, cb, 4, 4), F.relu(S) if relu_S else S, stride=2, padding=1)
-    Sd, Ld = nhwc_dev(S, F16), nhwc_dev(L, F16)
+    Sd = nhwc_dev(S, F16)
+    Ld = torch.full((n, 2 * Hs, 2 * Hs, ldm * cb), float("nan"), dtype=torch.float16, device="cuda")
+    Ld[..., :cb] = nhwc_dev(L, F16)
     lib, ctx = B.lib(), B.get_ctx()
     nbytes = lib.gi_wgrad_s2_scratch_bytes(F16, n, Hs, Hs, ca, cb)
     ws = torch.full((max(nbytes // 4, 4),), float("nan"), dtype=torch.float32, device="cuda")
     outs = []
     for _ in range(2):
         dW = torch.full((ca, 4, 4, cb), 1.0, dtype=torch.float32, device="cuda")
-        B.check(lib.gi_wgrad_s2_ws(ctx, F16, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), n, Hs, Hs, ca, ca, cb, cb, relu_S, 1.0, B.ptr(ws), nbytes))
+        B.check(lib.gi_wgrad_s2_ws(ctx, F16, B.ptr(Sd), B.ptr(Ld), B.ptr(dW), n, Hs, Hs, ca, ca, cb, ldm * cb, relu_S, 1.0, B.ptr(ws), nbytes))
         torch.cuda.synchronize()
         outs.append(dW.clone())
     assert B.last_kernel() == kernel, (name, B.last_kernel())

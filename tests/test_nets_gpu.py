@@ -264,10 +264,11 @@ def test_unet_forward_and_gradients_are_reproducible(dtype):
             assert torch.equal(runs[0][3][k], r[3][k]), f"parameter gradient {k} differs between runs"
 
 
-@pytest.mark.parametrize("dtype", ["fp16"])
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 def test_patchgan_gradients_are_reproducible(dtype):
     """The stacked critic of the headline step (two BatchNorm populations): output, input gradient and every parameter
-    gradient bit for bit from run to run."""
+    gradient bit for bit from run to run - fp16 (the benchmarked path) and fp32 (BASELINE config 2; its head's weight gradient
+    went from float atomics to per-block partials summed in a fixed order in round 4)."""
     HW, N = 128, 8
     P = op.make_patchgan_params(901, HW, HW)
     ground, _ = op.synth_batch(902, N, HW, HW)
@@ -347,6 +348,36 @@ def test_frozen_discriminator_gives_dx_only():
     net(x).sum().backward()
     assert float(net.flat_grads().abs().max()) == 0.0
     assert float(x.grad.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+@pytest.mark.parametrize("hw,n", [(256, 8), (128, 4)], ids=["256-n8-aligned", "128-n4-column-pass"])
+def test_patchgan_two_populations_vs_oracle(dtype, hw, n):
+    """The stacked critic batch of the headline step (WGANStep(stacked=True), gi_net_set_bn_groups(2)): n images = two BatchNorm
+    populations of n / 2 in ONE launch sequence, against the oracle's TWO calls on the same parameters (wgan_l1.py:134-135:
+    D(ground), then D(inpainted); running statistics moved twice, in that order; gradients accumulated) - output, running
+    statistics, input gradient and every parameter gradient, strict per tensor with the kink-aware fp64 reference (oracle/kink.py)
+    like the single-population cases. 256x256 with n = 8: the GEMM epilogues' statistics split between the populations by tile;
+    128x128 with n = 4: a population is not a whole number of tiles (per-population column pass)."""
+    seed = 900 + hw
+    case = kink.patchgan_case(seed, hw, n, False, groups=2)
+    net = make_d(case["P"], hw, False, dtype)
+    net.zero_grad()
+    xd = case["x"].cuda()
+    y, s, g = net._forward_raw(xd, 2)
+    dx = net._backward_raw(s, g, case["R"].cuda(), True, True)
+    torch.cuda.synchronize()
+    what = f"patchgan two populations {hw} n={n} {dtype}"
+    yo, _, _, OP = kink.run(case, torch.float32, backward=False)
+    ok, msg = report(f"{what} out", y.detach().cpu(), yo, TOL_OUT[dtype])
+    assert ok, msg
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            ok, msg = report(f"{what} {k}", v.cpu(), OP[k], 1e-4 if dtype == "fp32" else 2e-2)
+            assert ok, msg
+    for _, p in net.named_parameters():   # _backward_raw accumulated into the flat gradient buffer: expose it as .grad
+        assert p.grad is not None
+    check_grads_vs_kink_reference(what, net, case, dx, dtype, TOL_GRAD[dtype], TOL_GRAD_L2[dtype])
 
 
 @pytest.mark.parametrize("dtype,hw,n", [("fp32", 256, 2), ("fp16", 256, 4), ("fp32", 128, 2)])

@@ -155,7 +155,7 @@ def _patchgan_run(dtype, seed=66, N=8, HW=128, groups=2):
     return y.detach().cpu(), dx.detach().cpu(), net.flat_grads().detach().cpu().clone(), stats
 
 
-NET_OPTIONS = [("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
+NET_OPTIONS = [("GI_BN_FOLD", 0), ("GI_C1_FUSED", 0), ("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
                ("GI_IGEMM6", 0), ("GI_WGRAD3", 0), ("GI_WGRAD2", 0), ("GI_IGEMM8", 2), ("GI_IGEMM8", 0)]
 
 
@@ -218,6 +218,18 @@ def test_folded_normalisation_is_bit_identical(N, HW, impose, option):
         assert torch.equal(u, v), f"{name}: folded vs separate pass differ, max |d| = {(u.float() - v.float()).abs().max().item():.3e}"
     for k in a[4]:
         assert torch.equal(a[4][k], b[4][k]), k
+
+
+@pytest.mark.parametrize("N,HW", [(2, 64), (4, 128), (32, 256), (2, 512)], ids=["n2-64", "n4-128", "n32-256", "n2-512"])
+def test_one_launch_u1_is_bit_identical(N, HW, option):
+    """GI_C1_FUSED (default on): the generator's last layer ConvTranspose2d(128 -> 1) + Tanh (networks.py:292-298) and d1's input
+    gradient run as ONE launch with the col rows in LDS (c1_scatter_fused_kernel) instead of c1_col + c1_col2im through a col tensor
+    in memory: same fragments, same fp16 rounding of col, same order of additions - output and input gradient must be EQUAL."""
+    a = _unet_fold_run(N, HW, False)
+    option("GI_C1_FUSED", 0)
+    b = _unet_fold_run(N, HW, False)
+    for name, u, v in zip(("first forward", "second forward", "input gradient", "parameter gradients"), a[:4], b[:4]):
+        assert torch.equal(u, v), f"{name}: one-launch u1 vs col tensor differ, max |d| = {(u.float() - v.float()).abs().max().item():.3e}"
 
 
 def test_folded_normalisation_is_dispatched_at_the_headline_shapes(option):

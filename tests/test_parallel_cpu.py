@@ -62,8 +62,35 @@ def _worker(rank, world, port, q):
     want = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.BatchNorm2d(4))
     want[1].running_mean.normal_()
     ok = ok and all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), want.state_dict().values()))
+    # fp16 wire format (GradSync(wire='fp16'), off by default): the range travels as fp16(scale * g) and comes back as fp32;
+    # values chosen exactly representable so that the SUM is exact, plus small ones that only survive thanks to the scale
+    s3 = parallel.GradSync(use_side_stream=False, wire="fp16", wire_scale=1024.0)
+    fw = torch.arange(600, dtype=torch.float32) * 2.0 ** -14 * (rank + 1)     # down to 6e-5: below fp16's normal range unscaled;
+    keep = fw.clone()                                                          # 3 * 599 < 2048: every sum is exact in fp16
+    s3.launch(fw, 0, 300, key="W")
+    s3.launch(fw, 300, 600, key="W")
+    assert torch.equal(fw, keep)            # nothing is written before wait()
+    s3.wait(key="W")
+    ok = ok and bool(torch.equal(fw, torch.arange(600, dtype=torch.float32) * 2.0 ** -14 * tot))
+    try:
+        parallel.GradSync(use_side_stream=False, wire="fp8")
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, ok))
     dist.destroy_process_group()
+
+
+def test_rendezvous_watchdog_names_the_stuck_rank():
+    """A rank whose peers never arrive does not hang: parallel.init_from_env's watchdog says which rank is stuck and the process
+    exits with code 5 (GI_RENDEZVOUS_TIMEOUT seconds; the driver's 8-GPU run then fails fast instead of timing out silently)."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import gan_inpainting_amd; from gan_inpainting_amd import parallel; "
+            "parallel.init_from_env(backend='gloo')" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="1", WORLD_SIZE="2", GI_RENDEZVOUS_TIMEOUT="3")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 5, (p.returncode, p.stderr[-400:])
+    assert "rank 1 is still in the process-group rendezvous" in p.stderr
 
 
 def test_gradsync_world2_gloo():

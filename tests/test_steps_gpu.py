@@ -26,6 +26,7 @@ LOSS_TOL = {"fp32": 2e-3, "fp16": 3e-2}
 # the tight fp16 checks are the pre-update ones (it0 losses 3e-2, single-pass gradients in
 # test_nets_gpu.py) and the parameter statistics below.
 LOSS_TOL_AFTER_ADAM = {"fp32": 1e-2, "fp16": 0.15}
+GRADFLOW_TOL_AFTER_ADAM = {"fp32": 0.15, "fp16": 0.4}
 STAT_TOL = {"fp32": 2e-4, "fp16": 2e-3}
 
 
@@ -77,8 +78,10 @@ def test_minimax_steps_vs_reference(dtype):
         ref = {n: float(v) for n, v in zip(names, fx[f"it{it}_g_grad_absmean"])}
         got = gflow.as_dict()
         assert list(got.keys()) == [n for n in names if "bias" not in n]
+        tol = (5e-3 if dtype == "fp32" else 8e-2) if it == 0 else GRADFLOW_TOL_AFTER_ADAM[dtype]   # it>0: post-Adam chaos, see LOSS_TOL_AFTER_ADAM
+        worst = max(abs(v - ref[n]) / (abs(ref[n]) + 1e-12) for n, v in got.items())
+        print(f"minimax it{it} gradient-flow worst rel {worst:.2e} (bound {tol:.2e})")
         for n, v in got.items():
-            tol = (5e-3 if dtype == "fp32" else 8e-2) if it == 0 else (0.15 if dtype == "fp32" else 0.4)   # it>0: post-Adam chaos, see LOSS_TOL_AFTER_ADAM
             assert abs(v - ref[n]) <= tol * abs(ref[n]) + 1e-12, f"it{it} absmean {n}: {v} vs {ref[n]}"
         assert relerr(abs_sums(G), fx[f"it{it}_g_param_stats"][:, 1]) <= STAT_TOL[dtype]
         assert relerr(abs_sums(D), fx[f"it{it}_d_param_stats"][:, 1]) <= STAT_TOL[dtype]
