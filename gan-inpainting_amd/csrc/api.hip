@@ -16,25 +16,29 @@ void gi_set_error(const char* fmt, ...) {
 }
 
 namespace {
-struct OptDesc { const char* name; int dflt; int value; int state; };   // state 0: unread, 1: from default / environment, 2: set by the caller
+// state 0: unread, 1: from default / environment, 2: set by the caller. value / state are relaxed atomics: two host threads that
+// drive separate contexts may read (and lazily initialise, to the same value) an option at the same time
+struct OptDesc { const char* name; int dflt; int value; int state; };
+inline int opt_load(const int& v) { return __atomic_load_n(&v, __ATOMIC_RELAXED); }
+inline void opt_store(int& v, int x) { __atomic_store_n(&v, x, __ATOMIC_RELAXED); }
 OptDesc g_opts[GI_OPT_COUNT] = {
   {"GI_IGEMM5", 7, 0, 0}, {"GI_IGEMM6", 1, 0, 0}, {"GI_IGEMM7", 1, 0, 0}, {"GI_IGEMM_FIXUP", 1, 0, 0}, {"GI_IGEMM_VARIANT", 3, 0, 0},
   {"GI_BN_ACC", 1, 0, 0}, {"GI_FUSE_HEAD", 1, 0, 0}, {"GI_HEAD_FAST", 1, 0, 0}, {"GI_BN_BWD_FUSE", 1, 0, 0}, {"GI_BN_BWD_SMALL", 512, 0, 0},
   {"GI_WGRAD2", 1, 0, 0}, {"GI_WGRAD3", 1, 0, 0}, {"GI_IGEMM8", 1, 0, 0}, {"GI_BN_FOLD", 1, 0, 0}, {"GI_C1_FUSED", 1, 0, 0},
 };
-const char* g_last_kernel = "";
+thread_local const char* g_last_kernel = "";   // per host thread: gi_debug_last_kernel never reports another thread's launch
 int g_fold_count = 0;
 }  // namespace
-void gi_note_fold() { ++g_fold_count; }
+void gi_note_fold() { __atomic_fetch_add(&g_fold_count, 1, __ATOMIC_RELAXED); }
 
 int gi_opt(int id) {
   OptDesc& o = g_opts[id];
-  if (o.state == 0) {
+  if (opt_load(o.state) == 0) {
     const char* e = getenv(o.name);
-    o.value = e ? atoi(e) : o.dflt;
-    o.state = 1;
+    opt_store(o.value, e ? atoi(e) : o.dflt);
+    __atomic_store_n(&o.state, 1, __ATOMIC_RELEASE);
   }
-  return o.value;
+  return opt_load(o.value);
 }
 void gi_note_kernel(const char* name) { g_last_kernel = name; }
 
@@ -44,8 +48,8 @@ int gi_set_option(const char* name, int value) {
   GI_REQUIRE(name, "set_option: null name");
   for (int i = 0; i < GI_OPT_COUNT; ++i)
     if (strcmp(name, g_opts[i].name) == 0) {
-      if (value < 0) g_opts[i].state = 0;      // back to the environment / default
-      else { g_opts[i].value = value; g_opts[i].state = 2; }
+      if (value < 0) opt_store(g_opts[i].state, 0);      // back to the environment / default
+      else { opt_store(g_opts[i].value, value); __atomic_store_n(&g_opts[i].state, 2, __ATOMIC_RELEASE); }
       return GI_OK;
     }
   gi_set_error("set_option: unknown option '%s'", name);
@@ -59,7 +63,7 @@ int gi_get_option(const char* name, int* value) {
   return GI_ERR_INVALID;
 }
 const char* gi_debug_last_kernel(void) { return g_last_kernel; }
-int gi_debug_fold_count(void) { return g_fold_count; }
+int gi_debug_fold_count(void) { return __atomic_load_n(&g_fold_count, __ATOMIC_RELAXED); }
 
 const char* gi_last_error(void) { return g_err; }
 int gi_version(void) { return 100; }
@@ -129,8 +133,12 @@ int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_ph
 }
 
 // the same two layers with the optional fused epilogues of IgemmArgs (what the networks pass; include/ganinpaint.h: gi_igemm_ex)
-static void apply_ex(IgemmArgs& a, const gi_igemm_ex* ex) {
-  if (!ex) return;
+static int apply_ex(IgemmArgs& a, const gi_igemm_ex* ex) {
+  if (!ex) return GI_OK;
+  // relu_cend is a HINT (IgemmArgs::relu_cend): kernels apply the input ReLU per 32- or 64-channel chunk up to it, the generic
+  // kernel to every channel - all agree only when the channels from relu_cend on are non-negative already and it is chunk-aligned
+  GI_REQUIRE(ex->relu_cend >= 0 && ex->relu_cend % 64 == 0 && ex->relu_cend <= a.cin, "igemm_ex: relu_cend=%d must be a multiple of 64 within the %d input channels",
+             ex->relu_cend, a.cin);
   a.relu_cend = ex->relu_cend;
   a.mask = ex->mask; a.ldmask = ex->ldmask; a.mask_slope = ex->mask_slope;
   a.add = ex->add; a.ldadd = ex->ldadd;
@@ -139,6 +147,7 @@ static void apply_ex(IgemmArgs& a, const gi_igemm_ex* ex) {
   a.bwd_x = ex->bwd_x; a.bwd_ldx = ex->bwd_ldx; a.bwd_scale = ex->bwd_scale; a.bwd_shift = ex->bwd_shift; a.bwd_mean = ex->bwd_mean;
   a.bwd_inv = ex->bwd_inv; a.bwd_stride = ex->bwd_stride; a.bwd_slope = ex->bwd_slope; a.bwd_acc = ex->bwd_acc; a.bwd_reps = ex->bwd_reps;
   a.bwd_pg = ex->bwd_pg;
+  return GI_OK;
 }
 static void return_ex(const IgemmArgs& a, gi_igemm_ex* ex) {
   if (!ex) return;
@@ -156,7 +165,7 @@ int gi_conv_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w_
   a.n = n; a.Hs = H / 2; a.Ws = W / 2;
   a.cin = cb; a.ldin = ldin; a.cout = ca; a.ldout = ldout;
   a.relu_in = relu_in; a.act_out = act_out;
-  apply_ex(a, ex);
+  GI_TRY(apply_ex(a, ex));
   const int rc = op_igemm(ctx->stream, dtype, 0, a);
   return_ex(a, ex);
   return rc;
@@ -172,7 +181,7 @@ int gi_convT_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w
   a.n = n; a.Hs = H; a.Ws = W;
   a.cin = ca; a.ldin = ldin; a.cout = cb; a.ldout = ldout;
   a.relu_in = relu_in; a.act_out = act_out;
-  apply_ex(a, ex);
+  GI_TRY(apply_ex(a, ex));
   const int rc = op_igemm(ctx->stream, dtype, 1, a);
   return_ex(a, ex);
   return rc;

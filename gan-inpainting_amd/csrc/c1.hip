@@ -1580,6 +1580,7 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
       hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((c * 16 + 15) / 16), dim3(256), 0, st, (const float*)part, dW, c * 16, grid);
       GI_LAUNCH_CHECK();
     }
+    gi_note_kernel(part ? "c1_wgrad_mfma" : "c1_wgrad_mfma,atomics");   // (which summation ran: fixed-order partials or float atomics)
     return GI_OK;
   }
   const int epc = dtype == GI_F16 ? 8 : 4;
@@ -1604,6 +1605,7 @@ int op_c1_wgrad(hipStream_t st, int dtype, const void* X, const float* img, floa
     hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((c * 16 + 15) / 16), dim3(256), 0, st, (const float*)part, dW, c * 16, grid);
     GI_LAUNCH_CHECK();
   }
+  gi_note_kernel(part ? "c1_wgrad" : "c1_wgrad,atomics");
   return GI_OK;
 }
 
@@ -1616,8 +1618,8 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
     const int lds = (((a.Hh * a.Wh * HT_PITCH + 3) & ~3) + 16) * 4 + 16 * 512 * 2 + 2 * 512 * 4;
     GI_REQUIRE(lds <= 160 * 1024, "head: feature map %dx%d too large", a.Hh, a.Wh);
     if (lds > 64 * 1024) {
-      static bool attr = false;
-      if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+      static GiDevOnce attr;
+      if (attr.first()) { GI_HIP(hipFuncSetAttribute((const void*)head_fwd512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     }
     // large maps with few images (512x512 inputs: 32x32 map, 64 tiles per image): slice each image over several
     // workgroups so that ~256 of them stream the activations, and finish in a second small kernel

@@ -184,7 +184,13 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
       for (int e = 0; e < EPC; ++e) { sc1[e] = scale[gstride + cc * EPC + e]; sh1[e] = shift[gstride + cc * EPC + e]; }
     }
   }
-  // one 16-byte chunk: affine map + activation (+ dropout) + store
+  // one 16-byte chunk: affine map + activation (+ dropout) + store. The activation and the dropout mode are the same for every
+  // element of a launch: the streaming loops below run inside gi_with_act with both as compile-time constants (written as run-time
+  // tests inside `finish`, hipcc kept them as scalar branches per ELEMENT: 299 branches in this kernel's 3000 instructions)
+  gi_with_act(act, [&](auto ACTc) {
+  constexpr int ACT = decltype(ACTc)::value;
+  auto body = [&](auto DROPc) {
+  constexpr int DROP = decltype(DROPc)::value;   // 0 none, 1 read the keep-mask, 2 draw it here
   auto finish = [&](int64_t pix, u4_t raw) {
     float v[EPC];
     if constexpr (std::is_same<T, half_t>::value) {
@@ -199,14 +205,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
     const bool second = G2 && pix >= pg;
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float t = G2 ? fmaf(v[e], second ? sc1[e] : sc[e], second ? sh1[e] : sh[e]) : fmaf(v[e], sc[e], sh[e]);
-      if (act == GI_ACT_RELU) t = t > 0.f ? t : 0.f;
-      else if (act == GI_ACT_LRELU) t = t > 0.f ? t : 0.2f * t;
-      v[e] = t;
+      const float t = G2 ? fmaf(v[e], second ? sc1[e] : sc[e], second ? sh1[e] : sh[e]) : fmaf(v[e], sc[e], sh[e]);
+      v[e] = gi_act_c<ACT>(t);
     }
-    if (drop) {
+    if constexpr (DROP != 0) {
       const int64_t e0 = pix * c + cc * EPC;
-      if (drop_thresh) {     // draw the keep-mask here; the backward reads it back
+      if constexpr (DROP == 2) {     // draw the keep-mask here; the backward reads it back
         uint8_t k[EPC];
 #pragma unroll
         for (int e = 0; e < EPC; ++e) k[e] = dropout_keep(drop_seed, e0 + e, drop_thresh);
@@ -239,6 +243,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const char* x, char* y, i
     full = nfull;
   }
   for (; gid < total; gid += stride) finish(gid >> lg, *(const u4_t*)(x + ((gid >> lg) * c + cc * EPC) * esz));
+  };   // body
+  if (!drop) body(std::integral_constant<int, 0>{});
+  else if (!drop_thresh) body(std::integral_constant<int, 1>{});
+  else body(std::integral_constant<int, 2>{});
+  });  // gi_with_act
 }
 
 // column sum / sumsq of a dense (pixels,c) tensor -> partials [blocks][2][c]
@@ -341,16 +350,18 @@ __device__ __forceinline__ void unpack_raw(const BwdP& p, const RawIn& r, bool w
   if (with_y) cvt_raw<T, EPC>(r.y, in.y);
 }
 // sgn: values with the sign of the activation's input (the saved y, or fma(x, scale, shift) of the forward)
+// slope of the activation's derivative on the negative side (1 / 0 / 0.2 for none / ReLU / LeakyReLU): one select per element
+// instead of a test of the activation id per element (which hipcc keeps as scalar branches inside the unrolled loops)
+__device__ __forceinline__ float neg_slope_of(int act) { return act == GI_ACT_LRELU ? 0.2f : (act == GI_ACT_RELU ? 0.f : 1.f); }
 template <typename T, int EPC>
 __device__ __forceinline__ void finish_dz(const BwdP& p, const DzIn<T, EPC>& in, const float (&sgn)[EPC], float (&dz)[EPC]) {
+  const float ns = neg_slope_of(p.act);
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     const bool pos = sgn[e] > 0.f;
     float g = p.g1 ? in.g1[e] : 0.f;
     if (p.g2) g += pos ? in.g2[e] : 0.f;
-    float sl = 1.f;
-    if (p.act == GI_ACT_LRELU) sl = pos ? 1.f : 0.2f;
-    else if (p.act == GI_ACT_RELU) sl = pos ? 1.f : 0.f;
+    const float sl = pos ? 1.f : ns;
     dz[e] = g * sl * p.drop_scale;
   }
 }
@@ -656,7 +667,7 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_acc_kernel(BwdP p) {
   if (blockIdx.x == 0 && p.zero_next) zero_words64(p.zero_next, p.zero_words);
   __syncthreads();
   const bool have_scale = p.scale != nullptr;
-  const int act = p.act;
+  const float ns = neg_slope_of(p.act);
   const float drop_scale = p.drop_scale;
   for (int64_t gid = gid0; gid < total; gid += U * stride) {
 #pragma unroll
@@ -684,9 +695,7 @@ __global__ void __launch_bounds__(256) act_bn_bwd_apply_acc_kernel(BwdP p) {
           const bool pos = sg[e] > 0.f;
           float g = (IN & 1) ? g1v[e] : 0.f;
           if constexpr ((IN & 2) != 0) g += pos ? g2v[e] : 0.f;
-          float sl = 1.f;
-          if (act == GI_ACT_LRELU) sl = pos ? 1.f : 0.2f;
-          else if (act == GI_ACT_RELU) sl = pos ? 1.f : 0.f;
+          const float sl = pos ? 1.f : ns;
           out[e] = g * sl * drop_scale;
         }
         // dx = k1 * dz + (k2 * x + k3), the same fmaf nest as the generic kernel

@@ -338,19 +338,30 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[mt][nt][r] = 0.f;
-    for (int k = 0; k < p.splitk; ++k) {   // split order, whoever is last
-      const unsigned src = (unsigned)(k * ntile + tile) * TILE_BYTES + tid * 16;
-      f4_t v[NF];
+    // split order, whoever is last; the tiles of TWO splits are requested before the first is added (igemm7.hip's tail: one split
+    // per iteration is a chain of `splitk` dependent memory round trips). A split beyond the last: out-of-range offset, not added.
+    constexpr int PF = 2;
+    for (int k0 = 0; k0 < p.splitk; k0 += PF) {
+      f4_t v[PF][NF];
 #pragma unroll
-      for (int i = 0; i < NF; ++i) v[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+      for (int f = 0; f < PF; ++f) {
+        const unsigned src = k0 + f < p.splitk ? (unsigned)((k0 + f) * ntile + tile) * TILE_BYTES + tid * 16 : 0x80000000u;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int i = 0; i < NF; ++i) v[f][i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+      }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+      for (int f = 0; f < PF; ++f) {
+        if (k0 + f < p.splitk) {
 #pragma unroll
-          for (int q = 0; q < Q4; ++q)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mt][nt][4 * q + j] += v[(mt * NT + nt) * Q4 + q][j];
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int q = 0; q < Q4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mt][nt][4 * q + j] += v[f][(mt * NT + nt) * Q4 + q][j];
+        }
+      }
     }
   } else if (p.splitk > 1) {
 #pragma unroll
@@ -496,10 +507,9 @@ int launch_cfg(hipStream_t st, const KP& kp, dim3 grid) {
   constexpr int EPI = BM * (BN + 16 / (int)sizeof(T)) * (int)sizeof(T) + WGM * BN * 2 * 4;
   constexpr int LDS = (2 * STAGE_BYTES > EPI ? 2 * STAGE_BYTES : EPI);
   auto kern = igemm_kernel<T, PHASE, BM, BN, WGM, WGN>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static GiDevOnce attr_set;
+  if (attr_set.first()) {
     GI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), LDS, st, kp);
   GI_LAUNCH_CHECK();

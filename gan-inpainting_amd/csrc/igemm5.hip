@@ -796,7 +796,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   const int BNk = dual ? 128 : BN;             // columns of the workgroup tile
   const int ring = 2 * (mode == 2 ? 384 : 320) * 128 + 3 * BNk * 128, epi = 256 * (BNk + 8) * 2 + 4 * BNk * 8;
   const int LDS = ring > epi ? ring : epi;
-  static bool attr[6] = {false, false, false, false, false, false};
+  static GiDevOnce attr[6];
   const void* fn[6] = {(const void*)igemm5_kernel<0, 128>, (const void*)igemm5_kernel<1, 128>, (const void*)igemm5_kernel<2, 128>,
                        (const void*)igemm5_kernel<0, 64>,  (const void*)igemm5_kernel<1, 64>,  (const void*)igemm5_kernel<2, 64>};
   // igemm8 (igemm8.hip): the same tile on four waves, two workgroups per CU. GI_IGEMM8: 0 off, 1 (default) layers whose grid
@@ -823,9 +823,9 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
     const int lds6 = 2 * 320 * 128 + 4 * BNk * 128;
     const int lds = lds6 > epi ? lds6 : epi;
     const int v6 = (dual ? 4 : (BN == 64 ? 2 : 0) + mode) * 2 + (a.relu_in ? 1 : 0);
-    static bool attr6[10] = {false, false, false, false, false, false, false, false, false, false};
+    static GiDevOnce attr6[10];
 #define GI_K6(MODE_, BN_, RELU_) do { \
-      if (!attr6[v6]) { GI_HIP(hipFuncSetAttribute((const void*)igemm6_kernel<MODE_, BN_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr6[v6] = true; } \
+      if (attr6[v6].first()) { GI_HIP(hipFuncSetAttribute((const void*)igemm6_kernel<MODE_, BN_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); } \
       hipLaunchKernelGGL((igemm6_kernel<MODE_, BN_, RELU_>), dim3(grid), dim3(512), lds, st, kp); } while (0)
 #ifdef GI_ABLATION   // timing-only ablation kernels compute wrong results: compiled only with `build.sh -DGI_ABLATION`
     { const char* e = getenv("GI_IGEMM6_DBG"); const int dbg = e ? atoi(e) : 0;
@@ -860,8 +860,8 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
     return GI_OK;
   }
   if (dual) {
-    static bool attr_dual = false;
-    if (!attr_dual) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<3, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_dual = true; }
+    static GiDevOnce attr_dual;
+    if (attr_dual.first()) { GI_HIP(hipFuncSetAttribute((const void*)igemm5_kernel<3, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
     hipLaunchKernelGGL((igemm5_kernel<3, 128>), dim3(grid), dim3(512), LDS, st, kp);
     gi_note_kernel("igemm5<3,128>");
     GI_LAUNCH_CHECK();
@@ -869,7 +869,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
     return GI_OK;
   }
   const int vi = (BN == 64 ? 3 : 0) + mode;
-  if (!attr[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr[vi] = true; }
+  if (attr[vi].first()) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); }
   switch (vi) {
     case 0: hipLaunchKernelGGL((igemm5_kernel<0, 128>), dim3(grid), dim3(512), LDS, st, kp); break;
     case 1: hipLaunchKernelGGL((igemm5_kernel<1, 128>), dim3(grid), dim3(512), LDS, st, kp); break;

@@ -57,20 +57,27 @@ __device__ __forceinline__ void glds16_7(const char* src, char* lds_wave_base) {
                                    16, 0, 0);
 }
 template <int N>
-__device__ __forceinline__ void wait_vm7() {
-  static_assert(N == 0 || N == 6 || N == 8 || N == 12 || N == 16, "unexpected DMA count");
+__device__ __forceinline__ void wait_vm7() {   // counted wait: all but the N youngest LDS-DMA pieces have landed
+  static_assert(N >= 0 && N <= 63 && (N % 6 == 0 || N % 8 == 0), "unexpected DMA count");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else static_assert(N < 0, "add the immediate");
 }
 
 template <int PHASE, int BN>
 __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   constexpr int BM = 128, BK = 64, NW = 4;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 32 / 24 KiB
-  constexpr int NSTG = 4;
+  // ring depth: 4 stages with 128-column tiles (32 KiB per stage); SIX with 64-column tiles (24 KiB per stage, 144 KiB): four K tiles
+  // in flight while one is multiplied - these launches (d6, d7, u7: 64 - 256 workgroups of 16 K tiles) are bound by the LDS-DMA
+  // flight time (~1 us issued -> landed while every CU streams), not by bytes or MFMAs
+  constexpr int NSTG = BN == 64 ? 6 : 4;
+  constexpr int AH = NSTG - 1;               // K tiles issued ahead of the one being multiplied
   constexpr int AJ = (BM / 8) / NW, BJ = (BN / 8) / NW;   // 8-row blocks per wave per tile: 4 + (4 | 2)
   constexpr int NPC = AJ + BJ;
   constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
@@ -225,40 +232,38 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
     if (cc0 >= p.cin) cc0 = 0;
   };
 
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>;
-  using S3 = std::integral_constant<int, 3>;
   using T1 = std::integral_constant<bool, true>;
   using T0 = std::integral_constant<bool, false>;
-  // ---- 4-stage ring: tiles t+1, t+2 stay in flight while tile t is multiplied; tile t+3 is issued during that step into the
-  //      stage tile t-1 was read from (free once every wave has passed the barrier of step t) -------------------------------
-  issue(S0{});
-  if (nk > 1) issue(S1{});
-  if (nk > 2) issue(S2{});
-  auto wait_tile = [&](int newer) {   // `newer` tiles issued after tile t may stay in flight
-    if (newer >= 2) wait_vm7<2 * NPC>();
-    else if (newer == 1) wait_vm7<NPC>();
-    else wait_vm7<0>();
+  // ---- NSTG-stage ring: tiles t+1 .. t+AH-1 stay in flight while tile t is multiplied -----------------------------------------
+  static_for<AH>([&](auto I) { if (nk > decltype(I)::value) issue(I); });
+  auto wait_tile = [&](int newer) {   // `newer` tiles issued after tile t may stay in flight (newer <= AH - 1)
+    static_for<AH>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if (newer == i || (i == AH - 1 && newer > i)) wait_vm7<i * NPC>();
+    });
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   };
+  // tile t is multiplied from stage t % NSTG while tile t + AH is issued into the stage tile t - 1 was read from (free once every
+  // wave has passed the barrier of step t); the steady state is unrolled over the ring so that stage indices are compile-time
   int t = 0;
-  for (; t + 3 < nk - 3; t += 4) {   // steady state (every step issues), stage indices are compile-time
-    wait_tile(2); compute(S0{}, S3{}, T1{});
-    wait_tile(2); compute(S1{}, S0{}, T1{});
-    wait_tile(2); compute(S2{}, S1{}, T1{});
-    wait_tile(2); compute(S3{}, S2{}, T1{});
-  }
+  for (; t + NSTG - 1 < nk - AH; t += NSTG)
+    static_for<NSTG>([&](auto S) {
+      constexpr int st = decltype(S)::value;
+      wait_tile(AH - 1);
+      compute(S, std::integral_constant<int, (st + AH) % NSTG>{}, T1{});
+    });
   for (; t < nk; ++t) {
-    wait_tile(min(2, nk - 1 - t));
-    const bool is = t + 3 < nk;
-    switch (t & 3) {
-      case 0: if (is) compute(S0{}, S3{}, T1{}); else compute(S0{}, S3{}, T0{}); break;
-      case 1: if (is) compute(S1{}, S0{}, T1{}); else compute(S1{}, S0{}, T0{}); break;
-      case 2: if (is) compute(S2{}, S1{}, T1{}); else compute(S2{}, S1{}, T0{}); break;
-      default: if (is) compute(S3{}, S2{}, T1{}); else compute(S3{}, S2{}, T0{}); break;
-    }
+    wait_tile(min(AH - 1, nk - 1 - t));
+    const bool is = t + AH < nk;
+    const int cur = t % NSTG;
+    static_for<NSTG>([&](auto S) {
+      constexpr int st = decltype(S)::value;
+      if (cur == st) {
+        if (is) compute(S, std::integral_constant<int, (st + AH) % NSTG>{}, T1{});
+        else compute(S, std::integral_constant<int, (st + AH) % NSTG>{}, T0{});
+      }
+    });
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -294,13 +299,25 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
     if (!s_last) return;
 #pragma unroll
     for (int i = 0; i < NF; ++i) acc[i / NT][i % NT] = f4_t{0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < p.splitk; ++k) {   // split order, whoever is last
-      const unsigned src = (unsigned)(k * ntile + tile) * TILE_BYTES + tid * 16;
-      f4_t v[NF];
+    // split order, whoever is last. The tiles of FOUR splits are requested before the first is added (splits beyond the last one
+    // with an out-of-range offset: zeros, not added): as one split per iteration - load its tile, wait, add - the tail was a chain
+    // of `splitk` dependent memory round trips of ~1.5 us each on ONE CU while the others still stream (8 splits on d6 / d7).
+    constexpr int PF = 4;
+    for (int k0 = 0; k0 < p.splitk; k0 += PF) {
+      f4_t v[PF][NF];
 #pragma unroll
-      for (int i = 0; i < NF; ++i) v[i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+      for (int j = 0; j < PF; ++j) {
+        const unsigned src = k0 + j < p.splitk ? (unsigned)((k0 + j) * ntile + tile) * TILE_BYTES + tid * 16 : 0x80000000u;
 #pragma unroll
-      for (int i = 0; i < NF; ++i) acc[i / NT][i % NT] += v[i];
+        for (int i = 0; i < NF; ++i) v[j][i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+      }
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        if (k0 + j < p.splitk) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i) acc[i / NT][i % NT] += v[j][i];
+        }
+      }
     }
   }
 
@@ -555,13 +572,13 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   }
   const int nyz = ntiles * nph * splitk;
   const int grid = mtiles >= 8 ? ((mtiles + 7) / 8) * 8 * nyz : mtiles * nyz;
-  const int ring = 4 * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
+  const int ring = (BN == 64 ? 6 : 4) * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
   const int LDS = ring > epi ? ring : epi;
-  static bool attr_set[4] = {false, false, false, false};
+  static GiDevOnce attr_set[4];
   const void* fn[4] = {(const void*)igemm7_kernel<0, 128>, (const void*)igemm7_kernel<1, 128>, (const void*)igemm7_kernel<0, 64>,
                        (const void*)igemm7_kernel<1, 64>};
   const int vi = (BN == 64 ? 2 : 0) + mode;
-  if (!attr_set[vi]) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 256 * 128)); attr_set[vi] = true; }
+  if (attr_set[vi].first()) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); }
   switch (vi) {
     case 0: hipLaunchKernelGGL((igemm7_kernel<0, 128>), dim3(grid), dim3(256), LDS, st, kp); break;
     case 1: hipLaunchKernelGGL((igemm7_kernel<1, 128>), dim3(grid), dim3(256), LDS, st, kp); break;

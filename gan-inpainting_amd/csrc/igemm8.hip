@@ -560,19 +560,19 @@ int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, c
   if (mode == 2 && bn == 64) {      // VGG conv1_2: 64 output channels
     // (64-column tiles were also measured on the 4-tap layers whose 128-column grid is one workgroup per CU - d3, u4, critic conv4:
     //  twice the workgroups, two per CU - and ran 6 - 10 % SLOWER than igemm6 there: twice the halo DMA per MAC; not instantiated)
-    static bool attr64 = false;
+    static GiDevOnce attr64;
     const int lds64 = 2 * 22528 + 4 * 4096;
-    if (!attr64) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<2, false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64)); attr64 = true; }
+    if (attr64.first()) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<2, false, 0, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds64)); }
     hipLaunchKernelGGL((igemm8_kernel<2, false, 0, 64>), dim3(grid), dim3(256), lds64, st, kp);
     gi_note_kernel("igemm8<2,64>");
     GI_LAUNCH_CHECK();
     return GI_OK;
   }
   const int LDS = (mode == 2 ? 2 * 22528 : 2 * 20480) + 4 * 8192;   // 4-tap modes: = the epilogue's 256 x 136 halves + 4 x 128 x 2 floats
-  static bool attr[8] = {false, false, false, false, false, false, false, false};
+  static GiDevOnce attr[8];
   const int v = mode == 2 ? 6 : (dual ? 2 : mode) * 2 + (relu ? 1 : 0);
 #define GI_K8(MODE_, RELU_, NAME_) do { \
-    if (!attr[v]) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<MODE_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); attr[v] = true; } \
+    if (attr[v].first()) { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<MODE_, RELU_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); } \
     hipLaunchKernelGGL((igemm8_kernel<MODE_, RELU_>), dim3(grid), dim3(256), LDS, st, kp); gi_note_kernel(NAME_); } while (0)
 #ifdef GI_ABLATION   // timing-only ablation kernels compute wrong results: compiled only with `build.sh -DGI_ABLATION`
   { const char* e = getenv("GI_IGEMM8_DBG"); const int dbg = e ? atoi(e) : 0;

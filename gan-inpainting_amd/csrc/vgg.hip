@@ -443,8 +443,8 @@ int vgg_run(gi_vgg* v, const float* xa, const float* xb, int n, int stop_tap, fl
         split = (steps + gp.steps_per_split - 1) / gp.steps_per_split;
         gp.split = split;
         if (BLK == 128) {
-          static bool attr = false;
-          if (!attr) { GI_HIP(hipFuncSetAttribute((const void*)gram2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 288)); attr = true; }
+          static GiDevOnce attr;
+          if (attr.first()) { GI_HIP(hipFuncSetAttribute((const void*)gram2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 32 * 288)); }
           hipLaunchKernelGGL(gram2_kernel<64>, dim3(ntile, split, n), dim3(256), 2 * 4 * 32 * 288, st, gp);
         } else {
           hipLaunchKernelGGL(gram2_kernel<32>, dim3(ntile, split, n), dim3(256), 2 * 4 * 32 * 160, st, gp);

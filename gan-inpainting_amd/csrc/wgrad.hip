@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   const int per = (split + 3) / 4, k0 = ty * per, k1 = min(split, k0 + per);
   f4_t s = f4_t{0.f, 0.f, 0.f, 0.f};
   if (i < count4)
-    for (int k = k0; k < k1; ++k) s += *(const f4_t*)(part + ((int64_t)k * count4 + i) * 4);
+    s = gi_ordered_sum_f4((const f4_t*)part + i, count4, k0, k1, s);   // eight loads in flight, the same order of additions
   if (ty > 0) red[ty - 1][tx] = s;
   __syncthreads();
   if (ty == 0 && i < count4) {
@@ -291,10 +291,9 @@ int run(hipStream_t st, const WgradArgs& a) {
   constexpr int LROW = F16 ? 256 + 32 : 512;
   constexpr int LDS = 2 * 2 * BKP * LROW;
   dim3 grid(a.ca / 128, 16 * a.cb / 128, split);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static GiDevOnce attr_set;
+  if (attr_set.first()) {
     GI_HIP(hipFuncSetAttribute((const void*)wgrad_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr_set = true;
   }
   hipLaunchKernelGGL(wgrad_kernel<T>, grid, dim3(256), LDS, st, p);
   gi_note_kernel(F16 ? "wgrad<f16>" : "wgrad<f32>");

@@ -485,7 +485,7 @@ __global__ void __launch_bounds__(256) wgrad2_reduce_kernel(const float* __restr
   const int per = (split + 3) / 4, k0 = ty * per, k1 = min(split, k0 + per);
   f4_t s = f4_t{0.f, 0.f, 0.f, 0.f};
   if (i < count4)
-    for (int k = k0; k < k1; ++k) s += *(const f4_t*)(part + ((int64_t)k * count4 + i) * 4);
+    s = gi_ordered_sum_f4((const f4_t*)part + i, count4, k0, k1, s);   // eight loads in flight, the same order of additions
   if (ty > 0) red[ty - 1][tx] = s;
   __syncthreads();
   if (ty == 0 && i < count4) {
@@ -549,12 +549,11 @@ int op_wgrad2(hipStream_t st, const WgradArgs& a) {
   p.direct = split == 1 ? 1 : 0;
   if (split > 1 && a.scratch && a.scratch_bytes >= (int64_t)split * out_floats * 4) p.part = a.scratch;
   constexpr int LDS = 3 * (2 * 64 * 128 + 192 * 128);
-  static bool attr = false;
-  if (!attr) {
+  static GiDevOnce attr;
+  if (attr.first()) {
     GI_HIP(hipFuncSetAttribute((const void*)wgrad2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     GI_HIP(hipFuncSetAttribute((const void*)wgrad3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    attr = true;
   }
   const dim3 grid((a.ca / 128) * (a.cb / 64) * (4 / wgrad2_nky()), split);
   const int pipe = gi_opt(GI_OPT_WGRAD3);   // GI_WGRAD3=0: the unpipelined two-ky kernel (also the fallback beyond 2^31-byte tensors)

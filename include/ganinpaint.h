@@ -356,7 +356,9 @@ int gi_convT_s2_forward(gi_ctx* ctx, int dtype, const void* in, const void* w_ph
  * GEMMs). Fields marked (returned) say whether the kernel that served the shape implemented the fusion; if not, the caller
  * runs the separate pass. */
 typedef struct gi_igemm_ex {
-  int relu_cend;                 /* with relu_in: only input channels [0, relu_cend) need the ReLU (0 = all) */
+  int relu_cend;                 /* with relu_in: only input channels [0, relu_cend) need the ReLU (0 = all). A hint for inputs whose
+                                  * channels from relu_cend on are already non-negative (the decoder half of a concat buffer): kernels
+                                  * may apply the ReLU to more channels. Must be a multiple of 64 and <= the input channels. */
   /* activation backward on the result: out = (out + [mask > 0] * add) * (mask > 0 ? 1 : mask_slope); mask / add laid out
    * like out with leading dimensions ldmask / ldadd (the LeakyReLU backward of a norm-free layer, networks.py:287) */
   const void* mask; int ldmask; float mask_slope;

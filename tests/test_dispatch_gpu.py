@@ -265,7 +265,7 @@ WGRAD = [   # (name, n, Hs, ca, cb, relu_S, ldL / cb, kernel)
     ("d2", 32, 64, 128, 64, 0, 2, "wgrad3<4>"),
     ("d3", 32, 32, 256, 128, 0, 2, "wgrad3<4>"),
     ("d4", 32, 16, 512, 256, 0, 2, "wgrad3<4>"),
-    ("d5", 32, 8, 512, 512, 0, 2, "wgrad3<3>"),
+    ("d5", 32, 8, 512, 512, 0, 2, "wgrad<f16>"),
 ]
 
 

@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # Timing-only ablations of the dominant kernel (igemm6, generator u3 shape): builds the library with -DGI_ABLATION on the
 # GPU box (the shipped .so is restored afterwards) and times each variant with bench.py --kernel-only.
 # usage: tools/ablate_igemm6.sh   (through gpurun)
 set -o pipefail
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 cd $R
 cp gan-inpainting_amd/libganinpaint.so /tmp/libganinpaint.so.keep
 touch gan-inpainting_amd/csrc/igemm5.hip

@@ -1,7 +1,8 @@
 #!/bin/bash
+set -u
 # c1_wgrad_mfma_kernel grid cap (ablation build, GI_C1W_GRID) on a batch with a generator update: kernel durations per variant
 set -o pipefail
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 export GI_LIB_PATH=$R/gan-inpainting_amd/libganinpaint_abl.so
 cd /tmp && export TMPDIR=/tmp
 for cap in 512 1024 2048; do

@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # Kernel chain of one generator forward (256x256, bs=32, fp16, train mode) under rocprofv3, for each setting of an
 # environment switch. usage: tools/fwd_ab.sh <tag> [VAR=a VAR=b ...]   (run on the GPU box through gpurun)
 set -o pipefail
 TAG=${1:-ab}; shift
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 cd /tmp && export TMPDIR=/tmp
 for setting in "${@:-X=0}"; do
   OUT=$R/gpurun_out/fwd_${TAG}_${setting//=/_}

@@ -1,10 +1,11 @@
 #!/bin/bash
+set -u
 # Hardware counters per dispatch for one WGAN batch (tools/step_chain.py): separate --pmc passes (FETCH_SIZE / WRITE_SIZE / SQ groups),
 # merged into gpurun_out/<tag>_pmc.txt: one line per kernel of the last repetition with its counters.
 # usage (GPU box): tools/pmc_chain.sh <tag> [gen|critic]
 set -o pipefail
 TAG=${1:-p}; KIND=${2:-critic}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,8 +1,9 @@
 #!/bin/bash
+set -u
 # Hardware counters of the dominant kernel (bench.py --kernel-only), one rocprofv3 --pmc pass per group.
 # usage (on the GPU box): bash tools/pmc_dominant.sh <outdir-under-gpurun_out>
 set -o pipefail
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/${1:-pmc_dom}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

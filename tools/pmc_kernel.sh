@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # Hardware counters of the dominant kernel (bench.py --kernel-only: generator u3), separate rocprofv3 --pmc passes, for the default
 # kernel choice (igemm8) and for igemm6 (GI_IGEMM8=0) -> gpurun_out/<tag>_pmc_kernel.txt   usage (GPU box): tools/pmc_kernel.sh <tag>
 set -o pipefail
 TAG=${1:-k}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 cd /tmp && export TMPDIR=/tmp
 for variant in igemm8 igemm6; do
   OUT=$R/gpurun_out/pmck_${TAG}_$variant

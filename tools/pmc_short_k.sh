@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # HBM traffic and rocprof duration of the short-K kernel (critic conv2, bench.py --kernel-only --short-k): one --pmc pass per counter
 # + one --kernel-trace --stats pass -> gpurun_out/pmc_short_k/; summarised into profiles/short_k_kernel_traffic.json by
 # tools/summarize_short_k.py. usage (GPU box): bash tools/pmc_short_k.sh
 set -o pipefail
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/pmc_short_k
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

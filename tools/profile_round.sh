@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # Collect the rocprofv3 evidence for profiles/ (run on the GPU box through gpurun).
 # usage: tools/profile_round.sh <tag>
 set -o pipefail
 TAG=${1:-r01}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # rocprofv3 evidence for profiles/ (run on the GPU box through gpurun; every rocprofv3 run has the program directly after `--`).
 # usage: tools/profile_round2.sh <tag>     -> gpurun_out/prof_<tag>/..., summarised by tools/summarize_round2.py <tag>
 set -o pipefail
 TAG=${1:-r02}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # One batch with a generator update on one stream under rocprofv3 --kernel-trace -> gpurun_out/<tag>_chain.txt (every kernel in order)
 # usage (on the GPU box, through gpurun): tools/quick_chain.sh <tag> [gen|critic]
 set -o pipefail
 TAG=${1:-q}; KIND=${2:-gen}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/qc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

@@ -1,9 +1,10 @@
 #!/bin/bash
+set -u
 # Kernel chain of one WGAN batch WITH a generator update on one stream (256x256, bs=32, fp16) under rocprofv3.
 # usage: tools/step_ab.sh <tag> [gen|critic]   (through gpurun) -> gpurun_out/step_<tag>/chain.txt + per-kernel-class summary
 set -o pipefail
 TAG=${1:-x}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/step_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

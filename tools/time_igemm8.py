@@ -58,8 +58,8 @@ def timeit(args, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-# argv[2] = the GI_IGEMM8 value of the second arm (default 2: every eligible layer on 128-column igemm8 tiles; 3: also the layers with
-# fewer than 512 workgroups, on 64-column tiles); the first arm is GI_IGEMM8 = 0 (igemm6)
+# argv[2] = the GI_IGEMM8 value of the second arm (default 2: every eligible layer on igemm8; 1: only layers with >= 512 workgroups);
+# the first arm is GI_IGEMM8 = 0 (igemm6)
 arm = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 print(f"{'layer':22s} {'igemm6 us':>10s} {'igemm8 us':>10s} {'ratio':>6s} {'TF/s 6':>8s} {'TF/s 8':>8s}   kernels")
 for name, kind, n, H, cin, cout, relu, cend in LAYERS:
