@@ -99,6 +99,7 @@ PROTOTYPES = {
     "gi_check_finite": (_i, [_vp, _vp, _i64, _vp]),
     "gi_check_finite_scan": (_i, [_vp, _vp, _i64, _vp]),
     "gi_check_finite_finish": (_i, [_vp, _vp]),
+    "gi_check_finite_last": (_i, [_vp, _vp, _i64, _vp]),
     "gi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "gi_adam_step_guarded2": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _f, _vp]),
     "gi_rmsprop_step_guarded": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp]),
@@ -151,6 +152,8 @@ def lib():
                         "(gan-inpainting_amd/csrc/build.sh). There is no CPU fallback.")
                 handle = C.CDLL(LIB_PATH)
                 for name, (res, args) in PROTOTYPES.items():
+                    if os.environ.get("GI_LIB_PATH") and not hasattr(handle, name):
+                        continue    # an OLDER build named for an A/B run (tools/r4_ab.sh) may lack newer entries: calling one raises
                     fn = getattr(handle, name)
                     fn.restype = res
                     fn.argtypes = args

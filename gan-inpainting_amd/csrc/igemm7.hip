@@ -66,17 +66,18 @@ __device__ __forceinline__ void wait_vm7() {   // counted wait: all but the N yo
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
   else static_assert(N < 0, "add the immediate");
 }
 
-template <int PHASE, int BN>
+// NSTG: ring stages; PF: split-K tiles requested together in the last arriver's tail. Shipped: GI7_NSTG / GI7_PF below; the
+// ablation build (build.sh -DGI_ABLATION) instantiates the alternatives, selected by GI_IGEMM7_NSTG / GI_IGEMM7_PF.
+template <int PHASE, int BN, int NSTG_, int PF_>
 __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   constexpr int BM = 128, BK = 64, NW = 4;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 32 / 24 KiB
-  // ring depth: 4 stages with 128-column tiles (32 KiB per stage); SIX with 64-column tiles (24 KiB per stage, 144 KiB): four K tiles
-  // in flight while one is multiplied - these launches (d6, d7, u7: 64 - 256 workgroups of 16 K tiles) are bound by the LDS-DMA
-  // flight time (~1 us issued -> landed while every CU streams), not by bytes or MFMAs
-  constexpr int NSTG = BN == 64 ? 6 : 4;
+  // ring depth (K tiles of 64: 32 KiB per stage with 128-column tiles, 24 KiB with 64-column ones)
+  constexpr int NSTG = NSTG_;
   constexpr int AH = NSTG - 1;               // K tiles issued ahead of the one being multiplied
   constexpr int AJ = (BM / 8) / NW, BJ = (BN / 8) / NW;   // 8-row blocks per wave per tile: 4 + (4 | 2)
   constexpr int NPC = AJ + BJ;
@@ -302,7 +303,7 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
     // split order, whoever is last. The tiles of FOUR splits are requested before the first is added (splits beyond the last one
     // with an out-of-range offset: zeros, not added): as one split per iteration - load its tile, wait, add - the tail was a chain
     // of `splitk` dependent memory round trips of ~1.5 us each on ONE CU while the others still stream (8 splits on d6 / d7).
-    constexpr int PF = 4;
+    constexpr int PF = PF_;
     for (int k0 = 0; k0 < p.splitk; k0 += PF) {
       f4_t v[PF][NF];
 #pragma unroll
@@ -572,19 +573,46 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   }
   const int nyz = ntiles * nph * splitk;
   const int grid = mtiles >= 8 ? ((mtiles + 7) / 8) * 8 * nyz : mtiles * nyz;
-  const int ring = (BN == 64 ? 6 : 4) * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
+  // shipped choice, measured on d5 / d6 / d7 / u7 / u6 at the headline batch (tools/r4_small.sh, profiles/r04_igemm7_variants.txt):
+  // four stages and one split per tail iteration. A six-stage ring on the 64-column tiles (four K tiles in flight) ran 3 - 5 us
+  // SLOWER per layer (the five-tile prologue burst of every CU delays the first tile by more than the deeper ring gains), two or
+  // four splits of the tail in flight changed nothing (+-0.5 us): the tail's round trips are not what these launches wait for.
+  constexpr int GI7_NSTG = 4, GI7_PF = 1;
+  int nstg = GI7_NSTG, pf = GI7_PF;
+#ifdef GI_ABLATION
+  nstg = gi_tune("GI_IGEMM7_NSTG", GI7_NSTG);
+  pf = gi_tune("GI_IGEMM7_PF", GI7_PF);
+  if (BN == 128 || nstg != 6) nstg = 4;
+  if (pf != 2 && pf != 4) pf = 1;
+#endif
+  const int ring = nstg * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
   const int LDS = ring > epi ? ring : epi;
-  static GiDevOnce attr_set[4];
-  const void* fn[4] = {(const void*)igemm7_kernel<0, 128>, (const void*)igemm7_kernel<1, 128>, (const void*)igemm7_kernel<0, 64>,
-                       (const void*)igemm7_kernel<1, 64>};
   const int vi = (BN == 64 ? 2 : 0) + mode;
-  if (attr_set[vi].first()) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); }
-  switch (vi) {
-    case 0: hipLaunchKernelGGL((igemm7_kernel<0, 128>), dim3(grid), dim3(256), LDS, st, kp); break;
-    case 1: hipLaunchKernelGGL((igemm7_kernel<1, 128>), dim3(grid), dim3(256), LDS, st, kp); break;
-    case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
-    default: hipLaunchKernelGGL((igemm7_kernel<1, 64>), dim3(grid), dim3(256), LDS, st, kp); break;
-  }
+  auto launch = [&](auto NS, auto PFc) -> int {
+    constexpr int ns = decltype(NS)::value, pfc = decltype(PFc)::value;
+    static GiDevOnce attr_set[4];
+    const void* fn[4] = {(const void*)igemm7_kernel<0, 128, ns, pfc>, (const void*)igemm7_kernel<1, 128, ns, pfc>, (const void*)igemm7_kernel<0, 64, ns, pfc>,
+                         (const void*)igemm7_kernel<1, 64, ns, pfc>};
+    if (attr_set[vi].first()) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); }
+    switch (vi) {
+      case 0: hipLaunchKernelGGL((igemm7_kernel<0, 128, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
+      case 1: hipLaunchKernelGGL((igemm7_kernel<1, 128, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
+      case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
+      default: hipLaunchKernelGGL((igemm7_kernel<1, 64, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
+    }
+    return GI_OK;
+  };
+  using I1_ = std::integral_constant<int, 1>;
+  using I2_ = std::integral_constant<int, 2>;
+  using I4_ = std::integral_constant<int, 4>;
+  using I6_ = std::integral_constant<int, 6>;
+#ifdef GI_ABLATION
+  if (nstg == 6) { if (pf == 4) GI_TRY(launch(I6_{}, I4_{})); else if (pf == 2) GI_TRY(launch(I6_{}, I2_{})); else GI_TRY(launch(I6_{}, I1_{})); }
+  else { if (pf == 4) GI_TRY(launch(I4_{}, I4_{})); else if (pf == 2) GI_TRY(launch(I4_{}, I2_{})); else GI_TRY(launch(I4_{}, I1_{})); }
+#else
+  (void)nstg; (void)pf;
+  GI_TRY(launch(std::integral_constant<int, GI7_NSTG>{}, std::integral_constant<int, GI7_PF>{}));
+#endif
   { static const char* nm[8] = {"igemm7<0,128>", "igemm7<1,128>", "igemm7<0,64>", "igemm7<1,64>",
                                 "igemm7<0,128>+bn", "igemm7<1,128>+bn", "igemm7<0,64>+bn", "igemm7<1,64>+bn"}; gi_note_kernel(nm[vi + (fold ? 4 : 0)]); }
   GI_LAUNCH_CHECK();

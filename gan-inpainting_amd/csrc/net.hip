@@ -1457,8 +1457,10 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   net->slot_train[s] = train;
   const bool fuse_a4 = net->fuse_head && op_head_affine_ok(dt, 512);
   net->slot_fused_u2[s] = fuse_a4 ? 1 : 0;   // (critic: "conv4's activation was not materialised")
-  GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   GI_TRY(op_c1_gather(st, dt, x, net->params + net->dconv[1].w_off, net->slot(s, net->oA[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_LRELU, 1.f));
+  // the copy of the input that conv1's weight gradient reads rides in conv2's normalisation pass where that pass takes a side
+  // copy (accumulator path); otherwise a device copy
+  bool x_saved = false;
   for (int i = 2; i <= 4; ++i) {
     const Conv& c = net->dconv[i];
     const int Hs = H >> i, Ws = W >> i;
@@ -1467,10 +1469,14 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
     StatPlan sp = stat_plan(net, net->dbn[i], (int64_t)n * Hs * Ws, ((int64_t)n * Hs * Ws + 127) / 128, train);
     GI_TRY(igemm(net, 0, net->slot(s, net->oA[i - 1]), c.cb, c.cb, 0, packed_ptr(net, c), R, c.ca, c.ca, 0, n, Hs, Ws, 0, GI_ACT_NONE,
                  true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
+    const bool side = i == 2 && sp.use && ((int64_t)n * H * W * 4) % 16 == 0;
     // conv4 feeds only the head: its BatchNorm + LeakyReLU is applied by the head kernels from the raw tensor
     GI_TRY(bn_forward(net, s, net->dbn[i], R, (int64_t)n * Hs * Ws, nt, net->slot(s, net->oA[i]), c.ca, 0, GI_ACT_LRELU, nullptr, 1.f, train,
-                      !(i == 4 && fuse_a4), &sp));
+                      !(i == 4 && fuse_a4), &sp, 0.f, 0, side ? x : nullptr, side ? net->slot(s, net->oX) : nullptr,
+                      side ? (int64_t)n * H * W * 4 : 0));
+    if (side) x_saved = true;
   }
+  if (!x_saved) GI_HIP(hipMemcpyAsync(net->slot(s, net->oX), x, (size_t)n * H * W * 4, hipMemcpyDeviceToDevice, st));
   HeadArgs h;
   h.a4 = net->slot(s, fuse_a4 ? net->oRd[4] : net->oA[4]);
   if (fuse_a4) {

@@ -205,25 +205,33 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
 
   const int64_t ldw = (int64_t)16 * p.cb;
   constexpr int NR = F16 ? 4 : 16;
+  // (the store mode is the same for every element: chosen once, not tested per element inside the unrolled loops)
+  auto emit = [&](auto MODE) {
+    constexpr int mode = decltype(MODE)::value;   // 0 partial tile, 1 direct accumulate, 2 float atomics
+    float* base = mode == 0 ? p.part + (int64_t)ks * p.ca * ldw : p.dW;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      int row;
-      if constexpr (F16) row = wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
-      else row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int r = 0; r < NR; ++r) {
+        int row;
+        if constexpr (F16) row = wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
+        else row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        int c;
-        if constexpr (F16) c = wn * 64 + nt * 16 + (lane & 15);
-        else c = wn * 64 + nt * 32 + (lane & 31);
-        const int64_t o = (int64_t)(a0 + row) * ldw + n0 + c;
-        const float v = acc[mt][nt][r] * p.scale;
-        if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
-        else if (p.direct) p.dW[o] += v;
-        else atomicAdd(p.dW + o, v);
+        for (int nt = 0; nt < NT; ++nt) {
+          int c;
+          if constexpr (F16) c = wn * 64 + nt * 16 + (lane & 15);
+          else c = wn * 64 + nt * 32 + (lane & 31);
+          const int64_t o = (int64_t)(a0 + row) * ldw + n0 + c;
+          const float v = acc[mt][nt][r] * p.scale;
+          if constexpr (mode == 0) base[o] = v;
+          else if constexpr (mode == 1) base[o] += v;
+          else atomicAdd(base + o, v);
+        }
       }
-    }
+  };
+  if (p.part) emit(std::integral_constant<int, 0>{});
+  else if (p.direct) emit(std::integral_constant<int, 1>{});
+  else emit(std::integral_constant<int, 2>{});
 }
 
 // dW[i] += sum_k part[k][i] in a fixed order (deterministic): 64 float4 outputs per block, the splits divided among

@@ -455,26 +455,37 @@ __global__ void __launch_bounds__(512, 1) wgrad3_kernel(WP2 p) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  // ---- epilogue (as wgrad2_kernel<2>) ------------------------------------------------------------------------------------------
+  // ---- epilogue ----------------------------------------------------------------------------------------------------------------
   const int64_t ldw = (int64_t)16 * p.cb;
+  // (the store mode is the same for every element: chosen once, not tested per element inside the unrolled loops - it was two scalar
+  //  branches per element, 813 branches in this kernel's 4069 instructions. Measured and dropped in round 4: the partial tiles through a
+  //  wave-private LDS slab and out as 16-byte stores of whole 256-byte rows - 32 store instructions per lane instead of 128 four-byte ones -
+  //  critic conv2 55.5 -> 53.8 us, conv3 57.5 -> 65.0, generator u3 83.9 -> 87.2, u2 83.4 -> 80.5 on one box: the stores were not the limit)
+  auto emit = [&](auto MODE) {
+    constexpr int mode = decltype(MODE)::value;   // 0 partial tile, 1 direct accumulate, 2 float atomics
+    float* base = mode == 0 ? p.part + (int64_t)ks * p.ca * ldw : p.dW;
 #pragma unroll
-  for (int s2 = 0; s2 < 2; ++s2) {
-    const int colb = ((ky + 2 * s2) * 4 + kx) * p.cb + b0 + (lane & 15);
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int colb = ((ky + 2 * s2) * 4 + kx) * p.cb + b0 + (lane & 15);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = a0 + wa * 64 + mt * 16 + (lane >> 4) * 4 + r;
+        for (int r = 0; r < 4; ++r) {
+          const int row = a0 + wa * 64 + mt * 16 + (lane >> 4) * 4 + r;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const int64_t o = (int64_t)row * ldw + colb + nt * 16;
-          const float v = acc[s2][mt][nt][r] * p.scale;
-          if (p.part) p.part[(int64_t)ks * p.ca * ldw + o] = v;
-          else if (p.direct) p.dW[o] += v;
-          else atomicAdd(p.dW + o, v);
+          for (int nt = 0; nt < 4; ++nt) {
+            const int64_t o = (int64_t)row * ldw + colb + nt * 16;
+            const float v = acc[s2][mt][nt][r] * p.scale;
+            if constexpr (mode == 0) base[o] = v;
+            else if constexpr (mode == 1) base[o] += v;
+            else atomicAdd(base + o, v);
+          }
         }
-      }
-  }
+    }
+  };
+  if (p.part) emit(std::integral_constant<int, 0>{});
+  else if (p.direct) emit(std::integral_constant<int, 1>{});
+  else emit(std::integral_constant<int, 2>{});
 }
 
 // dW[i] += sum_k part[k][i] in a fixed order (as in wgrad.hip)

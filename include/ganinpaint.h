@@ -65,8 +65,9 @@ int gi_version(void);
  *   GI_BN_BWD_SMALL [512] largest pixel count served by the one-launch BatchNorm backward (0: never)
  *   GI_WGRAD2 [1]         0: weight gradients on the register-staged kernel (wgrad.hip) only
  *   GI_WGRAD3 [1]         0: the unpipelined two-tap-row weight-gradient kernel instead of wgrad3
- *   GI_BN_FOLD [1]        0: the BatchNorm + activation (+ dropout) pass of the generator's small layers as its own launch instead of
- *                         inside the GEMM that produces the layer (igemm7's last finisher per channel column); bit-identical results
+ *   GI_BN_FOLD [0]        1: the BatchNorm + activation (+ dropout) pass of the generator's small layers inside the GEMM that produces
+ *                         the layer (igemm7's last finisher per channel column) instead of as its own launch; bit-identical results.
+ *                         Off by default: measured SLOWER (+8 .. 10 us per folded layer at the headline shape)
  *   GI_C1_FUSED [1]       0: the single-channel transposed convolution (generator u1, d1's input gradient) as two launches through a
  *                         col tensor in memory instead of one launch with the col rows in LDS; bit-identical results */
 int gi_set_option(const char* name, int value);
@@ -246,6 +247,8 @@ int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
  * update share one verdict (all skip or none) and the running count advances by one per skipped update. */
 int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
 int gi_check_finite_finish(gi_ctx* ctx, int* flag3);
+/* scan + finish in ONE launch (the workgroup that ends last finishes): the last - or only - buffer of an update */
+int gi_check_finite_last(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
 int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
                          float beta1, float beta2, float eps, int step, float grad_scale, const int* guard);
 /* skipped_seen >= 0: `step` counts every call since the start minus the skipped updates the host has already learned of

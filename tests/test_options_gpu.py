@@ -155,7 +155,7 @@ def _patchgan_run(dtype, seed=66, N=8, HW=128, groups=2):
     return y.detach().cpu(), dx.detach().cpu(), net.flat_grads().detach().cpu().clone(), stats
 
 
-NET_OPTIONS = [("GI_BN_FOLD", 0), ("GI_C1_FUSED", 0), ("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
+NET_OPTIONS = [("GI_BN_FOLD", 1), ("GI_C1_FUSED", 0), ("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
                ("GI_IGEMM6", 0), ("GI_WGRAD3", 0), ("GI_WGRAD2", 0), ("GI_IGEMM8", 2), ("GI_IGEMM8", 0)]
 
 
@@ -207,10 +207,11 @@ def _unet_fold_run(N, HW, impose, seed=77):
 @pytest.mark.parametrize("N,HW,impose", [(4, 128, True), (4, 128, False), (2, 64, False), (32, 256, False)],
                          ids=["n4-128-imposed", "n4-128-drawn", "n2-64-drawn", "n32-256-drawn"])
 def test_folded_normalisation_is_bit_identical(N, HW, impose, option):
-    """GI_BN_FOLD (default on): the generator's small layers are normalised by the GEMM that produces them (igemm7's last finisher per
+    """GI_BN_FOLD = 1 (default 0: measured slower): the generator's small layers are normalised by the GEMM that produces them (igemm7's last finisher per
     channel column: IgemmFold, csrc/common.h) instead of by a bn_apply launch (networks.py:288-290 downnorm / upnorm + activation +
     Dropout are separate modules in the reference). Same accumulators, same expressions, same dropout hash: outputs of repeated
     forwards, input gradient, every parameter gradient and the running statistics must be EQUAL, with drawn and with imposed masks."""
+    option("GI_BN_FOLD", 1)
     a = _unet_fold_run(N, HW, impose)
     option("GI_BN_FOLD", 0)
     b = _unet_fold_run(N, HW, impose)
@@ -242,6 +243,7 @@ def test_folded_normalisation_is_dispatched_at_the_headline_shapes(option):
         pytest.skip("library without gi_debug_fold_count")
     net = networks.get_network("generator", "unet", dtype="fp16").to("cuda").train()
     x = torch.rand(32, 1, 256, 256, device="cuda")
+    option("GI_BN_FOLD", 1)
     c0 = BB.lib().gi_debug_fold_count()
     with torch.no_grad():
         net(x)
