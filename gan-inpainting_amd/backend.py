@@ -99,7 +99,6 @@ PROTOTYPES = {
     "gi_check_finite": (_i, [_vp, _vp, _i64, _vp]),
     "gi_check_finite_scan": (_i, [_vp, _vp, _i64, _vp]),
     "gi_check_finite_finish": (_i, [_vp, _vp]),
-    "gi_check_finite_last": (_i, [_vp, _vp, _i64, _vp]),
     "gi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "gi_adam_step_guarded2": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _f, _vp]),
     "gi_rmsprop_step_guarded": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp]),

@@ -1124,7 +1124,8 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
                                                            float* __restrict__ h, float* __restrict__ out,
                                                            float* __restrict__ out2, int Hh, int Wh, int sigmoid,
                                                            const float* __restrict__ sc4, const float* __restrict__ sh4,
-                                                           int n_per_group, int gstride, float* __restrict__ tbuf, int slices) {
+                                                           int n_per_group, int gstride, float* __restrict__ tbuf, int slices,
+                                                           BnAccP fa, int use_fa) {
   // tbuf != null (large feature maps, few images): `slices` workgroups per image each compute t for their share of
   // the pixel tiles into tbuf[image][pixel][16] and stop; head_h512_kernel finishes (h, Linear, sigmoid).
   // sc4 != null: a4 is the RAW conv4 output; LeakyReLU(fma(x, sc4, sh4)) (the layer's BatchNorm + activation, the
@@ -1136,7 +1137,29 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
   float* red = t_lds + (tbuf ? 0 : ((npx * HT_PITCH + 3) & ~3));   // 16-byte aligned
   half_t* wh = (half_t*)(red + 16);
   float* aff = (float*)(wh + 16 * 512);
-  if (sc4) {
+  if (sc4 && use_fa) {
+    // the scale / shift vectors do not exist yet: derived here from conv4's exact accumulators (bn_acc.h) - every workgroup the
+    // vectors of its image's population; workgroup 0 publishes ALL populations' vectors (sc4 / sh4 and the backward's), moves the
+    // running statistics population by population and clears the layer's other accumulator region: no finalize launch
+    const int grp = nn / n_per_group;
+    if (threadIdx.x < 512) {
+      float a = 0.f, b = 0.f;
+      if (blockIdx.x == 0) {
+        for (int j = 0; j < fa.groups; ++j) {
+          float aj, bj;
+          bn_from_acc(fa, 512, threadIdx.x, j, true, aj, bj);
+          if (j == grp) { a = aj; b = bj; }
+        }
+      } else {
+        bn_from_acc(fa, 512, threadIdx.x, grp, false, a, b);
+      }
+      aff[threadIdx.x] = a;
+      aff[512 + threadIdx.x] = b;
+    }
+    if (blockIdx.x == 0 && fa.zero_next) {
+      for (int i = threadIdx.x; i < fa.zero_words; i += 1024) fa.zero_next[i] = 0ull;
+    }
+  } else if (sc4) {
     const int go = (nn / n_per_group) * gstride;
     for (int i = threadIdx.x; i < 512; i += 1024) { aff[i] = sc4[go + i]; aff[512 + i] = sh4[go + i]; }
   }
@@ -1614,7 +1637,14 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
   GI_REQUIRE(Ph >= 1 && Pw >= 1, "head: feature map %dx%d too small", a.Hh, a.Wh);
   const int blocks = a.n * Ph * Pw;
   GI_REQUIRE(!a.scale4 || op_head_affine_ok(dtype, a.c), "head: fused BatchNorm input needs the fp16 c=512 kernels");
+  GI_REQUIRE(!a.bn || (a.scale4 && dtype == GI_F16 && a.c == 512 && head_fast()), "head: accumulator-derived BatchNorm needs the fused fp16 c=512 path");
   if (dtype == GI_F16 && a.c == 512 && head_fast()) {
+    BnAccP fa = {};
+    const int use_fa = a.bn ? 1 : 0;
+    if (use_fa) {
+      gi_fill_acc_params(fa, *a.bn);
+      GI_REQUIRE(fa.out_stride == a.gstride, "head: population stride %d != %d", fa.out_stride, a.gstride);
+    }
     const int lds = (((a.Hh * a.Wh * HT_PITCH + 3) & ~3) + 16) * 4 + 16 * 512 * 2 + 2 * 512 * 4;
     GI_REQUIRE(lds <= 160 * 1024, "head: feature map %dx%d too large", a.Hh, a.Wh);
     if (lds > 64 * 1024) {
@@ -1629,14 +1659,14 @@ int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a) {
     if (slices > 1 && a.tbuf && a.tbuf_bytes >= (int64_t)a.n * npx * 16 * 4) {
       const int lds2 = (16) * 4 + 16 * 512 * 2 + 2 * 512 * 4;
       hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n * slices), dim3(1024), lds2, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh,
-                         a.Wh, a.sigmoid, a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, a.tbuf, slices);
+                         a.Wh, a.sigmoid, a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, a.tbuf, slices, fa, use_fa);
       GI_LAUNCH_CHECK();
       hipLaunchKernelGGL(head_h512_kernel, dim3(a.n), dim3(256), 0, st, a.tbuf, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid);
       GI_LAUNCH_CHECK();
       return GI_OK;
     }
     hipLaunchKernelGGL(head_fwd512_kernel, dim3(a.n), dim3(1024), lds, st, (const char*)a.a4, a.w5, a.wl, a.bl, a.h, a.out, a.out2, a.Hh, a.Wh, a.sigmoid,
-                       a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, (float*)nullptr, 1);
+                       a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, (float*)nullptr, 1, fa, use_fa);
     GI_LAUNCH_CHECK();
     return GI_OK;
   }

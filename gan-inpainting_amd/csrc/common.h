@@ -94,14 +94,23 @@ __device__ __forceinline__ f4_t gi_ordered_sum_f4(const f4_t* part, int64_t stri
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += v[j];
   }
-  if (k < k1) {   // the last 1 .. 7: loads from clamped indices (no load under a condition), added only where in range
-    f4_t v[8];
+  // the last 1 .. 7 in groups of four, two and one (k0 / k1 are wave-uniform: plain branches; a first version loaded eight from
+  // clamped indices and read the last partial up to seven times - conv4's 8-way sum, two per wave, moved four times the bytes)
+  if (k + 4 <= k1) {
+    f4_t v[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(int64_t)(k + j < k1 ? k + j : k1 - 1) * stride];
+    for (int j = 0; j < 4; ++j) v[j] = part[(int64_t)(k + j) * stride];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (k + j < k1) s += v[j];
+    for (int j = 0; j < 4; ++j) s += v[j];
+    k += 4;
   }
+  if (k + 2 <= k1) {
+    const f4_t v0 = part[(int64_t)k * stride], v1 = part[(int64_t)(k + 1) * stride];
+    s += v0;
+    s += v1;
+    k += 2;
+  }
+  if (k < k1) s += part[(int64_t)k * stride];
   return s;
 }
 
@@ -370,6 +379,8 @@ struct HeadArgs {
   // population of image i: i / n_per_group, its vectors at + population * gstride floats); op_head_affine_ok()
   const float* scale4 = nullptr; const float* shift4 = nullptr; int n_per_group = 0, gstride = 0;
   float* tbuf = nullptr; int64_t tbuf_bytes = 0;   // optional (n, Hh*Wh, 16) fp32 scratch: lets large maps be sliced over workgroups
+  const BnAccArgs* bn = nullptr;   // with scale4: the vectors are DERIVED by the head's first kernel from conv4's exact accumulators and
+                                   // stored at scale4 / shift4 (+ the backward's vectors): no finalize launch in front of the head
 };
 bool op_head_affine_ok(int dtype, int c);
 int op_head_forward(hipStream_t st, int dtype, const HeadArgs& a);

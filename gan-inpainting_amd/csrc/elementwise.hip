@@ -1214,29 +1214,16 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, 
     p[i] = w;
   }
 }
-// flag[2] |= 1 when any element of g is inf or NaN. finish != 0: the workgroup that ends last also does what
-// check_finite_finish_kernel does (one launch less per optimizer step): every workgroup adds 2 to flag[2] after its own OR - the
-// adds and ORs on one word are totally ordered at the memory side - so the add that returns 2 * (gridDim.x - 1) (+ the bad bit) has
-// seen every workgroup's verdict in its return value.
-__global__ void __launch_bounds__(256) check_finite_kernel(const float* __restrict__ g, int64_t count, int* flag, int finish) {
+// flag[2] |= 1 when any element of g is inf or NaN.
+// (Measured and dropped in round 4: the workgroup that ends last also doing the finish - every workgroup adds to a ticket on the
+//  same word after its OR - made the scan 5 -> 20 us on the critic's 1350 workgroups: 1350 returning atomics on one address at ~12 ns.)
+__global__ void __launch_bounds__(256) check_finite_kernel(const float* __restrict__ g, int64_t count, int* flag) {
   int bad = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const unsigned u = __float_as_uint(g[i]);
     bad |= ((u & 0x7F800000u) == 0x7F800000u) ? 1 : 0;
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag + 2, 1);
-  if (!finish) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's OR has been performed (acknowledged) ...
-  __syncthreads();                                   // ... and so have the other waves' before thread 0 adds
-  if (threadIdx.x == 0) {
-    const int old = atomicAdd(flag + 2, 2);
-    if ((old >> 1) == (int)gridDim.x - 1) {
-      const int b = old & 1;
-      flag[1] = b;
-      flag[0] += b;
-      flag[2] = 0;
-    }
-  }
 }
 // flag[1] = this update's verdict, flag[0] += it (running count of skipped updates), flag[2] = 0
 __global__ void check_finite_finish_kernel(int* flag) {
@@ -1864,13 +1851,7 @@ int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, in
 }
 int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
   GI_REQUIRE(ctx && g && flag3 && count > 0, "check_finite_scan: bad argument");
-  hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks(count, 8)), dim3(256), 0, ctx->stream, g, count, flag3, 0);
-  GI_LAUNCH_CHECK();
-  return GI_OK;
-}
-int gi_check_finite_last(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
-  GI_REQUIRE(ctx && g && flag3 && count > 0, "check_finite_last: bad argument");
-  hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks(count, 8)), dim3(256), 0, ctx->stream, g, count, flag3, 1);
+  hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks(count, 8)), dim3(256), 0, ctx->stream, g, count, flag3);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
@@ -1880,7 +1861,10 @@ int gi_check_finite_finish(gi_ctx* ctx, int* flag3) {
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
-int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3) { return gi_check_finite_last(ctx, g, count, flag3); }
+int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
+  GI_TRY(gi_check_finite_scan(ctx, g, count, flag3));
+  return gi_check_finite_finish(ctx, flag3);
+}
 int gi_clamp(gi_ctx* ctx, float* p, int64_t count, float lo, float hi) {
   hipLaunchKernelGGL(clamp_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, count, lo, hi);
   GI_LAUNCH_CHECK();

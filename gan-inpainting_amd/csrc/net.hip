@@ -1460,7 +1460,8 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   GI_TRY(op_c1_gather(st, dt, x, net->params + net->dconv[1].w_off, net->slot(s, net->oA[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_LRELU, 1.f));
   // the copy of the input that conv1's weight gradient reads rides in conv2's normalisation pass where that pass takes a side
   // copy (accumulator path); otherwise a device copy
-  bool x_saved = false;
+  bool x_saved = false, a4_deferred = false;
+  BnAccArgs a4_acc;
   for (int i = 2; i <= 4; ++i) {
     const Conv& c = net->dconv[i];
     const int Hs = H >> i, Ws = W >> i;
@@ -1471,6 +1472,12 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
                  true, &nt, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, &sp));
     const bool side = i == 2 && sp.use && ((int64_t)n * H * W * 4) % 16 == 0;
     // conv4 feeds only the head: its BatchNorm + LeakyReLU is applied by the head kernels from the raw tensor
+    if (i == 4 && fuse_a4 && sp.use && gi_opt(GI_OPT_HEAD_FAST)) {   // the head's first kernel derives conv4's scale / shift itself (HeadArgs::bn)
+      a4_acc = bn_acc_args(net, s, net->dbn[i], sp, (int64_t)n * Hs * Ws / net->bn_groups, net->bn_groups);
+      bn_acc_commit(net, s, net->dbn[i], sp);
+      a4_deferred = true;
+      continue;
+    }
     GI_TRY(bn_forward(net, s, net->dbn[i], R, (int64_t)n * Hs * Ws, nt, net->slot(s, net->oA[i]), c.ca, 0, GI_ACT_LRELU, nullptr, 1.f, train,
                       !(i == 4 && fuse_a4), &sp, 0.f, 0, side ? x : nullptr, side ? net->slot(s, net->oX) : nullptr,
                       side ? (int64_t)n * H * W * 4 : 0));
@@ -1482,6 +1489,7 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   if (fuse_a4) {
     BNPtrs p = bn_ptrs(net, s, net->dbn[4]);
     h.scale4 = p.scale; h.shift4 = p.shift; h.n_per_group = n / net->bn_groups; h.gstride = 4 * 512;
+    if (a4_deferred) h.bn = &a4_acc;
   }
   if (net->oHt >= 0) { h.tbuf = (float*)net->shared(net->oHt); h.tbuf_bytes = net->ht_bytes; }
   h.w5 = net->params + net->w5_off; h.wl = net->params + net->wl_off; h.bl = net->params + net->bl_off;

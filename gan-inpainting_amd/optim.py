@@ -44,13 +44,10 @@ class _FlatOptimizer:
         lib = B.lib()
         if self._flags is None:
             self._flags = torch.zeros(3, dtype=torch.int32, device=self.nets[0].flat_params().device)
-        for i, net in enumerate(self.nets):   # the last buffer's scan also finishes (one launch less per update)
+        for net in self.nets:
             g = net.flat_grads()
-            last = i == len(self.nets) - 1 and hasattr(lib, "gi_check_finite_last")    # (absent only in an older A/B build)
-            scan = lib.gi_check_finite_last if last else lib.gi_check_finite_scan
-            B.check(scan(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags)))
-        if not hasattr(lib, "gi_check_finite_last"):
-            B.check(lib.gi_check_finite_finish(B.get_ctx(self._flags.device), B.ptr(self._flags)))
+            B.check(lib.gi_check_finite_scan(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags)))
+        B.check(lib.gi_check_finite_finish(B.get_ctx(self._flags.device), B.ptr(self._flags)))
         return B.ptr(self._flags)
 
     def poll_skipped(self):

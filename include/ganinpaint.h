@@ -247,8 +247,6 @@ int gi_check_finite(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
  * update share one verdict (all skip or none) and the running count advances by one per skipped update. */
 int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
 int gi_check_finite_finish(gi_ctx* ctx, int* flag3);
-/* scan + finish in ONE launch (the workgroup that ends last finishes): the last - or only - buffer of an update */
-int gi_check_finite_last(gi_ctx* ctx, const float* g, int64_t count, int* flag3);
 int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr,
                          float beta1, float beta2, float eps, int step, float grad_scale, const int* guard);
 /* skipped_seen >= 0: `step` counts every call since the start minus the skipped updates the host has already learned of
