@@ -71,6 +71,7 @@ PROTOTYPES = {
     "gi_loss_mse": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _f, _vp]),
     "gi_loss_local": (_i, [_vp, _vp, _vp, _vp, _i64, _i, _vp, _vp, _f, _vp]),
     "gi_loss_adv": (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _f]),
+    "gi_loss_adv_pair": (_i, [_vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp, _f, _f]),
     "gi_adam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f]),
     "gi_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f]),
     "gi_clamp": (_i, [_vp, _vp, _i64, _f, _f]),

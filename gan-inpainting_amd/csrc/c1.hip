@@ -1137,6 +1137,19 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
   float* red = t_lds + (tbuf ? 0 : ((npx * HT_PITCH + 3) & ~3));   // 16-byte aligned
   half_t* wh = (half_t*)(red + 16);
   float* aff = (float*)(wh + 16 * 512);
+  // this wave's first pixel tile is requested before the prologue (weights to LDS, the scale / shift derivation with its accumulator
+  // round trip): at the critic's map sizes a wave owns ONE tile, so that is all of its activation traffic
+  const char* img = a4 + (int64_t)nn * npx * 1024;
+  const int ntile = (npx + 15) / 16;
+  const int tile0 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices) / slices) : 0;
+  const int tile1 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices + 1) / slices) : ntile;
+  h8_t av[16];
+  {
+    const int t0 = tile0 + wave < tile1 ? tile0 + wave : tile0;     // (a wave without a tile loads one it will not use)
+    const char* row = img + (int64_t)min(t0 * 16 + (lane & 15), npx - 1) * 1024 + (lane >> 4) * 16;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) av[ks] = *(const h8_t*)(row + ks * 64);
+  }
   if (sc4 && use_fa) {
     // the scale / shift vectors do not exist yet: derived here from conv4's exact accumulators (bn_acc.h) - every workgroup the
     // vectors of its image's population; workgroup 0 publishes ALL populations' vectors (sc4 / sh4 and the backward's), moves the
@@ -1171,16 +1184,13 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
   h8_t bf[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bf[ks] = *(const h8_t*)(wh + (lane & 15) * 512 + ks * 32 + (lane >> 4) * 8);
-  const char* img = a4 + (int64_t)nn * npx * 1024;
-  const int ntile = (npx + 15) / 16;
-  const int tile0 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices) / slices) : 0;
-  const int tile1 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices + 1) / slices) : ntile;
   for (int tile = tile0 + wave; tile < tile1; tile += 16) {
-    const int px = min(tile * 16 + (lane & 15), npx - 1);
-    const char* row = img + (int64_t)px * 1024 + (lane >> 4) * 16;
-    h8_t av[16];
+    if (tile != tile0 + wave) {      // later tiles of this wave (large maps)
+      const int px = min(tile * 16 + (lane & 15), npx - 1);
+      const char* row = img + (int64_t)px * 1024 + (lane >> 4) * 16;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) av[ks] = *(const h8_t*)(row + ks * 64);
+      for (int ks = 0; ks < 16; ++ks) av[ks] = *(const h8_t*)(row + ks * 64);
+    }
     if (sc4) {
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks) {

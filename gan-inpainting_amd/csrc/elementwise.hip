@@ -1144,10 +1144,12 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const float* a, const fl
   }
 }
 
-// adversarial losses on (n,) predictions
+// adversarial losses on (n,) predictions. Workgroup b of a two-workgroup launch (gi_loss_adv_pair: the [real | fake] halves of a
+// stacked discriminator batch, their targets, loss slots and gradient signs) works on the b-th half.
 __global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n, int kind, float target, float* loss_out,
-                                                       float* grad, float gscale) {
+                                                       float* grad, float gscale, float target1, float* loss_out1, float gscale1) {
   __shared__ double sh[4];
+  if (blockIdx.x == 1) { pred += n; if (grad) grad += n; target = target1; loss_out = loss_out1; gscale = gscale1; }
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     const float p = pred[i];
@@ -1809,7 +1811,15 @@ int gi_loss_local(gi_ctx* ctx, const float* yhat, const float* y, const float* m
 }
 int gi_loss_adv(gi_ctx* ctx, const float* pred, int n, int kind, float target, float* loss_out, float* grad_pred, float gscale) {
   GI_REQUIRE(kind >= 0 && kind <= 2 && n > 0, "loss_adv: kind=%d n=%d", kind, n);
-  hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, ctx->stream, pred, n, kind, target, loss_out, grad_pred, gscale);
+  hipLaunchKernelGGL(adv_loss_kernel, dim3(1), dim3(256), 0, ctx->stream, pred, n, kind, target, loss_out, grad_pred, gscale, 0.f, (float*)nullptr, 0.f);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+int gi_loss_adv_pair(gi_ctx* ctx, const float* pred2, int n_each, int kind, float target_a, float target_b, float* loss_a, float* loss_b,
+                     float* grad_pred2, float gscale_a, float gscale_b) {
+  GI_REQUIRE(ctx && pred2 && loss_a && loss_b && kind >= 0 && kind <= 2 && n_each > 0, "loss_adv_pair: kind=%d n=%d", kind, n_each);
+  hipLaunchKernelGGL(adv_loss_kernel, dim3(2), dim3(256), 0, ctx->stream, pred2, n_each, kind, target_a, loss_a, grad_pred2, gscale_a, target_b, loss_b,
+                     gscale_b);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

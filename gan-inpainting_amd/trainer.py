@@ -44,6 +44,11 @@ class _Ops:
         B.check(B.lib().gi_loss_adv(self.ctx, B.ptr(pred), pred.numel(), kind, float(target), B.ptr(loss_out), B.ptr(grad),
                                     float(gscale)))
 
+    def adv_pair(self, pred2, n, kind, t_a, t_b, loss_a, loss_b, grad2, gs_a=1.0, gs_b=1.0):
+        """adv() of both halves of a stacked [a | b] prediction vector in one launch (gi_loss_adv_pair)."""
+        B.check(B.lib().gi_loss_adv_pair(self.ctx, B.ptr(pred2), int(n), kind, float(t_a), float(t_b), B.ptr(loss_a), B.ptr(loss_b),
+                                         B.ptr(grad2), float(gs_a), float(gs_b)))
+
     def recon(self, kind, a, b, loss_out, grad, gscale=1.0):
         lib = B.lib()
         if kind == "l1":
@@ -213,8 +218,7 @@ class _StepBase:
         if fake.data_ptr() != x2[n:].data_ptr():      # the caller may have produced `fake` in the pair buffer already
             x2[n:].copy_(fake)
         p, t = self._fwd(net, x2, bn_groups=2)
-        o.adv(p[:n], kind, t_real, self._loss(name_real), dp2[:n], gs_real)
-        o.adv(p[n:], kind, t_fake, self._loss(name_fake), dp2[n:], gs_fake)
+        o.adv_pair(p, n, kind, t_real, t_fake, self._loss(name_real), self._loss(name_fake), dp2, gs_real, gs_fake)
         if synced:
             self._bwd_D_synced(net, t, dp2)
         else:

@@ -229,6 +229,10 @@ int gi_loss_local(gi_ctx* ctx, const float* yhat, const float* y, const float* m
  * 2 mean (wgan_l1.py:137-143,177; gscale carries the +1/-1 of backward(one/mone)) */
 int gi_loss_adv(gi_ctx* ctx, const float* pred, int n, int kind, float target, float* loss_out,
                 float* grad_pred, float gscale);
+/* the two calls of a batch on a stacked [a | b] prediction vector (2 * n_each values: D(ground) | D(inpainted),
+ * wgan_l1.py:134-143) in ONE launch: the same arithmetic per half, each with its own target, loss slot and gradient sign */
+int gi_loss_adv_pair(gi_ctx* ctx, const float* pred2, int n_each, int kind, float target_a, float target_b, float* loss_a,
+                     float* loss_b, float* grad_pred2, float gscale_a, float gscale_b);
 
 /* ---- optimizers over flat fp32 buffers: optim.Adam(lr=2e-4,betas=(.5,.999))
  *      (minimaxgan_l1.py:64-65), optim.RMSprop(lr=5e-5) + p.data.clamp_(-c,c)

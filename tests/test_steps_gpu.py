@@ -20,13 +20,14 @@ LOSS_TOL = {"fp32": 2e-3, "fp16": 3e-2}
 # of the same graph: the build container's reference run, the GPU box's CPU re-run of the oracle and
 # an fp64 evaluation gave g_adv = 2.665852 / 2.658785 / 2.665300 (tools/debug_parity.py).
 # fp16: gradient rounding (~1e-3 relative) decides the sign, i.e. the whole +-lr move, of every element
-# whose gradient is below that level, and the fp32 atomics of the weight-gradient kernels make that set
-# differ from run to run: three runs of this file on one box gave minimax it1 d_loss_fake errors of
-# 3.4e-2 / 3.9e-2 / 6.1e-2 and g_adv 2.5e-2 / 2.7e-3 / 3.1e-2. The bound is set at 2.5x that spread;
-# the tight fp16 checks are the pre-update ones (it0 losses 3e-2, single-pass gradients in
-# test_nets_gpu.py) and the parameter statistics below.
-LOSS_TOL_AFTER_ADAM = {"fp32": 1e-2, "fp16": 0.15}
-GRADFLOW_TOL_AFTER_ADAM = {"fp32": 0.15, "fp16": 0.4}
+# whose gradient is below that level. The kernels are bit-reproducible since round 3 (no float atomics on
+# the training paths: test_*_reproducible), so these numbers no longer move from run to run; measured in
+# round 4 against the reference fixture (gpurun_out/r4_steps_print.txt): after the Adam step fp32 losses
+# <= 5.5e-4 and gradient-flow statistics <= 2.2e-2, fp16 losses <= 3.8e-2 and gradient flow <= 7.2e-2;
+# before it (it0) fp32 1.3e-6 / 1.2e-4, fp16 2.0e-4 / 1.8e-2. The bounds are about twice the measured values.
+LOSS_TOL_AFTER_ADAM = {"fp32": 2e-3, "fp16": 8e-2}
+GRADFLOW_TOL_AFTER_ADAM = {"fp32": 5e-2, "fp16": 0.15}
+GRADFLOW_TOL_IT0 = {"fp32": 1e-3, "fp16": 4e-2}
 STAT_TOL = {"fp32": 2e-4, "fp16": 2e-3}
 
 
@@ -78,7 +79,7 @@ def test_minimax_steps_vs_reference(dtype):
         ref = {n: float(v) for n, v in zip(names, fx[f"it{it}_g_grad_absmean"])}
         got = gflow.as_dict()
         assert list(got.keys()) == [n for n in names if "bias" not in n]
-        tol = (5e-3 if dtype == "fp32" else 8e-2) if it == 0 else GRADFLOW_TOL_AFTER_ADAM[dtype]   # it>0: post-Adam chaos, see LOSS_TOL_AFTER_ADAM
+        tol = GRADFLOW_TOL_IT0[dtype] if it == 0 else GRADFLOW_TOL_AFTER_ADAM[dtype]   # it>0: post-Adam chaos, see LOSS_TOL_AFTER_ADAM
         worst = max(abs(v - ref[n]) / (abs(ref[n]) + 1e-12) for n, v in got.items())
         print(f"minimax it{it} gradient-flow worst rel {worst:.2e} (bound {tol:.2e})")
         for n, v in got.items():

@@ -30,12 +30,14 @@ run step_critic rocprofv3 --kernel-trace --output-format csv -d $OUT/step_critic
 run step_gen rocprofv3 --kernel-trace --output-format csv -d $OUT/step_gen -- python3 $R/tools/step_chain.py 4 gen
 # F. secondary workloads: the plain line (no profiler) and the kernel statistics
 for wl in wgan_gp_128 dual_d_256 config5_512 vgg_512; do
-  run line_$wl python3 $R/bench.py --workload $wl --steps 20 --warmup 5 --preheat 50 --no-cpu-baseline
+  run line_$wl python3 $R/bench.py --workload $wl --steps 20 --warmup 5 --preheat 50      # (with its reduced cpu_baseline: 1 + 2 + 1 batches)
   run stats_$wl rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -- python3 $R/bench.py --workload $wl --steps 10 --warmup 5 --preheat 10 --no-cpu-baseline
 done
 # G. the headline line itself, unprofiled (with the CPU baseline); H. the multi-rank launch path rehearsed with two gloo ranks on
 # this one card (RCCL needs one GPU per rank: the 8-GPU run is the driver's)
 run line_headline python3 $R/bench.py --steps 20 --warmup 5
 GI_DIST_BACKEND=gloo run line_two_ranks_gloo python3 $R/bench.py --gpus 2 --steps 10 --warmup 2 --preheat 20 --no-cpu-baseline
+# I. per-layer / per-instantiation table of the GEMM-shaped launches (HIP events, no profiler)
+run layer_table python3 $R/tools/layer_table.py $TAG 30
 find $OUT -name "*.csv" | wc -l
 echo done
