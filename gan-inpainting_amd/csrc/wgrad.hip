@@ -229,8 +229,41 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WP p) {
         }
       }
   };
-  if (p.part) emit(std::integral_constant<int, 0>{});
-  else if (p.direct) emit(std::integral_constant<int, 1>{});
+  if (p.part) { emit(std::integral_constant<int, 0>{}); return; }
+  if constexpr (F16) {
+    if (p.direct) {
+      // One workgroup per output tile (no pixel-range split: the U-Net's innermost levels, 16.8 MB of gradient for <= 4 GFLOP):
+      // dW += tile as 16-byte read-modify-writes of whole 256-byte rows through a wave-private LDS slab - a lane holds one COLUMN of
+      // four rows per accumulator, so the direct form was 64 four-byte loads + 64 four-byte stores per lane on 64-byte segments
+      // (d6 / d7 / u7 weight gradients: 28 - 37 us for 33.5 MB of traffic). Rows padded to 68 floats (two-way write conflicts: free).
+      __syncthreads();                                  // every wave has read its last fragments: the staging buffers are free
+      float* slab = (float*)smem + wave * (64 * 68);
+      const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) slab[(mt * 16 + lq * 4 + r) * 68 + nt * 16 + lr] = acc[mt][nt][r] * p.scale;
+      __builtin_amdgcn_s_waitcnt(0xC07F);               // lgkmcnt(0): the slab is wave-private, no workgroup barrier
+      __builtin_amdgcn_wave_barrier();
+      f4_t* rowp[16];
+      f4_t cur[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                    // all sixteen loads of dW first
+        const int rr = i * 4 + lq;
+        rowp[i] = (f4_t*)(p.dW + (int64_t)(a0 + wm * 64 + rr) * ldw + n0 + wn * 64 + lr * 4);
+        cur[i] = *rowp[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const f4_t v = *(const f4_t*)(slab + (i * 4 + lq) * 68 + lr * 4);
+        *rowp[i] = cur[i] + v;
+      }
+      return;
+    }
+  }
+  if (p.direct) emit(std::integral_constant<int, 1>{});
   else emit(std::integral_constant<int, 2>{});
 }
 

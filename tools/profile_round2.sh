@@ -4,11 +4,14 @@ set -u
 # usage: tools/profile_round2.sh <tag>     -> gpurun_out/prof_<tag>/..., summarised by tools/summarize_round2.py <tag>
 set -o pipefail
 TAG=${1:-r02}
+PART=${2:-all}      # all | 1 (A - E: dominant kernel, benchmark process, counters, chains) | 2 (F - I: secondary workloads, headline line, two ranks, layer table)
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the tools run on the GPU box through gpurun)}
 OUT=$R/gpurun_out/prof_$TAG
-rm -rf $OUT; mkdir -p $OUT
+if [ "$PART" != "2" ]; then rm -rf $OUT; fi
+mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name"; timeout -k 10 600 "$@" > $OUT/$name.log 2>&1 || { echo "$name failed"; tail -5 $OUT/$name.log; }; }
+if [ "$PART" != "2" ]; then
 # A. the dominant kernel alone; B. the whole benchmark process; C. its HBM traffic (one --pmc pass per counter)
 run kernel_only rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kernel_only -- python3 $R/bench.py --kernel-only --kernel-iters 50
 run bench rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python3 $R/bench.py --steps 20 --warmup 5 --preheat 50 --no-cpu-baseline
@@ -28,6 +31,8 @@ done
 run gfwd rocprofv3 --kernel-trace --output-format csv -d $OUT/gfwd -- python3 $R/tools/gfwd_only.py 20
 run step_critic rocprofv3 --kernel-trace --output-format csv -d $OUT/step_critic -- python3 $R/tools/step_chain.py 4 critic
 run step_gen rocprofv3 --kernel-trace --output-format csv -d $OUT/step_gen -- python3 $R/tools/step_chain.py 4 gen
+fi
+if [ "$PART" != "1" ]; then
 # F. secondary workloads: the plain line (no profiler) and the kernel statistics
 for wl in wgan_gp_128 dual_d_256 config5_512 vgg_512; do
   run line_$wl python3 $R/bench.py --workload $wl --steps 20 --warmup 5 --preheat 50      # (with its reduced cpu_baseline: 1 + 2 + 1 batches)
@@ -39,5 +44,6 @@ run line_headline python3 $R/bench.py --steps 20 --warmup 5
 GI_DIST_BACKEND=gloo run line_two_ranks_gloo python3 $R/bench.py --gpus 2 --steps 10 --warmup 2 --preheat 20 --no-cpu-baseline
 # I. per-layer / per-instantiation table of the GEMM-shaped launches (HIP events, no profiler)
 run layer_table python3 $R/tools/layer_table.py $TAG 30
+fi
 find $OUT -name "*.csv" | wc -l
 echo done
