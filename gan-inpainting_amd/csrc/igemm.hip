@@ -389,32 +389,35 @@ __global__ void __launch_bounds__(256, 2) igemm_kernel(KP p) {
   T* stg = (T*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * sizeof(T));  // [WGM][BN][2]
 
+  const bool stats = p.partials || p.stat_acc;
+  gi_with_act(p.act_out, [&](auto ACTc) {              // the activation as a compile-time constant (common.h): no test per element
+    constexpr int ACT = decltype(ACTc)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = elem_col(nt);
-    const float b = p.bias ? p.bias[n0 + col] : 0.f;
-    float s = 0.f, q = 0.f;
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = elem_col(nt);
+      const float b = p.bias ? p.bias[n0 + col] : 0.f;
+      float s = 0.f, q = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int r = 0; r < NR; ++r) {
-        float v = acc[mt][nt][r] + b;
-        s += v;
-        q += v * v;
-        v = apply_act(v, p.act_out);
-        stg[elem_row(mt, r) * SLD + col] = (T)v;
-      }
-    if (p.partials || p.stat_acc) {
-      if constexpr (F16) {
-        s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
-        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (lane < 16) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
-      } else {
-        s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-        if (lane < 32) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+        for (int r = 0; r < NR; ++r) {
+          float v = acc[mt][nt][r] + b;
+          s += v;
+          q += v * v;
+          stg[elem_row(mt, r) * SLD + col] = (T)gi_act_c<ACT>(v);
+        }
+      if (stats) {
+        if constexpr (F16) {
+          s += __shfl_xor(s, 16); q += __shfl_xor(q, 16);
+          s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+          if (lane < 16) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+        } else {
+          s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+          if (lane < 32) { red[(wm * BN + col) * 2] = s; red[(wm * BN + col) * 2 + 1] = q; }
+        }
       }
     }
-  }
+  });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
     float s = 0.f, q = 0.f;
