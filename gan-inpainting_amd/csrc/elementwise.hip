@@ -365,6 +365,19 @@ __device__ __forceinline__ void finish_dz(const BwdP& p, const DzIn<T, EPC>& in,
     dz[e] = g * sl * p.drop_scale;
   }
 }
+// the same with the set of inputs (IN: bit 0 = g1, bit 1 = g2) known at compile time and the two launch constants in registers: no
+// test per element
+template <typename T, int EPC, int IN>
+__device__ __forceinline__ void finish_dz_c(float ns, float drop_scale, const DzIn<T, EPC>& in, const float (&sgn)[EPC], float (&dz)[EPC]) {
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const bool pos = sgn[e] > 0.f;
+    float g = (IN & 1) ? in.g1[e] : 0.f;
+    if constexpr ((IN & 2) != 0) g += pos ? in.g2[e] : 0.f;
+    const float sl = pos ? 1.f : ns;
+    dz[e] = g * sl * drop_scale;
+  }
+}
 template <typename T, int EPC>
 __device__ __forceinline__ void compute_dz(const BwdP& p, int64_t pix, int ch0, float (&dz)[EPC]) {
   DzIn<T, EPC> in;
@@ -396,6 +409,7 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
     for (int e = 0; e < EPC; ++e) { sc[e] = p.scale[so + q * EPC + e]; sh[e] = p.shift[so + q * EPC + e]; }
   }
   const bool need_y = p.g2 != nullptr || p.act != GI_ACT_NONE;
+  const float ns = neg_slope_of(p.act), drop_scale = p.drop_scale;
   constexpr int U = 4;   // rows whose loads are in flight together (the sums still run over the rows in ascending order)
   constexpr int64_t ES = (int64_t)sizeof(T);
   const bool have_scale = p.scale != nullptr;
@@ -425,7 +439,7 @@ __global__ void __launch_bounds__(256) act_bn_bwd_reduce_kernel(BwdP p) {
           for (int e = 0; e < EPC; ++e) in.y[e] = have_scale ? fmaf(xv[e], sc[e], sh[e]) : 1.f;
         }
         (void)need_y;
-        finish_dz<T, EPC>(p, in, in.y, dz);
+        finish_dz_c<T, EPC, IN>(ns, drop_scale, in, in.y, dz);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) { s[e] += dz[e]; sx[e] = fmaf(dz[e], (xv[e] - mu[e]) * iv[e], sx[e]); }
       }
