@@ -46,6 +46,10 @@ class _Ops:
 
     def adv_pair(self, pred2, n, kind, t_a, t_b, loss_a, loss_b, grad2, gs_a=1.0, gs_b=1.0):
         """adv() of both halves of a stacked [a | b] prediction vector in one launch (gi_loss_adv_pair)."""
+        if not hasattr(B.lib(), "gi_loss_adv_pair"):      # an older build loaded through GI_LIB_PATH for an A/B run
+            self.adv(pred2[:n], kind, t_a, loss_a, grad2[:n], gs_a)
+            self.adv(pred2[n:], kind, t_b, loss_b, grad2[n:], gs_b)
+            return
         B.check(B.lib().gi_loss_adv_pair(self.ctx, B.ptr(pred2), int(n), kind, float(t_a), float(t_b), B.ptr(loss_a), B.ptr(loss_b),
                                          B.ptr(grad2), float(gs_a), float(gs_b)))
 
