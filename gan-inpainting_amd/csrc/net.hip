@@ -119,6 +119,15 @@ struct gi_net {
   int fuse_head = 1;                 // generator: last decoder level's BatchNorm + ReLU applied inside the head kernels
   std::vector<int> slot_fused_u2;    // per slot: the forward ran that way (the backward must match)
   int64_t oWg = -1, wg_bytes = 0;    // weight-gradient split scratch (deterministic two-stage reduction)
+  // GI_WGRAD_STREAM: the weight-gradient GEMMs of a backward (and their fixed-order reduce launches) run on a second HIP stream
+  // beside the input-gradient chain, which never reads their result. dz buffers rotate (oDr; oD == oDr[0]) so that the chain
+  // does not wait for a weight gradient before it overwrites its operand; gi_net_backward[_phase] joins before it returns.
+  int64_t oDr[3] = {-1, -1, -1};
+  hipStream_t st2 = nullptr;
+  hipEvent_t ev_dz = nullptr, ev_wg[3] = {nullptr, nullptr, nullptr};
+  bool wg_busy[3] = {false, false, false};
+  int dz_i = 0;
+  bool side = false;                 // (transient) the backward in progress uses st2
   // train-mode BatchNorm statistics without a reduction launch: the GEMM epilogues add their tile sums into exact
   // per-channel accumulators (stat_acc.h), the normalisation pass derives scale / shift from them itself (and the backward
   // reductions likewise). Regions per BatchNorm layer: BN::acc_off; all zero after gi_net_bind, then kept zero by the
@@ -286,7 +295,9 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
     maxD = max64(maxD, pix * net->ch[nd] * T);
     maxSplit = max64(maxSplit, pix * net->ch[nd] * 4);
   }
-  net->oD = A.take(maxD);
+  net->oD = net->oDr[0] = A.take(maxD);
+  net->oDr[1] = A.take(maxD);
+  net->oDr[2] = A.take(maxD);
   net->oG0 = A.take(N * H * W * 4 * out_c);
   if (out_c > 1) {   // u1 on the generic kernels: weights [a][16][b] with b zero-padded to 64, NHWC staging buffer
     const int64_t cnt = (int64_t)2 * net->ch[1] * 16 * 64;
@@ -412,7 +423,9 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
     maxPart = max64(maxPart, part_rows(pix) * 2 * chans[i] * 3);   // x3: room for the per-group column pass (BN groups)
     if (pix <= 32768) maxSplit = max64(maxSplit, pix * chans[i] * 4);
   }
-  net->oD = A.take(maxD);
+  net->oD = net->oDr[0] = A.take(maxD);
+  net->oDr[1] = A.take(maxD);
+  net->oDr[2] = A.take(maxD);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
   net->oSums = A.take(2 * 8 * 512 * 4);   // [groups][8][c]: sums + apply coefficients
@@ -473,6 +486,11 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
 }
 
 extern "C" int gi_net_destroy(gi_net* net) {
+  if (net) {
+    if (net->st2) { (void)hipStreamSynchronize(net->st2); (void)hipStreamDestroy(net->st2); }
+    if (net->ev_dz) (void)hipEventDestroy(net->ev_dz);
+    for (hipEvent_t e : net->ev_wg) if (e) (void)hipEventDestroy(e);
+  }
   delete net;
   return GI_OK;
 }
@@ -797,7 +815,55 @@ int wgrad(gi_net* net, const void* S, int ca, int ldS, int coffS, int relu_S, co
   a.relu_S = relu_S; a.scale = 1.f / net->loss_scale;
   a.scratch = net->wg_bytes > 0 ? (float*)net->shared(net->oWg) : nullptr;
   a.scratch_bytes = net->wg_bytes;
-  return op_wgrad(net->ctx->stream, net->dtype, a);
+  if (!net->side) return op_wgrad(net->ctx->stream, net->dtype, a);
+  // second stream: starts when everything the chain has issued so far (dz of this level) is done; the event recorded behind it
+  // guards the dz buffer of this level (side_dz)
+  GI_HIP(hipEventRecord(net->ev_dz, net->ctx->stream));
+  GI_HIP(hipStreamWaitEvent(net->st2, net->ev_dz, 0));
+  GI_TRY(op_wgrad(net->st2, net->dtype, a));
+  GI_HIP(hipEventRecord(net->ev_wg[net->dz_i], net->st2));
+  net->wg_busy[net->dz_i] = true;
+  return GI_OK;
+}
+
+// --- second stream of a backward (gi_net::st2) ---
+int side_begin(gi_net* net, int need_wgrad) {
+  net->side = false;
+  net->dz_i = 0;
+  if (!need_wgrad || !gi_opt(GI_OPT_WGRAD_STREAM) || (net->kind == 0 && net->norm_kind != 0)) return GI_OK;
+  if (!net->st2) {
+    if (gi_opt(GI_OPT_WGRAD_STREAM) == 2) {   // lowest priority: the weight gradients fill what the chain leaves free
+      int least = 0, greatest = 0;
+      GI_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      GI_HIP(hipStreamCreateWithPriority(&net->st2, hipStreamNonBlocking, least));
+    } else {
+      GI_HIP(hipStreamCreateWithFlags(&net->st2, hipStreamNonBlocking));
+    }
+    GI_HIP(hipEventCreateWithFlags(&net->ev_dz, hipEventDisableTiming));
+    for (hipEvent_t& e : net->ev_wg) GI_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  net->side = true;
+  return GI_OK;
+}
+// the chain's stream waits for every weight gradient still in flight (also after an error return: the flags outlive the call)
+int side_join(gi_net* net) {
+  for (int i = 0; i < 3; ++i)
+    if (net->wg_busy[i]) {
+      net->wg_busy[i] = false;
+      GI_HIP(hipStreamWaitEvent(net->ctx->stream, net->ev_wg[i], 0));
+    }
+  net->side = false;
+  return GI_OK;
+}
+// the buffer the next level's dz is written to
+void* side_dz(gi_net* net) {
+  if (!net->side) return net->shared(net->oDr[0]);
+  net->dz_i = (net->dz_i + 1) % 3;
+  if (net->wg_busy[net->dz_i]) {   // read by the weight gradient three levels back
+    net->wg_busy[net->dz_i] = false;
+    (void)hipStreamWaitEvent(net->ctx->stream, net->ev_wg[net->dz_i], 0);
+  }
+  return net->shared(net->oDr[net->dz_i]);
 }
 
 int act_bn_bwd(gi_net* net, int slot, const void* g1, int ldg1, int coffg1, const void* g2, int ldg2, int coffg2,
@@ -1172,7 +1238,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
   auto gC = [&](int k) { return (void*)net->shared(net->ogC[k]); };
   auto gA = [&](int k) { return (void*)net->shared(net->ogA[k]); };
-  void* D = net->shared(net->oD);
+  void* D = net->shared(net->oD);   // dz of the level in progress (side_dz: rotates when the weight gradients run on the second stream)
   float* G0 = (float*)net->shared(net->oG0);
   const int64_t npx = (int64_t)n * H * W;
   if (phase == 0 || phase == 1) {
@@ -1212,6 +1278,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     const int ck = net->ch[k];
     const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
     const float ds = (!evalbn && net->dropout_p > 0.f && kk >= 5 && kk <= nd - 1) ? 1.f / (1.f - net->dropout_p) : 1.f;
+    D = side_dz(net);
     GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, gC(k), 2 * ck, ck, C(k), 2 * ck, ck, net->slot(s, net->oU[kk]), D, pix, ck,
                       GI_ACT_NONE, ds, &net->unorm[kk], need_wgrad));
     const void* Sin = (kk == nd) ? (const void*)net->slot(s, net->oE) : C(kk);
@@ -1232,6 +1299,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   if (run_inner) {
     const int c = net->ch[nd];
     const int64_t pix = (int64_t)n * net->Hk[nd] * net->Wk[nd];
+    D = side_dz(net);
     GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, net->shared(net->ogE), c, 0, net->slot(s, net->oE), c, 0, nullptr, D, pix, c, GI_ACT_NONE,
                       1.f, nullptr, need_wgrad));
     const int cb = net->ch[nd - 1];
@@ -1245,6 +1313,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     if (k >= 5 ? !run_inner : !run_outer) continue;
     const int c = net->ch[k];
     const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
+    D = side_dz(net);
     GI_TRY(act_bn_bwd(net, s, gA(k), c, 0, gC(k), 2 * c, 0, C(k), 2 * c, 0, net->slot(s, net->oR[k]), D, pix, c, GI_ACT_LRELU, 1.f,
                       &net->dnorm[k], need_wgrad));
     const int cb = net->ch[k - 1];
@@ -1259,7 +1328,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   if (run_outer) {
     const int c = net->ch[1];
     const int64_t pix = (int64_t)n * net->Hk[1] * net->Wk[1];
-    void* D1 = D;
+    void* D1 = D = side_dz(net);
     if (lrelu1_done) D1 = gA(1);
     else GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
     if (need_wgrad)
@@ -1542,6 +1611,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
     const int Hs = H >> i, Ws = W >> i;
     const int64_t pix = (int64_t)n * Hs * Ws;
     BwdFuse& pend = net->bwd_pending[net->dbn[i].id];
+    D = side_dz(net);
     GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[i]), c.ca, 0, nullptr, 0, 0, net->slot(s, net->oA[i]), c.ca, 0, net->slot(s, net->oRd[i]),
                       D, pix, c.ca, GI_ACT_LRELU, 1.f, &net->dbn[i], need_wgrad, pend.planned ? &pend : nullptr));
     pend = BwdFuse();
@@ -1561,7 +1631,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
   }
   if (phase == 1) return GI_OK;
   const int64_t pix = (int64_t)n * (H / 2) * (W / 2);
-  void* D1 = D;
+  void* D1 = D = side_dz(net);
   if (lrelu1_done) {
     D1 = net->shared(net->ogA[1]);
   } else {
@@ -1787,11 +1857,19 @@ extern "C" int gi_net_saved_activation(gi_net* net, int slot, int kind, int leve
   return GI_OK;
 }
 
+// weight gradients on the second stream (side_begin), joined before the caller sees the gradients
+static int backward_joined(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad, int phase) {
+  GI_TRY(side_begin(net, need_wgrad));
+  const int rc = net->kind == 0 ? unet_backward(net, slot, dy, dx, need_wgrad, phase) : patchgan_backward(net, slot, dy, dx, need_wgrad, phase);
+  const int rj = side_join(net);
+  return rc != GI_OK ? rc : rj;
+}
+
 extern "C" int gi_net_backward(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad) {
   GI_REQUIRE(net && net->bound, "net_backward: net not bound");
   GI_REQUIRE(dy, "net_backward: dy is null");
   GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_backward: slot=%d", slot);
-  return net->kind == 0 ? unet_backward(net, slot, dy, dx, need_wgrad, 0) : patchgan_backward(net, slot, dy, dx, need_wgrad);
+  return backward_joined(net, slot, dy, dx, need_wgrad, 0);
 }
 
 extern "C" int gi_net_backward_phase(gi_net* net, int slot, const float* dy, float* dx, int need_wgrad, int phase) {
@@ -1799,11 +1877,8 @@ extern "C" int gi_net_backward_phase(gi_net* net, int slot, const float* dy, flo
   GI_REQUIRE(dy, "net_backward_phase: dy is null");
   GI_REQUIRE(slot >= 0 && slot < net->n_slots, "net_backward_phase: slot=%d", slot);
   GI_REQUIRE(phase >= 0 && phase <= 4, "net_backward_phase: phase=%d", phase);
-  if (net->kind != 0) {
-    if (phase >= 3) return GI_OK;   // discriminator: two phases
-    return patchgan_backward(net, slot, dy, dx, need_wgrad, phase);
-  }
-  return unet_backward(net, slot, dy, dx, need_wgrad, phase);
+  if (net->kind != 0 && phase >= 3) return GI_OK;   // discriminator: two phases
+  return backward_joined(net, slot, dy, dx, need_wgrad, phase);
 }
 
 // first float of the gradient region completed by phase 1 (generator: the innermost up-conv weight; discriminator:

@@ -69,7 +69,10 @@ int gi_version(void);
  *                         the layer (igemm7's last finisher per channel column) instead of as its own launch; bit-identical results.
  *                         Off by default: measured SLOWER (+8 .. 10 us per folded layer at the headline shape)
  *   GI_C1_FUSED [1]       0: the single-channel transposed convolution (generator u1, d1's input gradient) as two launches through a
- *                         col tensor in memory instead of one launch with the col rows in LDS; bit-identical results */
+ *                         col tensor in memory instead of one launch with the col rows in LDS; bit-identical results
+ *   GI_WGRAD_STREAM [1]   0: the weight-gradient GEMMs of gi_net_backward[_phase] on the context's stream, in line with the
+ *                         input-gradient chain, instead of on the network's second HIP stream beside it (the entry joins the two
+ *                         before it returns; same kernels, same operands, same results) */
 int gi_set_option(const char* name, int value);
 int gi_get_option(const char* name, int* value);
 /* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.

@@ -181,6 +181,23 @@ def test_network_level_option_equals_default_path(name, value, net_kind, option)
         assert rel_l2(st1[k], st0[k]) <= 1e-3, (k, rel_l2(st1[k], st0[k]))
 
 
+@pytest.mark.parametrize("net_kind", ["unet", "patchgan"])
+def test_weight_gradients_on_second_stream_are_bit_identical(net_kind, option):
+    """GI_WGRAD_STREAM (default 1) moves the weight-gradient GEMMs of a backward to the network's second HIP stream: same
+    kernels on the same operands, so every result must be EQUAL to the in-line order's, and equal again on a repeat (the
+    rotation of the dz buffers and the join at the end of the entry leave nothing behind)."""
+    run = _unet_run if net_kind == "unet" else _patchgan_run
+    y1, dx1, g1, st1 = run("fp16")
+    y2, dx2, g2, _ = run("fp16")
+    option("GI_WGRAD_STREAM", 0)
+    y0, dx0, g0, st0 = run("fp16")
+    for a, b, what in ((y1, y0, "output"), (dx1, dx0, "input gradient"), (g1, g0, "parameter gradients"), (g2, g0, "parameter gradients, repeat"),
+                       (dx2, dx0, "input gradient, repeat")):
+        assert torch.equal(a, b), f"{net_kind}: {what} differ between the two stream orders (max |d| {(a - b).abs().max().item():.3e})"
+    for k in st0:
+        assert torch.equal(st1[k], st0[k]), k
+
+
 def _unet_fold_run(N, HW, impose, seed=77):
     """one train-mode forward + backward of the fp16 generator; drawn dropout masks come from a fixed seed"""
     nd = 7 if HW >= 128 else 6

@@ -16,4 +16,8 @@ for k in (5, 6, 7):
     rows.append((f"d{k}",) + LT.conv(32, 256 >> k, 512, 512, iters))
 for k, ca in ((7, 512), (6, 1024), (5, 1024)):
     rows.append((f"u{k}",) + LT.convT(32, 256 >> k, ca, 512, 0 if k == 7 else 1, iters))
+rows.append(("u5dg",) + LT.conv(32, 8, 512, 1024, iters))
+rows.append(("u6dg",) + LT.conv(32, 4, 512, 1024, iters))
+rows.append(("d6dg",) + LT.convT(32, 4, 512, 512, 0, iters))
+rows.append(("d5dg",) + LT.convT(32, 8, 512, 512, 0, iters))
 print("  ".join(f"{n} {us:5.1f}us [{kern}]" for n, us, _, kern in rows), f"  sum {sum(r[1] for r in rows):.1f} us")
