@@ -128,6 +128,7 @@ class IgemmEx(C.Structure):
     _fields_ = [("relu_cend", _i),
                 ("mask", _vp), ("ldmask", _i), ("mask_slope", _f),
                 ("add", _vp), ("ldadd", _i),
+                ("mask_bits", _vp),
                 ("stat_acc", _vp), ("stat_reps", _i), ("stat_pg", _i),
                 ("partials", _vp),
                 ("bwd_x", _vp), ("bwd_ldx", _i),

@@ -25,7 +25,7 @@ OptDesc g_opts[GI_OPT_COUNT] = {
   {"GI_IGEMM5", 7, 0, 0}, {"GI_IGEMM6", 1, 0, 0}, {"GI_IGEMM7", 1, 0, 0}, {"GI_IGEMM_FIXUP", 1, 0, 0}, {"GI_IGEMM_VARIANT", 3, 0, 0},
   {"GI_BN_ACC", 1, 0, 0}, {"GI_FUSE_HEAD", 1, 0, 0}, {"GI_HEAD_FAST", 1, 0, 0}, {"GI_BN_BWD_FUSE", 1, 0, 0}, {"GI_BN_BWD_SMALL", 512, 0, 0},
   {"GI_WGRAD2", 1, 0, 0}, {"GI_WGRAD3", 1, 0, 0}, {"GI_IGEMM8", 1, 0, 0}, {"GI_BN_FOLD", 0, 0, 0}, {"GI_C1_FUSED", 1, 0, 0},
-  {"GI_WGRAD_STREAM", 1, 0, 0},
+  {"GI_WGRAD_STREAM", 1, 0, 0}, {"GI_MASK_BITS", 1, 0, 0},
 };
 thread_local const char* g_last_kernel = "";   // per host thread: gi_debug_last_kernel never reports another thread's launch
 int g_fold_count = 0;
@@ -143,6 +143,7 @@ static int apply_ex(IgemmArgs& a, const gi_igemm_ex* ex) {
   a.relu_cend = ex->relu_cend;
   a.mask = ex->mask; a.ldmask = ex->ldmask; a.mask_slope = ex->mask_slope;
   a.add = ex->add; a.ldadd = ex->ldadd;
+  a.mask_bits = ex->mask ? ex->mask_bits : nullptr;
   a.stat_acc = ex->stat_acc; a.stat_reps = ex->stat_reps; a.stat_pg = ex->stat_pg;
   a.partials = ex->partials;
   a.bwd_x = ex->bwd_x; a.bwd_ldx = ex->bwd_ldx; a.bwd_scale = ex->bwd_scale; a.bwd_shift = ex->bwd_shift; a.bwd_mean = ex->bwd_mean;

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) c1_gather_strip_kernel(const float* __res
 template <int MTC, int ACT>   // MTC = c / 16
 __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __restrict__ img, const float* __restrict__ w,
                                                              char* out, int n, int Hs, int Ws, int ldout, int coffout,
-                                                             float in_scale) {
+                                                             float in_scale, unsigned long long* __restrict__ bits) {
   __shared__ __attribute__((aligned(16))) char slab[4][2048];   // a wave's 16 pixels x 128 bytes, re-read pixel-major for the stores
   const int lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
@@ -216,6 +216,24 @@ __global__ void __launch_bounds__(256) c1_gather_mfma_kernel(const float* __rest
           if (ACT == GI_ACT_LRELU) v = fmaxf(v, 0.2f * v);      // = v > 0 ? v : 0.2 v
           o[m4 >> 1][(m4 & 1) * 4 + r] = (half_t)v;
         }
+      }
+      if (MTC == 4 && bits) {
+        // sign word of the pixel (bit c = [out[p][c] > 0], 64 channels): what the fused activation backward of the next layer's
+        // input-gradient GEMM needs of this tensor (IgemmArgs::mask_bits: 8 bytes per pixel instead of 128). Lane (lr, kq) holds
+        // channels 8 kq .. + 7 and 32 + 8 kq .. + 7 of pixel lr; the four kq lanes of a pixel are 16 lanes apart.
+        typedef short s8_t __attribute__((ext_vector_type(8)));
+        const s8_t s0 = __builtin_bit_cast(s8_t, o[0]), s1 = __builtin_bit_cast(s8_t, o[1]);
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { lo |= (s0[j] > 0 ? 1u : 0u) << j; hi |= (s1[j] > 0 ? 1u : 0u) << j; }
+        lo <<= 8 * kq; hi <<= 8 * kq;
+        // OR over the four 16-lane rows: v_permlane16_swap / v_permlane32_swap (gfx950) pair the rows in registers, no LDS crossbar
+        typedef unsigned u2v_t __attribute__((ext_vector_type(2)));
+        u2v_t t = __builtin_amdgcn_permlane16_swap(lo, lo, false, false); lo = t[0] | t[1];
+        t = __builtin_amdgcn_permlane16_swap(hi, hi, false, false); hi = t[0] | t[1];
+        t = __builtin_amdgcn_permlane32_swap(lo, lo, false, false); lo = t[0] | t[1];
+        t = __builtin_amdgcn_permlane32_swap(hi, hi, false, false); hi = t[0] | t[1];
+        if (kq == 0) bits[(int64_t)g * 16 + lr] = (unsigned long long)lo | ((unsigned long long)hi << 32);
       }
       {
         // through a wave-private LDS slab so that one store instruction covers whole 128-byte pixel rows (8 pixels each; measured
@@ -1144,11 +1162,14 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
   const int tile0 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices) / slices) : 0;
   const int tile1 = tbuf ? (int)((int64_t)ntile * (blockIdx.x % slices + 1) / slices) : ntile;
   h8_t av[16];
+  constexpr int AV_EARLY = 12;   // chunks requested before the prologue; the rest behind it (all 16 + the prologue's 64 accumulator
+                                 // registers went 16 bytes over the 128 VGPRs of a 1024-thread workgroup)
+  const char* row0;
   {
     const int t0 = tile0 + wave < tile1 ? tile0 + wave : tile0;     // (a wave without a tile loads one it will not use)
-    const char* row = img + (int64_t)min(t0 * 16 + (lane & 15), npx - 1) * 1024 + (lane >> 4) * 16;
+    row0 = img + (int64_t)min(t0 * 16 + (lane & 15), npx - 1) * 1024 + (lane >> 4) * 16;
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) av[ks] = *(const h8_t*)(row + ks * 64);
+    for (int ks = 0; ks < AV_EARLY; ++ks) av[ks] = *(const h8_t*)(row0 + ks * 64);
   }
   if (sc4 && use_fa) {
     // the scale / shift vectors do not exist yet: derived here from conv4's exact accumulators (bn_acc.h) - every workgroup the
@@ -1180,10 +1201,12 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
     const f4_t v = *(const f4_t*)(w5 + i * 4);
     *(h4_t*)(wh + i * 4) = h4_t{(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
   }
-  __syncthreads();
-  h8_t bf[16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bf[ks] = *(const h8_t*)(wh + (lane & 15) * 512 + ks * 32 + (lane >> 4) * 8);
+  for (int ks = AV_EARLY; ks < 16; ++ks) av[ks] = *(const h8_t*)(row0 + ks * 64);
+  __syncthreads();
+  // (the weight fragments are read from LDS next to their MFMA: kept in registers beside av - 64 + 64 of the 128 a 1024-thread
+  //  workgroup has per lane - the kernel spilled 132 bytes per lane, and at the critic's map sizes a wave owns one tile anyway)
+  const half_t* bfp = wh + (lane & 15) * 512 + (lane >> 4) * 8;
   for (int tile = tile0 + wave; tile < tile1; tile += 16) {
     if (tile != tile0 + wave) {      // later tiles of this wave (large maps)
       const int px = min(tile * 16 + (lane & 15), npx - 1);
@@ -1205,7 +1228,7 @@ __global__ void __launch_bounds__(1024) head_fwd512_kernel(const char* __restric
     }
     f4_t acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[ks], bf[ks], acc, 0, 0, 0);
+    for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[ks], *(const h8_t*)(bfp + ks * 32), acc, 0, 0, 0);
     // D[row = pixel][col = tap]: lane holds tap (lane&15), pixels 4*(lane>>4) + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1479,8 +1502,9 @@ int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh) {
 }
 
 int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs, int Ws, int c,
-                 int ldout, int coffout, int act_out, float in_scale, const float* bias) {
+                 int ldout, int coffout, int act_out, float in_scale, const float* bias, unsigned long long* bits, int* bits_written) {
   GI_REQUIRE(c % 8 == 0 && c <= 1024, "c1_gather: c=%d", c);
+  if (bits_written) *bits_written = 0;
   const int64_t total = (int64_t)n * Hs * Ws * (c / 8);
   const int groups = c / 8;
   if (dtype == GI_F16 && !bias && (c == 64 || c == 128) && Ws % 16 == 0 && ldout % 8 == 0 && coffout % 8 == 0) {
@@ -1488,7 +1512,9 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
     GI_REQUIRE(ngroups < (1ll << 31) && (act_out == GI_ACT_NONE || act_out == GI_ACT_RELU || act_out == GI_ACT_LRELU), "c1_gather: %lld pixel groups / activation %d",
                (long long)ngroups, act_out);
     const int grid = grid_for(ngroups, 4, 256 * 8);
-#define GI_C1G(MTC_, ACT_) hipLaunchKernelGGL((c1_gather_mfma_kernel<MTC_, ACT_>), dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, in_scale)
+    unsigned long long* const bw = c == 64 ? bits : nullptr;   // (the sign words cover 64 channels)
+    if (bw && bits_written) *bits_written = 1;
+#define GI_C1G(MTC_, ACT_) hipLaunchKernelGGL((c1_gather_mfma_kernel<MTC_, ACT_>), dim3(grid), dim3(256), 0, st, img, w, (char*)out, n, Hs, Ws, ldout, coffout, in_scale, bw)
     if (c == 64) {
       if (act_out == GI_ACT_LRELU) GI_C1G(4, GI_ACT_LRELU); else if (act_out == GI_ACT_RELU) GI_C1G(4, GI_ACT_RELU); else GI_C1G(4, GI_ACT_NONE);
     } else {

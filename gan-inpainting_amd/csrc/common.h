@@ -23,7 +23,7 @@ void gi_set_error(const char* fmt, ...);
 // once per process), else the default. include/ganinpaint.h documents each; tests/test_options_gpu.py runs every alternative.
 enum gi_opt_id {
   GI_OPT_IGEMM5 = 0, GI_OPT_IGEMM6, GI_OPT_IGEMM7, GI_OPT_IGEMM_FIXUP, GI_OPT_IGEMM_VARIANT, GI_OPT_BN_ACC, GI_OPT_FUSE_HEAD,
-  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_WGRAD_STREAM, GI_OPT_COUNT
+  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_WGRAD_STREAM, GI_OPT_MASK_BITS, GI_OPT_COUNT
 };
 int gi_opt(int id);
 // name of the GEMM / weight-gradient kernel a dispatcher has just launched (gi_debug_last_kernel: tests assert which kernel
@@ -64,6 +64,12 @@ __device__ __forceinline__ void gi_with_act(int act, F&& f) {
   if (act == GI_ACT_NONE) f(std::integral_constant<int, GI_ACT_NONE>{});
   else if (act == GI_ACT_RELU) f(std::integral_constant<int, GI_ACT_RELU>{});
   else f(std::integral_constant<int, GI_ACT_LRELU>{});
+}
+// the same for a launch-constant flag (statistics wanted, bias present): the accumulator loops drop the work of the unused side
+template <typename F>
+__device__ __forceinline__ void gi_with_bool(bool b, F&& f) {
+  if (b) f(std::true_type{});
+  else f(std::false_type{});
 }
 // Sum over the 16 lanes of a DPP row (lane & 15 = the pixel row of a 16x16 MFMA tile), every lane receives the total. The same
 // additions in the same order as the xor butterfly `v += __shfl_xor(v, 1 / 2 / 4 / 8)` it replaces (quad_perm = xor 1, xor 2; after
@@ -208,6 +214,10 @@ struct IgemmArgs {
   const void* add; int ldadd, coffadd;   // with mask: a second gradient added where mask > 0 before the slope (the skip
                                          // half of a U-Net concat gradient, which passed the parent's in-place ReLU)
   int mask_applied;
+  // with mask: one 64-bit sign word per output pixel, bit c = [mask[p][coffmask + c] > 0] for the 64 channels from coffmask
+  // (op_c1_gather writes them with the tensor), or null. A kernel that takes them (igemm8's dual-px tiles, cout = 64) never reads
+  // `mask`: 8 bytes per pixel instead of 128, the slope applied to the fp32 accumulators (one rounding instead of two).
+  const unsigned long long* mask_bits;
   // column statistics without partial rows (stat_acc.h): every tile adds its column sum / sum of squares into the exact
   // per-channel accumulator block stat_acc (layout: stat_acc.h; zeroed by the caller; stat_reps replicas, a power of two,
   // tile t adds to replica t mod stat_reps). stat_pg > 0: the GEMM rows (small-grid pixels) are two consecutive BatchNorm
@@ -253,8 +263,11 @@ int64_t op_wgrad_scratch_bytes(int dtype, int n, int Hs, int Ws, int ca, int cb)
 // single-channel-side kernels (generator first conv / last transposed conv, discriminator first
 // conv): weights fp32 [c][16] (= [a][ky][kx][b] with b == 1)
 // out[p][c] = act(sum_tap img[n,2y-1+ky,2x-1+kx] * w[c][tap])      img fp32 (n,2Hs,2Ws)
+// bits != null: the kernels that can also write one 64-bit sign word per pixel (bit c = [out[p][c] > 0], c = 64 only) and say so
+// in *bits_written
 int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, void* out, int n, int Hs,
-                 int Ws, int c, int ldout, int coffout, int act_out, float in_scale, const float* bias = nullptr);
+                 int Ws, int c, int ldout, int coffout, int act_out, float in_scale, const float* bias = nullptr,
+                 unsigned long long* bits = nullptr, int* bits_written = nullptr);
 // img[n,Y,X] = post( bias + sum_{c,tap} relu?(X[p][c]) * w[c][tap] ) (overlap-add of the 4x4 taps)
 // post: 0 none, 1 tanh. img fp32 (n,2Hs,2Ws); out_scale multiplies the result (loss-scale removal)
 // col_scratch (fp16 path): >= n*Hs*Ws*16 halves; null selects the register-reduction kernel

@@ -20,6 +20,7 @@ struct KP5 {
   int ntiles;
   const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
   const char* add; int ldadd, coffadd;
+  const unsigned long long* mask_bits;   // IgemmArgs::mask_bits (igemm8, MODE 3 only; else null)
   // fused BatchNorm-backward reduction (IgemmArgs::bwd_*)
   const char* bwd_x; int bwd_ldx;
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;

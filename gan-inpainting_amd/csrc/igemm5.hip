@@ -76,13 +76,16 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4][BN][2]
   const bool stats = p.partials || p.stat_acc;
-  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation, statistics and bias as compile-time constants (common.h)
+  gi_with_bool(stats, [&](auto STc) {
+  gi_with_bool(p.bias != nullptr, [&](auto BIc) {
     constexpr int ACT = decltype(ACTc)::value;
+    constexpr bool ST = decltype(STc)::value, BI = decltype(BIc)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int ch = wn * WN + nt * 16 + 4 * lq;         // column of the tile (DUAL: px * 64 + channel)
       float bs[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+      if constexpr (BI) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
       }
@@ -92,14 +95,14 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
         h4_t o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[mt][nt][r] + bs[r];
-          s[r] += v;
-          q[r] += v * v;
+          float v = acc[mt][nt][r];
+          if constexpr (BI) v += bs[r];
+          if constexpr (ST) { s[r] += v; q[r] += v * v; }
           o[r] = (half_t)gi_act_c<ACT>(v);
         }
         *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (stats) {
+      if constexpr (ST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
         if (lr == 0) {
@@ -108,7 +111,7 @@ __device__ __forceinline__ void epilogue5(const KP5& p, f4_t (&acc)[4][BN / 32],
         }
       }
     }
-  });
+  }); }); });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
     float s = 0.f, q = 0.f;
@@ -768,6 +771,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.relu_cend = a.relu_cend > 0 ? a.relu_cend : a.cin;
   kp.mask = (const char*)a.mask; kp.ldmask = a.ldmask; kp.coffmask = a.coffmask; kp.mask_slope = a.mask_slope;
   kp.add = a.mask ? (const char*)a.add : nullptr; kp.ldadd = a.ldadd; kp.coffadd = a.coffadd;
+  kp.mask_bits = nullptr;
   kp.dbg_epi = 0;
   kp.pool = 0;
   a.pool_applied = 0;
@@ -813,6 +817,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
       kp.pool = 1;
       a.pool_applied = 1;
     }
+    if (dual && !a.relu_in && a.mask && a.mask_bits && a.cout == 64 && !a.bias && a.act_out == GI_ACT_NONE && !a.stat_acc && !a.partials) kp.mask_bits = a.mask_bits;
     GI_TRY(op_igemm8_launch(st, mode, dual, a.relu_in != 0, grid, kp, BN));
     a.ntiles_out = mtiles * nph;
     return GI_OK;

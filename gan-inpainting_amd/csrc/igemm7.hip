@@ -335,13 +335,16 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [2][BN][2]
   const bool stats = p.partials || p.stat_acc;
-  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation, statistics and bias as compile-time constants (common.h)
+  gi_with_bool(stats, [&](auto STc) {
+  gi_with_bool(p.bias != nullptr, [&](auto BIc) {
     constexpr int ACT = decltype(ACTc)::value;
+    constexpr bool ST = decltype(STc)::value, BI = decltype(BIc)::value;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int ch = wn * WN + nt * 16 + 4 * lq;         // this lane's 4 consecutive channels
       float bs[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+      if constexpr (BI) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + ch + r];
       }
@@ -351,14 +354,14 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
         h4_t o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[mt][nt][r] + bs[r];
-          s[r] += v;
-          q[r] += v * v;
+          float v = acc[mt][nt][r];
+          if constexpr (BI) v += bs[r];
+          if constexpr (ST) { s[r] += v; q[r] += v * v; }
           o[r] = (half_t)gi_act_c<ACT>(v);
         }
         *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (stats) {
+      if constexpr (ST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
         if (lr == 0) {
@@ -367,7 +370,7 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
         }
       }
     }
-  });
+  }); }); });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
     const float s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];

@@ -41,7 +41,10 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff,
 // ---- epilogue (contract of igemm3 / epilogue5): bias / activation, per-tile column statistics, the tile staged through LDS
 //      and stored with 16-byte rows; optional fused activation backward and BatchNorm-backward reduction. 256 threads, wave w
 //      holds rows 64 w .. 64 w + 63 x 128 columns. -----------------------------------------------------------------------------
-template <int MODE, int BN>
+// BITS: the instantiation carries the sign-word form of the fused activation backward (IgemmArgs::mask_bits). Only the dual-px
+// kernel without the input ReLU (the input-gradient GEMMs of the second layers) does: the forward's <3, relu> instantiation sits at
+// 256 VGPRs and spills with any more epilogue code (measured: u2 77.5 -> 101 us with 116 bytes of scratch).
+template <int MODE, int BN, bool BITS>
 __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16], char* smem, int tid, int lane, int wave, int mt_idx,
                                           int ph, int py, int px, int n0, int img, int y0, int x0, int lgTW) {
   constexpr bool DUAL = MODE == 3;
@@ -57,13 +60,42 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4 waves][BN][2]
   const bool stats = p.partials || p.stat_acc;
-  gi_with_act(p.act_out, [&](auto ACTc) {                // the activation as a compile-time constant (common.h)
+  if constexpr (BITS) {
+    if (p.mask_bits) {
+      // fused activation backward from sign words (IgemmArgs::mask_bits): the two px phases of a row are adjacent output pixels,
+      // i.e. 16 consecutive bytes; element (column nt * 16 + 4 lq + r) is bit (nt & 1) * 16 + 4 lq + r of word (nt >> 1). The
+      // slope goes to the fp32 accumulator; a second gradient (`add`) is added in the copy-out loop below.
+      u4_t mb[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) mb[mt] = *(const u4_t*)(p.mask_bits + out_pixel(wave * 64 + mt * 16 + lr));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int ch = nt * 16 + 4 * lq;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int t = (int)(mb[mt][nt >> 1] >> ((nt & 1) * 16 + 4 * lq));
+          h4_t o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[mt][nt][r];
+            const int pos = (t << (31 - r)) >> 31;                         // -1 where the bit is set
+            o[r] = (half_t)__builtin_bit_cast(float, (__builtin_bit_cast(int, v) & pos) | (__builtin_bit_cast(int, v * p.mask_slope) & ~pos));
+          }
+          *(h4_t*)(stg + (wave * 64 + mt * 16 + lr) * SLD + ch) = o;
+        }
+      }
+    }
+  }
+  // the accumulator loop with the activation as a compile-time constant (common.h), and - MODE 0 / 1, which have the registers for
+  // the extra code paths (the other modes spill: MODE 2 128 bytes of scratch, MODE 3 112) - the statistics and bias flags as well
+  auto acc_loop = [&](auto ACTc, auto st, auto bi) {     // st / bi: std::true_type / std::false_type, or bool
     constexpr int ACT = decltype(ACTc)::value;
+    constexpr bool CT = !std::is_same<decltype(st), bool>::value;   // run-time flags: the sums run unconditionally (as before)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int ch = nt * 16 + 4 * lq;                   // column of the tile (DUAL: px * 64 + channel)
       float bs[4] = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
+      if (bi) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[r] = p.bias[n0 + (DUAL ? (ch & 63) : ch) + r];
       }
@@ -73,14 +105,20 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
         h4_t o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[mt][nt][r] + bs[r];
-          s[r] += v;
-          q[r] += v * v;
+          float v = acc[mt][nt][r];
+          if constexpr (CT) {
+            if (bi) v += bs[r];
+            if (st) { s[r] += v; q[r] += v * v; }
+          } else {
+            v += bs[r];
+            s[r] += v;
+            q[r] += v * v;
+          }
           o[r] = (half_t)gi_act_c<ACT>(v);
         }
         *(h4_t*)(stg + (wave * 64 + mt * 16 + lr) * SLD + ch) = o;
       }
-      if (stats) {
+      if (st) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { s[r] = gi_row16_sum(s[r]); q[r] = gi_row16_sum(q[r]); }
         if (lr == 0) {
@@ -88,6 +126,14 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
           for (int r = 0; r < 4; ++r) { red[(wave * BN + ch + r) * 2] = s[r]; red[(wave * BN + ch + r) * 2 + 1] = q[r]; }
         }
       }
+    }
+  };
+  if (!(BITS && p.mask_bits))
+  gi_with_act(p.act_out, [&](auto ACTc) {
+    if constexpr (MODE == 0 || MODE == 1) {
+      gi_with_bool(stats, [&](auto STc) { gi_with_bool(p.bias != nullptr, [&](auto BIc) { acc_loop(ACTc, STc, BIc); }); });
+    } else {
+      acc_loop(ACTc, stats, p.bias != nullptr);
     }
   });
   __syncthreads();
@@ -150,7 +196,12 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
       const int r = tid / CPRO + (h * NR + k) * RP;
       opxs[k] = out_pixel(r) + (DUAL ? (oc >> 3) : 0);
       const int64_t opx = opxs[k];
-      if (p.mask) mk[k] = *(const u4_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
+#ifdef GI_ABLATION
+      if (p.mask && (p.dbg_epi & 2)) mk[k] = *(const u4_t*)(p.mask + (((opx * p.ldmask + p.coffmask + och) * 2) & 0xFFF0));   // mask from a 64 KiB window
+      else
+#endif
+      if (BITS && p.mask_bits) { if (p.add) mk[k][0] = ((const unsigned char*)p.mask_bits)[opx * 8 + (oc & 7)]; }   // the chunk's 8 sign bits
+      else if (p.mask) mk[k] = *(const u4_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
       if (p.mask && p.add) ad[k] = *(const u4_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
       if (bwd) xs[k] = *(const u4_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
     }
@@ -171,7 +222,20 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
           bsx[e] = fmaf(dz, (xf - bmu[e]) * biv[e], bsx[e]);
         }
       }
-      if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
+      if (BITS && p.mask_bits) {
+        if (p.add) {    // the slope is in (accumulator stage): only the second gradient where the sign bit is set. Branch-free and packed:
+          // the chunk's 8 bits become four 2 x 16-bit lane masks, the masked gradient is added with v_pk_add_f16 (written per element
+          // with a select, hipcc emitted eight divergent branches per chunk: this GEMM 66 -> 79 us)
+          const int b = (int)mk[k][0];
+          u4_t a8 = ad[k];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned lo = (unsigned)((b << (31 - 2 * i)) >> 31) & 0xFFFFu, hi = (unsigned)((b << (30 - 2 * i)) >> 31) & 0xFFFF0000u;
+            a8[i] &= lo | hi;
+          }
+          v = __builtin_bit_cast(u4_t, __builtin_bit_cast(h8_t, v) + __builtin_bit_cast(h8_t, a8));
+        }
+      } else if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
         const h8_t m = __builtin_bit_cast(h8_t, mk[k]);
         h8_t hv = __builtin_bit_cast(h8_t, v);
         if (p.add) {
@@ -188,6 +252,9 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
         }
         v = __builtin_bit_cast(u4_t, hv);
       }
+#ifdef GI_ABLATION
+      if (p.dbg_epi & 1) { *(u4_t*)(p.out + ((o * 2) & 0xFFF0)) = v; continue; }   // all tiles store into one 64 KiB window
+#endif
       *(u4_t*)(p.out + o * 2) = v;
     }
   }
@@ -550,7 +617,7 @@ __global__ void __launch_bounds__(256, 2) igemm8_kernel(KP5 p) {
     if (t == 12345.678f) p.out[0] = 1;
     return;
   }
-  epilogue8<MODE, BN>(p, acc, smem, tid, lane, wave, mt_idx, ph, py, px, n0, img, y0, x0, lgTW);
+  epilogue8<MODE, BN, (MODE == 3 && !RELU)>(p, acc, smem, tid, lane, wave, mt_idx, ph, py, px, n0, img, y0, x0, lgTW);
 }
 
 }  // namespace

@@ -123,6 +123,10 @@ struct gi_net {
   // beside the input-gradient chain, which never reads their result. dz buffers rotate (oDr; oD == oDr[0]) so that the chain
   // does not wait for a weight gradient before it overwrites its operand; gi_net_backward[_phase] joins before it returns.
   int64_t oDr[3] = {-1, -1, -1};
+  // per slot: one 64-bit sign word per pixel of the first layer's activation (op_c1_gather), what the fused LeakyReLU backward in
+  // the second layer's input-gradient GEMM reads instead of the activation itself (IgemmArgs::mask_bits); slot_bits1: written
+  int64_t oBits1 = -1;
+  std::vector<int> slot_bits1;
   hipStream_t st2 = nullptr;
   hipEvent_t ev_dz = nullptr, ev_wg[3] = {nullptr, nullptr, nullptr};
   bool wg_busy[3] = {false, false, false};
@@ -329,6 +333,7 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
   for (int k = 5; k <= nd - 1; ++k) net->oMask[k] = S.take(N * net->Hk[k - 1] * net->Wk[k - 1] * net->ch[k - 1]);
   net->oOut = S.take(N * H * W * 4 * out_c);
   net->oX = S.take(N * H * W * 4);
+  net->oBits1 = S.take(N * net->Hk[1] * net->Wk[1] * 8 + 16);
   int64_t stat_floats = 0;
   int nbn = 0;
   for (int k = 1; k <= nd; ++k)
@@ -353,6 +358,7 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
   net->slot_n.assign(n_slots, 0);
   net->slot_train.assign(n_slots, 0);
   net->slot_fused_u2.assign(n_slots, 0);
+  net->slot_bits1.assign(n_slots, 0);
   net->slot_inference.assign(n_slots, 0);
   net->eval_gen.assign(n_slots, std::vector<uint64_t>(nbn, 0));
   net->bwd_pending.assign(nbn, BwdFuse());
@@ -464,6 +470,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oHh = S.take(N * net->P * 4);
   net->oOut = S.take(N * 4);
   net->oX = S.take(N * H * W * 4);
+  net->oBits1 = S.take(N * (H >> 1) * (W >> 1) * 8 + 16);
   int64_t stat_floats = 0;
   for (int i = 2; i <= 4; ++i) { net->dbn[i].stat_off = stat_floats; stat_floats += 2 * 4 * net->dbn[i].c; net->dbn[i].id = i - 2; }   // x2: BN groups
   net->eval_gen.assign(n_slots + 1, std::vector<uint64_t>(3, 0));
@@ -479,6 +486,7 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->slot_n.assign(n_slots + 1, 0);
   net->slot_train.assign(n_slots + 1, 0);
   net->slot_fused_u2.assign(n_slots + 1, 0);
+  net->slot_bits1.assign(n_slots + 1, 0);
   net->fuse_head = gi_opt(GI_OPT_FUSE_HEAD);
   net->slot_groups.assign(n_slots + 1, 1);
   *out = net;
@@ -777,9 +785,10 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
           const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr, BwdFuse* bf = nullptr,
-          const IgemmFold* fold = nullptr, int* fold_applied = nullptr) {
+          const IgemmFold* fold = nullptr, int* fold_applied = nullptr, const unsigned long long* mask_bits = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
+  a.mask_bits = mask ? mask_bits : nullptr;
   if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; a.stat_reps = sp->reps; a.fold = fold; }
   if (bf && bf->planned) {
     a.bwd_x = bf->x; a.bwd_ldx = bf->ldx; a.bwd_scale = bf->scale; a.bwd_shift = bf->shift; a.bwd_mean = bf->mean; a.bwd_inv = bf->inv;
@@ -1100,7 +1109,7 @@ int unet_forward(gi_net* net, int s, const float* x, float* y, int n) {
   auto C = [&](int k) { return (void*)net->slot(s, net->oC[k]); };
   // d1: Conv2d(1->ngf) then the next block's in-place LeakyReLU (networks.py:287): the skip IS lrelu(x)
   GI_TRY(op_c1_gather(st, dt, x, net->params + net->conv[1].w_off, C(1), n, net->Hk[1], net->Wk[1], net->ch[1], 2 * net->ch[1], 0,
-                      GI_ACT_LRELU, 1.f));
+                      GI_ACT_LRELU, 1.f, nullptr, gi_opt(GI_OPT_MASK_BITS) ? (unsigned long long*)net->slot(s, net->oBits1) : nullptr, &net->slot_bits1[s]));
   // the copy of the input that d1's weight gradient reads (8.4 MB at the headline shape) rides in d2's normalisation pass
   // (bn_forward's side copy); where that pass does not exist, a device copy
   bool x_saved = false;
@@ -1323,7 +1332,8 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     // input-gradient GEMM when the kernel supports it (same arithmetic, one 4-tensor HBM pass less)
     const bool fuse1 = (k == 2);
     GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[k]), gA(k - 1), cb, cb, 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE,
-                 false, nullptr, 0, fuse1 ? C(1) : nullptr, 2 * cb, 0.2f, fuse1 ? &lrelu1_done : nullptr, fuse1 ? gC(1) : nullptr, 2 * cb));
+                 false, nullptr, 0, fuse1 ? C(1) : nullptr, 2 * cb, 0.2f, fuse1 ? &lrelu1_done : nullptr, fuse1 ? gC(1) : nullptr, 2 * cb, nullptr, nullptr,
+                 nullptr, nullptr, nullptr, (fuse1 && net->slot_bits1[s] && gi_opt(GI_OPT_MASK_BITS)) ? (const unsigned long long*)net->slot(s, net->oBits1) : nullptr));
   }
   if (run_outer) {
     const int c = net->ch[1];
@@ -1526,7 +1536,8 @@ int patchgan_forward(gi_net* net, int s, const float* x, float* y, int n) {
   net->slot_train[s] = train;
   const bool fuse_a4 = net->fuse_head && op_head_affine_ok(dt, 512);
   net->slot_fused_u2[s] = fuse_a4 ? 1 : 0;   // (critic: "conv4's activation was not materialised")
-  GI_TRY(op_c1_gather(st, dt, x, net->params + net->dconv[1].w_off, net->slot(s, net->oA[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_LRELU, 1.f));
+  GI_TRY(op_c1_gather(st, dt, x, net->params + net->dconv[1].w_off, net->slot(s, net->oA[1]), n, H / 2, W / 2, 64, 64, 0, GI_ACT_LRELU, 1.f, nullptr,
+                      gi_opt(GI_OPT_MASK_BITS) ? (unsigned long long*)net->slot(s, net->oBits1) : nullptr, &net->slot_bits1[s]));
   // the copy of the input that conv1's weight gradient reads rides in conv2's normalisation pass where that pass takes a side
   // copy (accumulator path); otherwise a device copy
   bool x_saved = false, a4_deferred = false;
@@ -1627,7 +1638,8 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
       *pbf = bwd_fuse_plan(net, s, net->dbn[i - 1], net->slot(s, net->oRd[i - 1]), pix * 4, pix / 256 * 4, 0.2f);
     }
     GI_TRY(igemm(net, 1, D, c.ca, c.ca, 0, phase_ptr(net, c), net->shared(net->ogA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, 0, GI_ACT_NONE, false,
-                 nullptr, 0, fuse1 ? net->slot(s, net->oA[1]) : nullptr, 64, 0.2f, fuse1 ? &lrelu1_done : nullptr, nullptr, 0, nullptr, nullptr, pbf));
+                 nullptr, 0, fuse1 ? net->slot(s, net->oA[1]) : nullptr, 64, 0.2f, fuse1 ? &lrelu1_done : nullptr, nullptr, 0, nullptr, nullptr, pbf, nullptr,
+                 nullptr, (fuse1 && net->slot_bits1[s] && gi_opt(GI_OPT_MASK_BITS)) ? (const unsigned long long*)net->slot(s, net->oBits1) : nullptr));
   }
   if (phase == 1) return GI_OK;
   const int64_t pix = (int64_t)n * (H / 2) * (W / 2);

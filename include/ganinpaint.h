@@ -72,7 +72,10 @@ int gi_version(void);
  *                         col tensor in memory instead of one launch with the col rows in LDS; bit-identical results
  *   GI_WGRAD_STREAM [1]   0: the weight-gradient GEMMs of gi_net_backward[_phase] on the context's stream, in line with the
  *                         input-gradient chain, instead of on the network's second HIP stream beside it (the entry joins the two
- *                         before it returns; same kernels, same operands, same results) */
+ *                         before it returns; same kernels, same operands, same results)
+ *   GI_MASK_BITS [1]      0: the LeakyReLU backward of the first layer, fused into the second layer's input-gradient GEMM, reads the
+ *                         layer's fp16 activation (128 bytes per pixel) instead of the 64-bit sign word per pixel the forward wrote
+ *                         beside it, and applies the slope to the fp16-rounded gradient instead of the fp32 accumulator */
 int gi_set_option(const char* name, int value);
 int gi_get_option(const char* name, int* value);
 /* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.
@@ -371,6 +374,10 @@ typedef struct gi_igemm_ex {
    * like out with leading dimensions ldmask / ldadd (the LeakyReLU backward of a norm-free layer, networks.py:287) */
   const void* mask; int ldmask; float mask_slope;
   const void* add; int ldadd;
+  /* with mask, optional: one 64-bit sign word per output pixel, bit c = [mask[p][c] > 0] for its first 64 channels. The kernel
+   * that takes them (sub-pixel phases with 64 output channels) reads 8 bytes per pixel instead of 128 and applies the slope to
+   * its fp32 accumulators (one rounding: within fp16 rounding of the result without them) */
+  const unsigned long long* mask_bits;
   /* BatchNorm batch statistics of the result: every tile adds its column sum / sum of squares to the exact accumulator
    * block stat_acc (gi_stat_acc_words(ca) zeroed 64-bit words; tile t -> replica t mod stat_reps, a power of two <= 4;
    * stat_pg > 0: GEMM rows >= stat_pg belong to a second population). partials: per-tile rows instead, [tiles][2][c] */

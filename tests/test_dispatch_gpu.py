@@ -156,10 +156,17 @@ def test_convT_forward_with_statistics_at_headline_shapes(case, family):
         assert err <= 1e-5, f"{name}: column statistics off by {err:.2e} of sum|x|"
 
 
-def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1(family):
+def _sign_words(y_nhwc):
+    """one 64-bit word per pixel, bit c = [y[p][c] > 0], as 8 bytes (little endian) - what the first layer's forward kernel writes"""
+    pos = (y_nhwc[..., :64] > 0).to(torch.int32).reshape(-1, 8, 8)
+    return (pos << torch.arange(8, device=pos.device, dtype=torch.int32)).sum(-1).to(torch.uint8).contiguous()
+
+
+@pytest.mark.parametrize("bits", [False, True], ids=["fp16 mask", "sign words"])
+def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1(family, bits):
     """d2's input gradient at n = 32 (sub-pixel phases with 64 output channels: the dual-px kernel) with d1's activation
     backward in the epilogue: out = (g + [y > 0] * skip gradient) * (y > 0 ? 1 : 0.2), y = the saved LeakyReLU output of d1
-    (networks.py:287: the skip IS lrelu(x)), both read from 128-channel concat buffers."""
+    (networks.py:287: the skip IS lrelu(x)), both read from 128-channel concat buffers; `bits`: the mask as sign words."""
     n, Hs, ca, cb = 32, 64, 128, 64
     D = quant(_rand((n, ca, Hs, Hs), 31), F16)
     w = quant(_rand((ca, cb, 4, 4), 32, 0.05), F16)       # Conv2d weight [out = ca, in = cb] read as ConvTranspose2d [in, out]
@@ -172,11 +179,37 @@ def test_conv_dgrad_with_fused_leaky_relu_backward_of_d1(family):
     ex = B.IgemmEx()
     ex.mask = B.ptr(ybuf); ex.ldmask = 2 * cb; ex.mask_slope = 0.2   # noqa: E702
     ex.add = B.ptr(gbuf); ex.ldadd = 2 * cb                           # noqa: E702
+    if bits:
+        words = _sign_words(ybuf)
+        ex.mask_bits = B.ptr(words)
     out, g = _convT(n, Hs, Hs, ca, cb, ex, x=D, w=w)
     assert B.last_kernel() == family("igemm6<3,128>", 1024) and ex.mask_applied == 1, (B.last_kernel(), ex.mask_applied)
     pos = (y > 0).float()
     ref = (g + pos * skip) * (pos + (1 - pos) * 0.2)
     ok, msg = report("d2 dgrad + fused LeakyReLU backward", from_nhwc(out), ref, TOL)
+    assert ok, msg
+
+
+@pytest.mark.parametrize("bits", [False, True], ids=["fp16 mask", "sign words"])
+def test_critic_conv2_dgrad_with_fused_leaky_relu_backward_of_conv1(family, bits):
+    """The stacked critic's conv2 input gradient (n = 64, 64x64 -> 128x128, 128 -> 64 channels) with conv1's LeakyReLU backward
+    in the epilogue (networks.py:334-336), no second gradient; `bits`: the mask as the sign words conv1's forward wrote."""
+    n, Hs, ca, cb = 64, 64, 128, 64
+    D = quant(_rand((n, ca, Hs, Hs), 35), F16)
+    w = quant(_rand((ca, cb, 4, 4), 36, 0.05), F16)
+    y = quant(_rand((n, cb, 2 * Hs, 2 * Hs), 37), F16)
+    y[:, :, ::7, ::5] = 0.0                                          # exact zeros take the slope ((float)y > 0 is false)
+    ybuf = nhwc_dev(y, F16)
+    ex = B.IgemmEx()
+    ex.mask = B.ptr(ybuf); ex.ldmask = cb; ex.mask_slope = 0.2       # noqa: E702
+    if bits:
+        words = _sign_words(ybuf)
+        ex.mask_bits = B.ptr(words)
+    out, g = _convT(n, Hs, Hs, ca, cb, ex, x=D, w=w)
+    assert B.last_kernel() == family("igemm6<3,128>", 2048) and ex.mask_applied == 1, (B.last_kernel(), ex.mask_applied)
+    pos = (y > 0).float()
+    ref = g * (pos + (1 - pos) * 0.2)
+    ok, msg = report("critic conv2 dgrad + fused LeakyReLU backward", from_nhwc(out), ref, TOL)
     assert ok, msg
 
 
