@@ -779,7 +779,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   { const char* e = getenv("GI_EPI_DBG"); if (e) kp.dbg_epi = atoi(e); }
 #endif
   kp.bwd_acc = nullptr;
-  if (a.bwd_acc && mode != 2 && a.cout % 128 == 0 && BN == 128) {   // (the dual-px / 64-column tiles do not take it)
+  if (a.bwd_acc && !a.mask && mode != 2 && a.cout % 128 == 0 && BN == 128) {   // (the dual-px / 64-column tiles do not take it; nor a launch with a mask)
     const int64_t px_per_tile = 256 * (mode == 1 ? 4 : 1);          // output pixels per M tile over all phases
     GI_REQUIRE(a.bwd_ldx % 8 == 0 && out_px * a.bwd_ldx < (1ll << 31) && (a.bwd_pg == 0 || a.bwd_pg % px_per_tile == 0) && a.coffout == 0,
                "igemm5: fused BatchNorm-backward reduction: layout");

@@ -182,13 +182,83 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
       return;
     }
   }
+  // sign words + second gradient (the generator's d2 input gradient): its own copy loop, four rows in flight, no run-time tests - in
+  // the generic loop below hipcc puts every row's loads behind branches with an s_waitcnt vmcnt(0) after each pair (eight dependent
+  // round trips per pass; with the byte load among them this GEMM went 66 -> 80 us). The slope is in already (accumulator stage):
+  // the chunk's 8 sign bits become four 2 x 16-bit lane masks and the masked gradient is added with v_pk_add_f16.
+  constexpr int RP = 256 / CPRO;        // rows per pass of the workgroup
+  const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
+  bool copied = false;
+  if constexpr (BITS) {
+    if (p.mask_bits && p.add) {
+      constexpr int NB = 4;
+#pragma unroll 1
+      for (int h = 0; h < BM / (RP * NB); ++h) {
+        int opxs[NB], mbyte[NB];
+        u4_t ad[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const int r = tid / CPRO + (h * NB + k) * RP;
+          opxs[k] = out_pixel(r) + (oc >> 3);
+          mbyte[k] = ((const unsigned char*)p.mask_bits)[(int64_t)opxs[k] * 8 + (oc & 7)];
+          ad[k] = *(const u4_t*)(p.add + ((int64_t)opxs[k] * p.ldadd + p.coffadd + och) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const int r = tid / CPRO + (h * NB + k) * RP;
+          u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+          const int b = mbyte[k];
+          u4_t a8 = ad[k];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned lo = (unsigned)((b << (31 - 2 * i)) >> 31) & 0xFFFFu, hi = (unsigned)((b << (30 - 2 * i)) >> 31) & 0xFFFF0000u;
+            a8[i] &= lo | hi;
+          }
+          v = __builtin_bit_cast(u4_t, __builtin_bit_cast(h8_t, v) + __builtin_bit_cast(h8_t, a8));
+          *(u4_t*)(p.out + ((int64_t)opxs[k] * p.ldout + p.coffout + och) * 2) = v;
+        }
+      }
+      copied = true;
+    }
+  }
+  // the BatchNorm-backward sums (critic conv3 / conv4 input gradients): the same - their own copy loop, four rows' loads of the
+  // layer's raw output in flight
+  if constexpr (!DUAL && MODE != 2) {
+    if (bwd && !p.mask) {
+      constexpr int NB = 4;
+#pragma unroll 1
+      for (int h = 0; h < BM / (RP * NB); ++h) {
+        int opxs[NB];
+        u4_t xs[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          opxs[k] = out_pixel(tid / CPRO + (h * NB + k) * RP);
+          xs[k] = *(const u4_t*)(p.bwd_x + ((int64_t)opxs[k] * p.bwd_ldx + och) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+          const int r = tid / CPRO + (h * NB + k) * RP;
+          const u4_t v = *(const u4_t*)((const char*)stg + ((int64_t)r * SLD + oc * 8) * 2);
+          const h8_t xv = __builtin_bit_cast(h8_t, xs[k]);
+          const h8_t gv = __builtin_bit_cast(h8_t, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xf = (float)xv[e];
+            const float dz = (float)gv[e] * (fmaf(xf, bsc[e], bsh[e]) > 0.f ? 1.f : p.bwd_slope);
+            bs[e] += dz;
+            bsx[e] = fmaf(dz, (xf - bmu[e]) * biv[e], bsx[e]);
+          }
+          *(u4_t*)(p.out + ((int64_t)opxs[k] * p.ldout + p.coffout + och) * 2) = v;
+        }
+      }
+      copied = true;
+    }
+  }
   // a thread copies 16 rows (one 16-byte chunk each), eight at a time: all global loads of the eight rows (fused mask, second
   // gradient, BatchNorm input) go out before the first store (as epilogue5)
-  constexpr int RP = 256 / CPRO;        // rows per pass of the workgroup
   constexpr int NR = 8;
-  const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
 #pragma unroll 1
-  for (int h = 0; h < BM / (RP * NR); ++h) {
+  for (int h = 0; h < (copied ? 0 : BM / (RP * NR)); ++h) {
     int opxs[NR];
     u4_t mk[NR], ad[NR], xs[NR];
 #pragma unroll
@@ -200,9 +270,9 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
       if (p.mask && (p.dbg_epi & 2)) mk[k] = *(const u4_t*)(p.mask + (((opx * p.ldmask + p.coffmask + och) * 2) & 0xFFF0));   // mask from a 64 KiB window
       else
 #endif
-      if (BITS && p.mask_bits) { if (p.add) mk[k][0] = ((const unsigned char*)p.mask_bits)[opx * 8 + (oc & 7)]; }   // the chunk's 8 sign bits
+      if (BITS && p.mask_bits) {}
       else if (p.mask) mk[k] = *(const u4_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
-      if (p.mask && p.add) ad[k] = *(const u4_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
+      if (!(BITS && p.mask_bits) && p.mask && p.add) ad[k] = *(const u4_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
       if (bwd) xs[k] = *(const u4_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
     }
 #pragma unroll
@@ -223,18 +293,6 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
         }
       }
       if (BITS && p.mask_bits) {
-        if (p.add) {    // the slope is in (accumulator stage): only the second gradient where the sign bit is set. Branch-free and packed:
-          // the chunk's 8 bits become four 2 x 16-bit lane masks, the masked gradient is added with v_pk_add_f16 (written per element
-          // with a select, hipcc emitted eight divergent branches per chunk: this GEMM 66 -> 79 us)
-          const int b = (int)mk[k][0];
-          u4_t a8 = ad[k];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const unsigned lo = (unsigned)((b << (31 - 2 * i)) >> 31) & 0xFFFFu, hi = (unsigned)((b << (30 - 2 * i)) >> 31) & 0xFFFF0000u;
-            a8[i] &= lo | hi;
-          }
-          v = __builtin_bit_cast(u4_t, __builtin_bit_cast(h8_t, v) + __builtin_bit_cast(h8_t, a8));
-        }
       } else if (p.mask) {   // same arithmetic as the separate pass: fp16 value -> fp32 * slope -> fp16
         const h8_t m = __builtin_bit_cast(h8_t, mk[k]);
         h8_t hv = __builtin_bit_cast(h8_t, v);
