@@ -1549,6 +1549,32 @@ int op_c1_gather(hipStream_t st, int dtype, const float* img, const float* w, vo
   return GI_OK;
 }
 
+// first stage for many rows (the fused form writes one row per GEMM workgroup: 2048 on the critic): workgroup g adds rows
+// [g * per, (g + 1) * per) in order for all `count` outputs, 16-byte loads, eight in flight, and writes row g of `out`
+__global__ void __launch_bounds__(256) c1_wgrad_rows_kernel(const float* __restrict__ part, float* __restrict__ out, int count, int blocks, int per) {
+  const int b0 = blockIdx.x * per, b1 = min(blocks, b0 + per);
+  const int stride = count / 4;
+  for (int i = threadIdx.x; i < stride; i += 256) {
+    f4_t s = {0.f, 0.f, 0.f, 0.f};
+    s = gi_ordered_sum_f4((const f4_t*)part + i, stride, b0, b1, s);
+    ((f4_t*)out)[(int64_t)blockIdx.x * stride + i] = s;
+  }
+}
+
+int op_c1_wgrad_reduce(hipStream_t st, const float* part, float* dW, int count, int blocks, float* scratch, int64_t scratch_floats) {
+  constexpr int G1 = 64;
+  if (blocks >= 4 * G1 && count % 4 == 0 && scratch && scratch_floats >= (int64_t)G1 * count) {
+    const int per = (blocks + G1 - 1) / G1;
+    hipLaunchKernelGGL(c1_wgrad_rows_kernel, dim3(G1), dim3(256), 0, st, part, scratch, count, blocks, per);
+    GI_LAUNCH_CHECK();
+    part = scratch;
+    blocks = (blocks + per - 1) / per;
+  }
+  hipLaunchKernelGGL(c1_wgrad_reduce_kernel, dim3((count + 15) / 16), dim3(256), 0, st, part, dW, count, blocks);
+  GI_LAUNCH_CHECK();
+  return GI_OK;
+}
+
 bool op_c1_affine_ok(int dtype, int c, int Ws, int ldx, int coffx) {
   return dtype == GI_F16 && (c == 64 || c == 128) && Ws % 32 == 0 && ldx % 8 == 0 && coffx % 8 == 0;
 }

@@ -23,7 +23,7 @@ void gi_set_error(const char* fmt, ...);
 // once per process), else the default. include/ganinpaint.h documents each; tests/test_options_gpu.py runs every alternative.
 enum gi_opt_id {
   GI_OPT_IGEMM5 = 0, GI_OPT_IGEMM6, GI_OPT_IGEMM7, GI_OPT_IGEMM_FIXUP, GI_OPT_IGEMM_VARIANT, GI_OPT_BN_ACC, GI_OPT_FUSE_HEAD,
-  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_WGRAD_STREAM, GI_OPT_MASK_BITS, GI_OPT_COUNT
+  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_WGRAD_STREAM, GI_OPT_MASK_BITS, GI_OPT_C1W_FUSE, GI_OPT_COUNT
 };
 int gi_opt(int id);
 // name of the GEMM / weight-gradient kernel a dispatcher has just launched (gi_debug_last_kernel: tests assert which kernel
@@ -218,6 +218,13 @@ struct IgemmArgs {
   // (op_c1_gather writes them with the tensor), or null. A kernel that takes them (igemm8's dual-px tiles, cout = 64) never reads
   // `mask`: 8 bytes per pixel instead of 128, the slope applied to the fp32 accumulators (one rounding instead of two).
   const unsigned long long* mask_bits;
+  // with mask_bits, the result being the gradient dz1 at the output of a single-channel 4x4 / s2 convolution (the networks' first
+  // layers, 64 channels): that layer's weight gradient from the tile while it is in LDS, dW1[c][tap] = sum_p img[2Y-1+ky, 2X-1+kx] *
+  // dz1[p][c] (img: the layer's fp32 input, n x 4Hs x 4Ws). Every workgroup writes its 64 x 16 sums * c1w_scale to
+  // c1w_part[workgroup][1024] (>= c1w_part_floats); the caller adds the c1w_blocks rows in a fixed order (op_c1_wgrad_reduce).
+  // c1w_skip_out: nothing else reads the result - it is not stored. Kernels that implement it set c1w_applied.
+  const float* c1w_img; float* c1w_part; int64_t c1w_part_floats; float c1w_scale; int c1w_skip_out;
+  int c1w_applied, c1w_blocks;
   // column statistics without partial rows (stat_acc.h): every tile adds its column sum / sum of squares into the exact
   // per-channel accumulator block stat_acc (layout: stat_acc.h; zeroed by the caller; stat_reps replicas, a power of two,
   // tile t adds to replica t mod stat_reps). stat_pg > 0: the GEMM rows (small-grid pixels) are two consecutive BatchNorm
@@ -283,6 +290,9 @@ int64_t op_c1_head4_col_bytes(int n, int Hs, int Ws);
 int op_c1_head4_forward(hipStream_t st, const void* X, const float* w, const float* bias, float* out, float* out2, int n, int Hs, int Ws, int ldx,
                         int coffx, int relu_in, void* col_scratch);
 int op_c1_head4_dgrad(hipStream_t st, const float* g, const float* w, void* out, int n, int Hs, int Ws, int ldout, int coffout);
+// dW[i] += sum over `blocks` rows of part[block][count], fixed order (the second stage of op_c1_wgrad and of IgemmArgs::c1w_part)
+// scratch (>= 64 * count floats, or null): a first stage over row ranges when there are many rows
+int op_c1_wgrad_reduce(hipStream_t st, const float* part, float* dW, int count, int blocks, float* scratch = nullptr, int64_t scratch_floats = 0);
 bool op_c1_affine_ok(int dtype, int c, int Ws, int ldx, int coffx);
 int op_c1_scatter(hipStream_t st, int dtype, const void* X, const float* w, const float* bias, float* img,
                   int n, int Hs, int Ws, int c, int ldx, int coffx, int relu_in, int post, float out_scale,

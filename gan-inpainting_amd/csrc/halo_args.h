@@ -21,6 +21,8 @@ struct KP5 {
   const char* mask; int ldmask, coffmask; float mask_slope;   // fused activation backward (IgemmArgs::mask)
   const char* add; int ldadd, coffadd;
   const unsigned long long* mask_bits;   // IgemmArgs::mask_bits (igemm8, MODE 3 only; else null)
+  // IgemmArgs::c1w_* (igemm8, MODE 3 with mask_bits only): the weight gradient of the single-channel layer below, from the tile
+  const float* c1w_img; float* c1w_part; float c1w_scale; int c1w_skip_out;
   // fused BatchNorm-backward reduction (IgemmArgs::bwd_*)
   const char* bwd_x; int bwd_ldx;
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;

@@ -772,6 +772,8 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   kp.mask = (const char*)a.mask; kp.ldmask = a.ldmask; kp.coffmask = a.coffmask; kp.mask_slope = a.mask_slope;
   kp.add = a.mask ? (const char*)a.add : nullptr; kp.ldadd = a.ldadd; kp.coffadd = a.coffadd;
   kp.mask_bits = nullptr;
+  kp.c1w_img = nullptr; kp.c1w_part = nullptr; kp.c1w_scale = 0.f; kp.c1w_skip_out = 0;
+  a.c1w_applied = 0; a.c1w_blocks = 0;
   kp.dbg_epi = 0;
   kp.pool = 0;
   a.pool_applied = 0;
@@ -818,6 +820,11 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
       a.pool_applied = 1;
     }
     if (dual && !a.relu_in && a.mask && a.mask_bits && a.cout == 64 && !a.bias && a.act_out == GI_ACT_NONE && !a.stat_acc && !a.partials) kp.mask_bits = a.mask_bits;
+    if (kp.mask_bits && a.c1w_part && a.c1w_img && mtiles % 8 == 0 && a.c1w_part_floats >= (int64_t)grid * 1024 &&
+        (int64_t)a.n * 16 * a.Hs * a.Ws < (1ll << 31)) {
+      kp.c1w_img = a.c1w_img; kp.c1w_part = a.c1w_part; kp.c1w_scale = a.c1w_scale; kp.c1w_skip_out = a.c1w_skip_out;
+      a.c1w_applied = 1; a.c1w_blocks = grid;
+    }
     GI_TRY(op_igemm8_launch(st, mode, dual, a.relu_in != 0, grid, kp, BN));
     a.ntiles_out = mtiles * nph;
     return GI_OK;

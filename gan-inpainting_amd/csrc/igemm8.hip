@@ -60,6 +60,32 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
   half_t* stg = (half_t*)smem;
   float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [4 waves][BN][2]
   const bool stats = p.partials || p.stat_acc;
+  // (IgemmArgs::c1w_*, stage below) the image values of this wave's four K blocks are requested first: they arrive while the
+  // accumulators are staged
+  float c1w_x[BITS ? 4 : 1][8];
+  if constexpr (BITS) {
+    if (p.c1w_part) {
+      const int Himg = 4 * p.Hs, Wimg = 4 * p.Ws;
+      const int tap = lane & 15, kq = lane >> 4, ky = tap >> 2, kx = tap & 3;
+      const float* ximg = p.c1w_img + (int64_t)img * Himg * Wimg;
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        const int b = wave + 4 * bi;
+        const int P = b & 1, mrow = (b >> 1) * 32 + 8 * kq;
+        const int iy = 4 * (y0 + (mrow >> lgTW)) + 2 * py - 1 + ky;
+        const bool yok = iy >= 0 && iy < Himg;
+        const float* rowp = ximg + (int64_t)(yok ? iy : 0) * Wimg;
+        const int ix0 = 4 * (x0 + (mrow & (p.TW - 1))) + 2 * P - 1 + kx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ix = ix0 + 4 * j;
+          const bool ok = yok && ix >= 0 && ix < Wimg;
+          const float a = rowp[ok ? ix : 0];
+          c1w_x[bi][j] = ok ? a : 0.f;
+        }
+      }
+    }
+  }
   if constexpr (BITS) {
     if (p.mask_bits) {
       // fused activation backward from sign words (IgemmArgs::mask_bits): the two px phases of a row are adjacent output pixels,
@@ -190,6 +216,7 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
   const int och = n0 + (DUAL ? (oc & 7) : oc) * 8;
   bool copied = false;
   if constexpr (BITS) {
+    if (p.c1w_part && p.c1w_skip_out && !p.add) copied = true;   // the result feeds the fused weight gradient below and nothing else
     if (p.mask_bits && p.add) {
       constexpr int NB = 4;
 #pragma unroll 1
@@ -215,7 +242,8 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
             a8[i] &= lo | hi;
           }
           v = __builtin_bit_cast(u4_t, __builtin_bit_cast(h8_t, v) + __builtin_bit_cast(h8_t, a8));
-          *(u4_t*)(p.out + ((int64_t)opxs[k] * p.ldout + p.coffout + och) * 2) = v;
+          if (p.c1w_part) *(u4_t*)((char*)stg + ((int64_t)r * SLD + oc * 8) * 2) = v;   // the finished gradient, for the stage below
+          if (!p.c1w_skip_out) *(u4_t*)(p.out + ((int64_t)opxs[k] * p.ldout + p.coffout + och) * 2) = v;
         }
       }
       copied = true;
@@ -314,6 +342,49 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
       if (p.dbg_epi & 1) { *(u4_t*)(p.out + ((o * 2) & 0xFFF0)) = v; continue; }   // all tiles store into one 64 KiB window
 #endif
       *(u4_t*)(p.out + o * 2) = v;
+    }
+  }
+  if constexpr (BITS) {
+    if (p.c1w_part) {
+      // Weight gradient of the single-channel layer below (IgemmArgs::c1w_*): the tile in LDS is dz1 for 256 x 2 output pixels
+      // (Y, X) = (2 (y0 + ty) + py, 2 (x0 + tx) + P) of the layer's 64-channel map. D[tap][c] = A[tap][pixel] * B[pixel][c] on
+      // v_mfma_f32_16x16x32_f16 as in c1_wgrad_mfma_kernel (c1.hip): K = 32 consecutive tile rows of one px phase P; A = the image
+      // values img[2Y - 1 + ky][2X - 1 + kx] gathered from global memory (lane: tap = lane & 15, its 8 pixels are 4 image columns
+      // apart), B = the staged rows read with the transposing ds_read_b64_tr_b16. Wave w takes K blocks w, w + 4, .. of the 16; the
+      // four waves' sums are added through LDS and the workgroup stores its 64 x 16 partial (* c1w_scale) for the fixed-order pass.
+      __syncthreads();                                   // every row of the tile is final (second gradient written back above)
+      const int tap = lane & 15, kq = lane >> 4;
+      const int tq = tap >> 2, tp = tap & 3;             // (transposing read: row tq / + 4 of the lane group's 8, columns 4 tp ..)
+      f4_t wacc[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wacc[nt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi) {
+        const int b = wave + 4 * bi;
+        const int P = b & 1, m0 = (b >> 1) * 32;
+        h8_t af;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[j] = (half_t)c1w_x[bi][j];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const char* b_lo = (const char*)stg + ((m0 + 8 * kq + tq) * SLD + P * 64 + nt * 16 + 4 * tp) * 2;
+          const char* b_hi = b_lo + 4 * SLD * 2;
+          fp16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)b_lo);
+          fp16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)b_hi);
+          const h4_t l4 = __builtin_bit_cast(h4_t, lo), h4 = __builtin_bit_cast(h4_t, hi);
+          const h8_t bf = h8_t{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+          wacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, wacc[nt], 0, 0, 0);
+        }
+      }
+      __syncthreads();                                   // the staged tile has been read by every wave
+      float* wred = (float*)smem;                        // [4 waves][64 channels][16 taps]
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wred[wave * 1024 + (nt * 16 + (lane & 15)) * 16 + 4 * (lane >> 4) + r] = wacc[nt][r];
+      __syncthreads();
+      float* part = p.c1w_part + (int64_t)blockIdx.x * 1024;
+      for (int i = tid; i < 1024; i += 256) part[i] = ((wred[i] + wred[1024 + i]) + (wred[2048 + i] + wred[3072 + i])) * p.c1w_scale;
     }
   }
   if (bwd) {

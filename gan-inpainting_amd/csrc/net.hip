@@ -127,6 +127,7 @@ struct gi_net {
   // the second layer's input-gradient GEMM reads instead of the activation itself (IgemmArgs::mask_bits); slot_bits1: written
   int64_t oBits1 = -1;
   std::vector<int> slot_bits1;
+  int64_t oC1w = -1, c1w_floats = 0;   // shared: per-workgroup partial sums of the fused first-layer weight gradient (IgemmArgs::c1w_part)
   hipStream_t st2 = nullptr;
   hipEvent_t ev_dz = nullptr, ev_wg[3] = {nullptr, nullptr, nullptr};
   bool wg_busy[3] = {false, false, false};
@@ -302,6 +303,10 @@ extern "C" int gi_unet_create_padded(gi_ctx* ctx, int num_downs, int ngf, int ch
   net->oD = net->oDr[0] = A.take(maxD);
   net->oDr[1] = A.take(maxD);
   net->oDr[2] = A.take(maxD);
+  if (nd >= 2) {   // workgroups of d2's input-gradient GEMM (256-pixel patches of level 2, two py phases) x 64 x 16 sums
+    net->c1w_floats = ((N * net->Hk[2] * net->Wk[2] / 256 + 8) * 2 + 64) * 1024;   // + 64 rows: op_c1_wgrad_reduce's first stage
+    net->oC1w = A.take(net->c1w_floats * 4);
+  }
   net->oG0 = A.take(N * H * W * 4 * out_c);
   if (out_c > 1) {   // u1 on the generic kernels: weights [a][16][b] with b zero-padded to 64, NHWC staging buffer
     const int64_t cnt = (int64_t)2 * net->ch[1] * 16 * 64;
@@ -432,6 +437,8 @@ extern "C" int gi_patchgan_create(gi_ctx* ctx, int H, int W, int sigmoid, int ma
   net->oD = net->oDr[0] = A.take(maxD);
   net->oDr[1] = A.take(maxD);
   net->oDr[2] = A.take(maxD);
+  net->c1w_floats = ((N * (H >> 2) * (W >> 2) / 256 + 8) * 2 + 64) * 1024;   // + 64 rows: op_c1_wgrad_reduce's first stage
+  net->oC1w = A.take(net->c1w_floats * 4);
   net->part_floats = maxPart;
   net->oPart = A.take(maxPart * 4);
   net->oSums = A.take(2 * 8 * 512 * 4);   // [groups][8][c]: sums + apply coefficients
@@ -780,15 +787,22 @@ BwdFuse bwd_fuse_plan(gi_net* net, int slot, const BN& bn, const void* x, int64_
   return f;
 }
 
+// IgemmArgs::c1w_* for the igemm() wrapper: the first layer's weight gradient from the second layer's input-gradient GEMM
+struct C1WFuse {
+  const float* img = nullptr; float* part = nullptr; int64_t part_floats = 0; float scale = 1.f; int skip_out = 0;
+  int applied = 0, blocks = 0;   // (returned)
+};
+
 // mask / ldmask / mask_slope / mask_applied: IgemmArgs::mask (activation backward fused into an input-gradient GEMM)
 int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin, const void* w, void* out, int cout,
           int ldout, int coffout, int n, int Hs, int Ws, int relu_in, int act_out, bool stats, int* ntiles, int relu_cend = 0,
           const void* mask = nullptr, int ldmask = 0, float mask_slope = 0.f, int* mask_applied = nullptr,
           const void* add = nullptr, int ldadd = 0, const float* bias = nullptr, StatPlan* sp = nullptr, BwdFuse* bf = nullptr,
-          const IgemmFold* fold = nullptr, int* fold_applied = nullptr, const unsigned long long* mask_bits = nullptr) {
+          const IgemmFold* fold = nullptr, int* fold_applied = nullptr, const unsigned long long* mask_bits = nullptr, C1WFuse* c1w = nullptr) {
   IgemmArgs a;
   memset(&a, 0, sizeof(a));
   a.mask_bits = mask ? mask_bits : nullptr;
+  if (c1w && a.mask_bits) { a.c1w_img = c1w->img; a.c1w_part = c1w->part; a.c1w_part_floats = c1w->part_floats; a.c1w_scale = c1w->scale; a.c1w_skip_out = c1w->skip_out; }
   if (stats && sp && sp->use) { a.stat_acc = sp->acc; a.stat_pg = sp->pg; a.stat_reps = sp->reps; a.fold = fold; }
   if (bf && bf->planned) {
     a.bwd_x = bf->x; a.bwd_ldx = bf->ldx; a.bwd_scale = bf->scale; a.bwd_shift = bf->shift; a.bwd_mean = bf->mean; a.bwd_inv = bf->inv;
@@ -808,6 +822,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   a.relu_in = relu_in; a.act_out = act_out;
   GI_TRY(op_igemm(net->ctx->stream, net->dtype, phase, a));
   if (mask_applied) *mask_applied = a.mask_applied;
+  if (c1w) { c1w->applied = a.c1w_applied; c1w->blocks = a.c1w_blocks; }
   if (fold_applied) *fold_applied = a.fold_applied;
   if (bf && bf->planned) bf->applied = a.bwd_applied != 0;
   if (sp && sp->use && !a.stat_used) sp->use = false;
@@ -1304,6 +1319,7 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
   // of the encoder's, are complete first), phase 4 = levels 4 .. 1; phase 2 (or 0) runs both
   const bool run_inner = phase != 4, run_outer = phase != 3;
   int lrelu1_done = 0;
+  C1WFuse c1w;
   // innermost conv (no norm): dz = gE * [E > 0]
   if (run_inner) {
     const int c = net->ch[nd];
@@ -1331,9 +1347,18 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     // d1 has no norm: its backward, (g + [y>0] * skip gradient) * LeakyReLU'(y), rides in the epilogue of d2's
     // input-gradient GEMM when the kernel supports it (same arithmetic, one 4-tensor HBM pass less)
     const bool fuse1 = (k == 2);
+    // ... and d1's weight gradient is formed from that GEMM's tiles while they are in LDS (IgemmArgs::c1w_*): the gradient at d1's
+    // output is never stored (the generator's input gradient is not asked for) and never read back
+    C1WFuse* pc1w = nullptr;
+    if (fuse1 && need_wgrad && net->oC1w >= 0 && gi_opt(GI_OPT_C1W_FUSE)) {
+      c1w.img = (const float*)net->slot(s, net->oX); c1w.part = (float*)net->shared(net->oC1w); c1w.part_floats = net->c1w_floats - 64 * 1024;
+      c1w.scale = iLS; c1w.skip_out = dx ? 0 : 1;
+      pc1w = &c1w;
+    }
     GI_TRY(igemm(net, 1, D, c, c, 0, phase_ptr(net, net->conv[k]), gA(k - 1), cb, cb, 0, n, net->Hk[k], net->Wk[k], 0, GI_ACT_NONE,
                  false, nullptr, 0, fuse1 ? C(1) : nullptr, 2 * cb, 0.2f, fuse1 ? &lrelu1_done : nullptr, fuse1 ? gC(1) : nullptr, 2 * cb, nullptr, nullptr,
-                 nullptr, nullptr, nullptr, (fuse1 && net->slot_bits1[s] && gi_opt(GI_OPT_MASK_BITS)) ? (const unsigned long long*)net->slot(s, net->oBits1) : nullptr));
+                 nullptr, nullptr, nullptr, (fuse1 && net->slot_bits1[s] && gi_opt(GI_OPT_MASK_BITS)) ? (const unsigned long long*)net->slot(s, net->oBits1) : nullptr,
+                 pc1w));
   }
   if (run_outer) {
     const int c = net->ch[1];
@@ -1341,7 +1366,10 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     void* D1 = D = side_dz(net);
     if (lrelu1_done) D1 = gA(1);
     else GI_TRY(act_bn_bwd(net, s, gA(1), c, 0, gC(1), 2 * c, 0, C(1), 2 * c, 0, nullptr, D, pix, c, GI_ACT_LRELU, 1.f, nullptr, need_wgrad));
-    if (need_wgrad)
+    if (need_wgrad && c1w.applied)
+      GI_TRY(op_c1_wgrad_reduce(st, c1w.part, net->grads + net->conv[1].w_off, c * 16, c1w.blocks, c1w.part + (int64_t)c1w.blocks * 1024,
+                                net->c1w_floats - (int64_t)c1w.blocks * 1024));
+    else if (need_wgrad)
       GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->conv[1].w_off, n, net->Hk[1], net->Wk[1], c, c,
                          0, 0, iLS, 1.f, nullptr, (float*)net->shared(net->oPart), net->part_floats));
     if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->conv[1].w_off, nullptr, dx, n, net->Hk[1], net->Wk[1], c, c, 0, 0, 0, iLS,
@@ -1616,6 +1644,7 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
     GI_TRY(op_head_backward(st, dt, hb));
   }
   int lrelu1_done = 0;
+  C1WFuse c1w;
   for (int i = 4; i >= 2; --i) {
     if (i == 4 ? phase == 2 : phase == 1) continue;
     const Conv& c = net->dconv[i];
@@ -1637,9 +1666,17 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
       pbf = &net->bwd_pending[net->dbn[i - 1].id];
       *pbf = bwd_fuse_plan(net, s, net->dbn[i - 1], net->slot(s, net->oRd[i - 1]), pix * 4, pix / 256 * 4, 0.2f);
     }
+    // ... and conv1's weight gradient is formed from that GEMM's tiles while they are in LDS (IgemmArgs::c1w_*); without an input
+    // gradient to compute, the gradient at conv1's output is never stored
+    C1WFuse* pc1w = nullptr;
+    if (fuse1 && need_wgrad && net->oC1w >= 0 && gi_opt(GI_OPT_C1W_FUSE)) {
+      c1w.img = (const float*)net->slot(s, net->oX); c1w.part = (float*)net->shared(net->oC1w); c1w.part_floats = net->c1w_floats - 64 * 1024;
+      c1w.scale = iLS; c1w.skip_out = dx ? 0 : 1;
+      pc1w = &c1w;
+    }
     GI_TRY(igemm(net, 1, D, c.ca, c.ca, 0, phase_ptr(net, c), net->shared(net->ogA[i - 1]), c.cb, c.cb, 0, n, Hs, Ws, 0, GI_ACT_NONE, false,
                  nullptr, 0, fuse1 ? net->slot(s, net->oA[1]) : nullptr, 64, 0.2f, fuse1 ? &lrelu1_done : nullptr, nullptr, 0, nullptr, nullptr, pbf, nullptr,
-                 nullptr, (fuse1 && net->slot_bits1[s] && gi_opt(GI_OPT_MASK_BITS)) ? (const unsigned long long*)net->slot(s, net->oBits1) : nullptr));
+                 nullptr, (fuse1 && net->slot_bits1[s] && gi_opt(GI_OPT_MASK_BITS)) ? (const unsigned long long*)net->slot(s, net->oBits1) : nullptr, pc1w));
   }
   if (phase == 1) return GI_OK;
   const int64_t pix = (int64_t)n * (H / 2) * (W / 2);
@@ -1650,7 +1687,10 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
     GI_TRY(act_bn_bwd(net, s, net->shared(net->ogA[1]), 64, 0, nullptr, 0, 0, net->slot(s, net->oA[1]), 64, 0, nullptr, D, pix, 64, GI_ACT_LRELU,
                       1.f, nullptr, need_wgrad));
   }
-  if (need_wgrad)
+  if (need_wgrad && c1w.applied)
+    GI_TRY(op_c1_wgrad_reduce(st, c1w.part, net->grads + net->dconv[1].w_off, 64 * 16, c1w.blocks, c1w.part + (int64_t)c1w.blocks * 1024,
+                              net->c1w_floats - (int64_t)c1w.blocks * 1024));
+  else if (need_wgrad)
     GI_TRY(op_c1_wgrad(st, dt, D1, (const float*)net->slot(s, net->oX), net->grads + net->dconv[1].w_off, n, H / 2, W / 2, 64, 64, 0, 0, iLS, 1.f,
                        nullptr, (float*)net->shared(net->oPart), net->part_floats));
   if (dx) GI_TRY(op_c1_scatter(st, dt, D1, net->params + net->dconv[1].w_off, nullptr, dx, n, H / 2, W / 2, 64, 64, 0, 0, 0, iLS,

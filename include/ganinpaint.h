@@ -75,7 +75,11 @@ int gi_version(void);
  *                         before it returns; same kernels, same operands, same results)
  *   GI_MASK_BITS [1]      0: the LeakyReLU backward of the first layer, fused into the second layer's input-gradient GEMM, reads the
  *                         layer's fp16 activation (128 bytes per pixel) instead of the 64-bit sign word per pixel the forward wrote
- *                         beside it, and applies the slope to the fp16-rounded gradient instead of the fp32 accumulator */
+ *                         beside it, and applies the slope to the fp16-rounded gradient instead of the fp32 accumulator
+ *   GI_C1W_FUSE [1]       0: the weight gradient of the first (single-channel) layer as its own launch reading the gradient at the
+ *                         layer's output from memory, instead of from the tiles of the second layer's input-gradient GEMM while they
+ *                         are in LDS (that gradient is then not stored at all unless the network's input gradient is asked for).
+ *                         Needs GI_MASK_BITS = 1 */
 int gi_set_option(const char* name, int value);
 int gi_get_option(const char* name, int* value);
 /* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.

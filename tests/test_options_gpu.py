@@ -155,7 +155,7 @@ def _patchgan_run(dtype, seed=66, N=8, HW=128, groups=2):
     return y.detach().cpu(), dx.detach().cpu(), net.flat_grads().detach().cpu().clone(), stats
 
 
-NET_OPTIONS = [("GI_BN_FOLD", 1), ("GI_C1_FUSED", 0), ("GI_MASK_BITS", 0), ("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
+NET_OPTIONS = [("GI_BN_FOLD", 1), ("GI_C1_FUSED", 0), ("GI_MASK_BITS", 0), ("GI_C1W_FUSE", 0), ("GI_BN_ACC", 0), ("GI_FUSE_HEAD", 0), ("GI_BN_BWD_FUSE", 0), ("GI_BN_BWD_SMALL", 0), ("GI_HEAD_FAST", 0), ("GI_IGEMM7", 0),
                ("GI_IGEMM6", 0), ("GI_WGRAD3", 0), ("GI_WGRAD2", 0), ("GI_IGEMM8", 2), ("GI_IGEMM8", 0)]
 
 
