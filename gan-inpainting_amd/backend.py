@@ -103,6 +103,9 @@ PROTOTYPES = {
     "gi_adam_step_guarded": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _f, _vp]),
     "gi_adam_step_guarded2": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _f, _vp]),
     "gi_rmsprop_step_guarded": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp]),
+    "gi_check_finite_scan_word": (_i, [_vp, _vp, _i64, _vp, _i]),
+    "gi_adam_step_scan": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _i, _i, _f, _vp, _i, _i]),
+    "gi_rmsprop_step_scan": (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _vp, _i, _i]),
     "gi_wgrad_s2_scratch_bytes": (_i64, [_i, _i, _i, _i, _i, _i]),
     "gi_wgrad_s2_ws": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i64]),
     "gi_conv_s2_forward": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64]),

@@ -1187,6 +1187,21 @@ __global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n,
 }
 
 // ---- optimizers --------------------------------------------------------------------------------
+// The verdict of the finite check (gi_check_finite*): guard[1] after the finish launch (vword = 0), or - vword = 2 / 3, no finish
+// launch - the scan word itself: every workgroup reads it, and for the first kernel of an update (finish) one thread also does what
+// the finish launch did (guard[1] = verdict, guard[0] += verdict) and clears the OTHER scan word for the next update's scan. The word
+// in use cannot be cleared here (later workgroups still read it): updates alternate between the two.
+__device__ __forceinline__ int gi_guard_verdict(int* guard, int vword, int finish) {
+  if (!guard) return 0;
+  if (vword == 0) return guard[1];
+  const int verdict = guard[vword];
+  if (finish && blockIdx.x == 0 && threadIdx.x == 0) {
+    guard[1] = verdict;
+    if (verdict) guard[0] += 1;
+    guard[vword ^ 1] = 0;
+  }
+  return verdict;
+}
 // guard (may be null): guard[1] != 0 means "the gradients of this update hold inf/NaN" (gi_check_finite): skip it whole
 // omb1 / omb2 / step_size: 1 - beta1, 1 - beta2 and lr / bias_correction1 are formed in double on the host and rounded once,
 // as torch.optim does with its Python floats (1.f - 0.999f differs from float(1 - 0.999) by 1e-4 relative)
@@ -1194,8 +1209,8 @@ __global__ void __launch_bounds__(256) adv_loss_kernel(const float* pred, int n,
 // the bias corrections are formed here from step - (guard[0] - seen), in double by one thread, so a skipped update never advances them
 __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, float* m, float* v, int64_t count, float step_size,
                                                    float b1, float b2, float eps, float omb1, float omb2, float sqrt_bc2, float gs,
-                                                   const int* guard, int step, int seen, double lrd, double b1d, double b2d) {
-  if (guard && guard[1]) return;
+                                                   int* guard, int step, int seen, double lrd, double b1d, double b2d, int vword, int finish) {
+  if (gi_guard_verdict(guard, vword, finish)) return;
   if (guard && seen >= 0) {
     __shared__ float s_ss, s_sq;
     if (threadIdx.x == 0) {
@@ -1219,8 +1234,8 @@ __global__ void __launch_bounds__(256) adam_kernel(float* p, const float* g, flo
   }
 }
 __global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, float* sq, int64_t count, float lr,
-                                                      float alpha, float oma, float eps, float clampv, float gs, const int* guard) {
-  if (guard && guard[1]) return;
+                                                      float alpha, float oma, float eps, float clampv, float gs, int* guard, int vword, int finish) {
+  if (gi_guard_verdict(guard, vword, finish)) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const float gg = g[i] * gs;
     const float s = alpha * sq[i] + oma * gg * gg;
@@ -1233,7 +1248,7 @@ __global__ void __launch_bounds__(256) rmsprop_kernel(float* p, const float* g, 
 // flag[2] |= 1 when any element of g is inf or NaN.
 // (Measured and dropped in round 4: the workgroup that ends last also doing the finish - every workgroup adds to a ticket on the
 //  same word after its OR - made the scan 5 -> 20 us on the critic's 1350 workgroups: 1350 returning atomics on one address at ~12 ns.)
-__global__ void __launch_bounds__(256) check_finite_kernel(const float* __restrict__ g, int64_t count, int* flag) {
+__global__ void __launch_bounds__(256) check_finite_kernel(const float* __restrict__ g, int64_t count, int* flag, int word) {
   int bad = 0;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(g) & 15) == 0) ? count / 4 : 0;   // 16-byte chunks, two in flight per thread
   const u4_t* g4 = (const u4_t*)g;
@@ -1253,7 +1268,7 @@ __global__ void __launch_bounds__(256) check_finite_kernel(const float* __restri
     const unsigned u = __float_as_uint(g[j]);
     bad |= ((u & 0x7F800000u) == 0x7F800000u) ? 1 : 0;
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag + 2, 1);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag + word, 1);
 }
 // flag[1] = this update's verdict, flag[0] += it (running count of skipped updates), flag[2] = 0
 __global__ void check_finite_finish_kernel(int* flag) {
@@ -1862,6 +1877,11 @@ int gi_adam_step_guarded(gi_ctx* ctx, float* p, const float* g, float* m, float*
 }
 int gi_adam_step_guarded2(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
                           float eps, int step, int skipped_seen, float grad_scale, const int* guard) {
+  return gi_adam_step_scan(ctx, p, g, m, v, count, lr, beta1, beta2, eps, step, skipped_seen, grad_scale, (int*)guard, 0, 0);
+}
+int gi_adam_step_scan(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                      float eps, int step, int skipped_seen, float grad_scale, int* guard, int word, int finish) {
+  GI_REQUIRE(word == 0 || ((word == 2 || word == 3) && guard), "adam: scan word %d", word);
   GI_REQUIRE(step >= 1, "adam: step=%d must be >= 1", step);
   // torch.optim forms 1 - beta and lr / bias_correction1 from Python floats (doubles) and rounds once. The hyper-parameters
   // arrive here as C floats (0.999f = 0.99900001...): recover the decimal the caller wrote (7 significant digits) first
@@ -1869,7 +1889,7 @@ int gi_adam_step_guarded2(gi_ctx* ctx, float* p, const float* g, float* m, float
   const double b1 = py(beta1), b2 = py(beta2), lrd = py(lr);
   const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, m, v, count, (float)(lrd / bc1), beta1, beta2, eps,
-                     (float)(1.0 - b1), (float)(1.0 - b2), (float)sqrt(bc2), grad_scale, guard, step, guard ? skipped_seen : -1, lrd, b1, b2);
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)sqrt(bc2), grad_scale, (int*)guard, step, guard ? skipped_seen : -1, lrd, b1, b2, word, finish);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
@@ -1879,17 +1899,23 @@ int gi_rmsprop_step(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t co
 }
 int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps,
                             float clamp, float grad_scale, const int* guard) {
+  return gi_rmsprop_step_scan(ctx, p, g, sq, count, lr, alpha, eps, clamp, grad_scale, (int*)guard, 0, 0);
+}
+int gi_rmsprop_step_scan(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps,
+                         float clamp, float grad_scale, int* guard, int word, int finish) {
+  GI_REQUIRE(word == 0 || ((word == 2 || word == 3) && guard), "rmsprop: scan word %d", word);
   char b[32];
   snprintf(b, sizeof b, "%.7g", (double)alpha);          // the Python float the caller meant (0.99), see gi_adam_step_guarded
   const float oma = (float)(1.0 - atof(b));
   hipLaunchKernelGGL(rmsprop_kernel, dim3(nblocks(count)), dim3(256), 0, ctx->stream, p, g, sq, count, lr, alpha, oma, eps, clamp, grad_scale,
-                     guard);
+                     guard, word, finish);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }
-int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3) {
-  GI_REQUIRE(ctx && g && flag3 && count > 0, "check_finite_scan: bad argument");
-  hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks((count + 3) / 4, 2)), dim3(256), 0, ctx->stream, g, count, flag3);
+int gi_check_finite_scan(gi_ctx* ctx, const float* g, int64_t count, int* flag3) { return gi_check_finite_scan_word(ctx, g, count, flag3, 2); }
+int gi_check_finite_scan_word(gi_ctx* ctx, const float* g, int64_t count, int* flag4, int word) {
+  GI_REQUIRE(ctx && g && flag4 && count > 0 && (word == 2 || word == 3), "check_finite_scan: bad argument");
+  hipLaunchKernelGGL(check_finite_kernel, dim3(nblocks((count + 3) / 4, 2)), dim3(256), 0, ctx->stream, g, count, flag4, word);
   GI_LAUNCH_CHECK();
   return GI_OK;
 }

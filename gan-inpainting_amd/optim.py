@@ -38,17 +38,19 @@ class _FlatOptimizer:
     def _guard_ptr(self):
         """Run the finite check over the gradients of EVERY network of this optimizer into one shared verdict (all of
         them skip the update or none does, and a skipped update counts once whatever the number of networks); returns
-        the device flag pointer (None when the guard is off)."""
+        (device flag pointer, scan word) - (None, 0) when the guard is off. No finish launch: the update's first
+        optimizer kernel records the verdict (gi_*_step_scan, include/ganinpaint.h); updates alternate between two scan words."""
         if not self.guard:
-            return None
+            return None, 0
         lib = B.lib()
         if self._flags is None:
-            self._flags = torch.zeros(3, dtype=torch.int32, device=self.nets[0].flat_params().device)
+            self._flags = torch.zeros(4, dtype=torch.int32, device=self.nets[0].flat_params().device)
+            self._word = 3
+        self._word = 5 - self._word      # 2, 3, 2, ...
         for net in self.nets:
             g = net.flat_grads()
-            B.check(lib.gi_check_finite_scan(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags)))
-        B.check(lib.gi_check_finite_finish(B.get_ctx(self._flags.device), B.ptr(self._flags)))
-        return B.ptr(self._flags)
+            B.check(lib.gi_check_finite_scan_word(B.get_ctx(g.device), B.ptr(g), g.numel(), B.ptr(self._flags), self._word))
+        return B.ptr(self._flags), self._word
 
     def poll_skipped(self):
         """Number of updates skipped since the last poll (one device read-back: call it at logging cadence)."""
@@ -78,13 +80,13 @@ class Adam(_FlatOptimizer):
     def step(self):
         self.t += 1
         lib = B.lib()
-        guard = self._guard_ptr()
-        for n, st in zip(self.nets, self.state):
+        guard, word = self._guard_ptr()
+        for k, (n, st) in enumerate(zip(self.nets, self.state)):
             p, g = n.flat_params(), n.flat_grads()
             # self.t still counts the updates skipped since the last poll_skipped(); the kernel subtracts them (device count - _seen)
-            B.check(lib.gi_adam_step_guarded2(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
-                                              self.lr, self.betas[0], self.betas[1], self.eps, self.t, self._seen if guard else -1,
-                                              self.grad_scale, guard))
+            B.check(lib.gi_adam_step_scan(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["m"]), B.ptr(st["v"]), p.numel(),
+                                          self.lr, self.betas[0], self.betas[1], self.eps, self.t, self._seen if guard else -1,
+                                          self.grad_scale, guard, word, 1 if k == 0 else 0))
         self._done()
 
     def poll_skipped(self):
@@ -106,11 +108,11 @@ class RMSprop(_FlatOptimizer):
     @torch.no_grad()
     def step(self):
         lib = B.lib()
-        guard = self._guard_ptr()
-        for n, st in zip(self.nets, self.state):
+        guard, word = self._guard_ptr()
+        for k, (n, st) in enumerate(zip(self.nets, self.state)):
             p, g = n.flat_params(), n.flat_grads()
-            B.check(lib.gi_rmsprop_step_guarded(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["sq"]), p.numel(), self.lr,
-                                                self.alpha, self.eps, self.clamp, self.grad_scale, guard))
+            B.check(lib.gi_rmsprop_step_scan(B.get_ctx(p.device), B.ptr(p), B.ptr(g), B.ptr(st["sq"]), p.numel(), self.lr,
+                                             self.alpha, self.eps, self.clamp, self.grad_scale, guard, word, 1 if k == 0 else 0))
         self._done()
 
 

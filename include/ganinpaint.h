@@ -270,6 +270,15 @@ int gi_adam_step_guarded2(gi_ctx* ctx, float* p, const float* g, float* m, float
                           float beta1, float beta2, float eps, int step, int skipped_seen, float grad_scale, const int* guard);
 int gi_rmsprop_step_guarded(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr,
                             float alpha, float eps, float clamp, float grad_scale, const int* guard);
+/* Without the finish launch: flag4 is 4 device ints {running count, verdict of the latest update, scan word, scan word}. An update
+ * scans its buffers into flag4[word] (word = 2 or 3, the other one than the previous update used) and passes the same word to the
+ * *_scan optimizer steps, which take their verdict from it; the FIRST step of the update (finish = 1) also records it (flag4[1],
+ * flag4[0]) and clears the other word for the next update. word = 0: the *_guarded behaviour (verdict from flag4[1]). */
+int gi_check_finite_scan_word(gi_ctx* ctx, const float* g, int64_t count, int* flag4, int word);
+int gi_adam_step_scan(gi_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                      float eps, int step, int skipped_seen, float grad_scale, int* guard, int word, int finish);
+int gi_rmsprop_step_scan(gi_ctx* ctx, float* p, const float* g, float* sq, int64_t count, float lr, float alpha, float eps,
+                         float clamp, float grad_scale, int* guard, int word, int finish);
 /* mean(|g|) of `nseg` segments [off[i], off[i]+len[i]) of g -> out[i]
  * (gradient-flow statistics, minimaxgan_l1.py:180-182); offsets/lengths are device int64 */
 int gi_grad_absmean(gi_ctx* ctx, const float* g, const int64_t* seg_off, const int64_t* seg_len,

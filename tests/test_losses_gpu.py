@@ -211,3 +211,32 @@ def test_clamp_parameters_is_the_reference_loop():
     for p in D.parameters():
         p.data.clamp_(-0.02, 0.02)
     assert float(D.flat_params().abs().max()) <= 0.02 and float(D.flat_params().abs().max()) > 0.011
+
+
+def test_rmsprop_consecutive_skipped_updates_and_the_two_scan_words():
+    """The finite check has no finish launch: an update scans into one of two flag words and its optimizer kernel takes the verdict
+    from that word, records it and clears the OTHER word for the next update. Two skipped updates in a row (both words set once), then
+    clean ones: exactly the clean gradients are applied, and the count of skipped updates is 2."""
+    torch.manual_seed(6)
+    D = networks.PatchGANDiscriminator(sigmoid=False, image_size=64, dtype="fp16").cuda()
+    ref = {k: v.detach().cpu().clone().contiguous() for k, v in D.named_parameters()}
+    ps = [torch.nn.Parameter(v) for v in ref.values()]
+    o, t = optim.RMSprop(D.parameters(), lr=0.00005), torch.optim.RMSprop(ps, lr=0.00005)
+    assert o.guard
+    gen = torch.Generator().manual_seed(10)
+    for it in range(6):
+        bad = it in (1, 2)
+        for (name, p), q in zip(D.named_parameters(), ps):
+            g = torch.randn(q.shape, generator=gen) * 0.01
+            p.grad.copy_(g.cuda())
+            if bad and name.endswith("model.2.weight"):
+                p.grad[-1, -1, -1, -1] = float("nan") if it == 1 else float("-inf")
+            q.grad = g.clone()
+        o.step()
+        if not bad:
+            t.step()
+    assert o.poll_skipped() == 2
+    assert o.poll_skipped() == 0
+    for (name, p), q in zip(D.named_parameters(), ps):
+        e = float((p.detach().cpu() - q.detach()).abs().max())
+        assert e <= 1e-6 * float(q.detach().abs().max()) + 1e-9, (name, e)
