@@ -29,8 +29,10 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
 done
 # E. one generator forward; one critic-only batch; one batch with a generator update (kernel chains)
 run gfwd rocprofv3 --kernel-trace --output-format csv -d $OUT/gfwd -- python3 $R/tools/gfwd_only.py 20
+export GI_WGRAD_STREAM=0   # the chains on ONE stream (the weight gradients in line): durations add up; the benchmark itself uses two
 run step_critic rocprofv3 --kernel-trace --output-format csv -d $OUT/step_critic -- python3 $R/tools/step_chain.py 4 critic
 run step_gen rocprofv3 --kernel-trace --output-format csv -d $OUT/step_gen -- python3 $R/tools/step_chain.py 4 gen
+unset GI_WGRAD_STREAM
 fi
 if [ "$PART" != "1" ]; then
 # F. secondary workloads: the plain line (no profiler) and the kernel statistics
