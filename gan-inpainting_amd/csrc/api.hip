@@ -25,7 +25,7 @@ OptDesc g_opts[GI_OPT_COUNT] = {
   {"GI_IGEMM5", 7, 0, 0}, {"GI_IGEMM6", 1, 0, 0}, {"GI_IGEMM7", 1, 0, 0}, {"GI_IGEMM_FIXUP", 1, 0, 0}, {"GI_IGEMM_VARIANT", 3, 0, 0},
   {"GI_BN_ACC", 1, 0, 0}, {"GI_FUSE_HEAD", 1, 0, 0}, {"GI_HEAD_FAST", 1, 0, 0}, {"GI_BN_BWD_FUSE", 1, 0, 0}, {"GI_BN_BWD_SMALL", 512, 0, 0},
   {"GI_WGRAD2", 1, 0, 0}, {"GI_WGRAD3", 1, 0, 0}, {"GI_IGEMM8", 1, 0, 0}, {"GI_BN_FOLD", 0, 0, 0}, {"GI_C1_FUSED", 1, 0, 0},
-  {"GI_WGRAD_STREAM", 1, 0, 0}, {"GI_MASK_BITS", 1, 0, 0}, {"GI_C1W_FUSE", 1, 0, 0},
+  {"GI_WGRAD_STREAM", 1, 0, 0}, {"GI_MASK_BITS", 1, 0, 0}, {"GI_C1W_FUSE", 1, 0, 0}, {"GI_IGEMM7_WAVES", 8, 0, 0},
 };
 thread_local const char* g_last_kernel = "";   // per host thread: gi_debug_last_kernel never reports another thread's launch
 int g_fold_count = 0;

@@ -23,7 +23,7 @@ void gi_set_error(const char* fmt, ...);
 // once per process), else the default. include/ganinpaint.h documents each; tests/test_options_gpu.py runs every alternative.
 enum gi_opt_id {
   GI_OPT_IGEMM5 = 0, GI_OPT_IGEMM6, GI_OPT_IGEMM7, GI_OPT_IGEMM_FIXUP, GI_OPT_IGEMM_VARIANT, GI_OPT_BN_ACC, GI_OPT_FUSE_HEAD,
-  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_WGRAD_STREAM, GI_OPT_MASK_BITS, GI_OPT_C1W_FUSE, GI_OPT_COUNT
+  GI_OPT_HEAD_FAST, GI_OPT_BN_BWD_FUSE, GI_OPT_BN_BWD_SMALL, GI_OPT_WGRAD2, GI_OPT_WGRAD3, GI_OPT_IGEMM8, GI_OPT_BN_FOLD, GI_OPT_C1_FUSED, GI_OPT_WGRAD_STREAM, GI_OPT_MASK_BITS, GI_OPT_C1W_FUSE, GI_OPT_IGEMM7_WAVES, GI_OPT_COUNT
 };
 int gi_opt(int id);
 // name of the GEMM / weight-gradient kernel a dispatcher has just launched (gi_debug_last_kernel: tests assert which kernel

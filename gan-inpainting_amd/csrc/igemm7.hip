@@ -37,6 +37,7 @@ struct KP7 {
   int relu_in, act_out, relu_cend;
   int Hin, Win, Hout, Wout;
   int mtiles, ntiles;
+  int dbg;            // ablation build only (GI_IGEMM7_DBG): 1 no MFMA, 2 no LDS-DMA (timing experiments, wrong results)
   // folded normalisation (IgemmFold, common.h): fold != 0 -> the last finisher of a channel column normalises the column
   int fold;
   unsigned* col_tickets;             // [ntiles], zero before the launch and left zero
@@ -45,10 +46,14 @@ struct KP7 {
   uint8_t* fdrop; float fdrop_scale; uint64_t fdrop_seed; uint32_t fdrop_thresh;
 };
 
-__device__ __forceinline__ h8_t relu7(h8_t v) {
+// max(v, floor) on the halves as 16-bit integers: floor = 0 is the ReLU (negative halves, sign bit set, are negative integers), floor =
+// -32768 leaves v as it is. A wave-uniform floor instead of a wave-uniform branch around the ReLU: a branch between the fragment reads
+// and the MFMAs makes hipcc wait for ALL outstanding LDS reads at the join (`s_waitcnt lgkmcnt(0)`), i.e. also for the second K
+// half's reads that are meant to run under the first half's MFMAs.
+__device__ __forceinline__ h8_t relu7(h8_t v, short floor) {
   typedef short s8_t __attribute__((ext_vector_type(8)));
   s8_t h = __builtin_bit_cast(s8_t, v);
-  const s8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  const s8_t z = {floor, floor, floor, floor, floor, floor, floor, floor};
   h = __builtin_elementwise_max(h, z);
   return __builtin_bit_cast(h8_t, h);
 }
@@ -58,8 +63,10 @@ __device__ __forceinline__ void glds16_7(const char* src, char* lds_wave_base) {
 }
 template <int N>
 __device__ __forceinline__ void wait_vm7() {   // counted wait: all but the N youngest LDS-DMA pieces have landed
-  static_assert(N >= 0 && N <= 63 && (N % 6 == 0 || N % 8 == 0), "unexpected DMA count");
+  static_assert(N >= 0 && N <= 63, "unexpected DMA count");
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -72,22 +79,31 @@ __device__ __forceinline__ void wait_vm7() {   // counted wait: all but the N yo
 
 // NSTG: ring stages; PF: split-K tiles requested together in the last arriver's tail. Shipped: GI7_NSTG / GI7_PF below; the
 // ablation build (build.sh -DGI_ABLATION) instantiates the alternatives, selected by GI_IGEMM7_NSTG / GI_IGEMM7_PF.
-template <int PHASE, int BN, int NSTG_, int PF_>
-__global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
-  constexpr int BM = 128, BK = 64, NW = 4;
+// NW: waves per workgroup. 4 (2 x 2 waves, 64 x BN/2 each): ONE wave per SIMD - its LDS fragment reads (512 cycles per K tile at the
+// LDS' 128 bytes per clock), its 32 MFMAs (512) and the issue of its 8 LDS-DMA pieces (~460) run one after the other, nothing else
+// is resident to fill the gaps: 0.83 us per K tile on d5, of which 0.45 remain with the MFMAs and the DMA switched off (ablation,
+// DESIGN.md 4.1j). 8 (2 x 4 waves, 64 x BN/4 each): two waves per SIMD, one's reads and DMA issue under the other's MFMAs; half
+// the DMA pieces and MFMAs per wave, 1.5 x the fragment-read bytes. The register cap of two waves per SIMD (256) also keeps hipcc
+// from parking accumulators in AGPRs (with 512 registers allowed it copied four of them around every MFMA).
+template <int PHASE, int BN, int NSTG_, int PF_, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) igemm7_kernel(KP7 p) {
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  constexpr int BM = 128, BK = 64, NTHR = NW * 64;
+  constexpr int NWM = (NW == 8 && BN == 64) ? 4 : 2, NWN = NW / NWM;   // waves along M / N: wave tiles 64 x BN/2 | 64 x 32 (BN 128) | 32 x 32 (BN 64)
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 32 / 24 KiB
   // ring depth (K tiles of 64: 32 KiB per stage with 128-column tiles, 24 KiB with 64-column ones)
   constexpr int NSTG = NSTG_;
   constexpr int AH = NSTG - 1;               // K tiles issued ahead of the one being multiplied
   constexpr int AJ = (BM / 8) / NW, BJ = (BN / 8) / NW;   // 8-row blocks per wave per tile: 4 + (4 | 2)
   constexpr int NPC = AJ + BJ;
-  constexpr int WN = BN / 2, MT = 4, NT = WN / 16;
+  constexpr int WM = BM / NWM, WN = BN / NWN, MT = WM / 16, NT = WN / 16;
+  static_assert(MT >= 1 && NT >= 1 && MT * NT >= 4, "wave tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int s_last;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
 
   // ---- work decode: (M tile, N tile, phase, split). With >= 8 M tiles the workgroups of one XCD (bid & 7) share M tiles
   //      (gathered rows from that XCD's L2); with fewer, consecutive workgroups walk the N tiles / splits so that all XCDs work
@@ -113,7 +129,11 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   const char* wptr = p.w + (PHASE == 1 ? (int64_t)ph * p.cout * p.Ktot * 2 : 0);
   const int kt0 = ks * p.kt_per_split;
   const int kt1 = min(p.nk, kt0 + p.kt_per_split);
+#ifdef GI_ABLATION
+  const int nk = (p.dbg & 8) ? 1 : kt1 - kt0;   // 8: one K tile only
+#else
   const int nk = kt1 - kt0;
+#endif
 
   // ---- per-lane gather rows (igemm3.hip) -----------------------------------------------------------
   const int lrow = lane >> 3;
@@ -168,6 +188,9 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   auto issue_piece = [&](auto STG, auto PIECE) {
     constexpr int stage = decltype(STG)::value;
     constexpr int j = decltype(PIECE)::value;
+#ifdef GI_ABLATION
+    if (p.dbg & 2) return;
+#endif
     if constexpr (j < AJ) glds16_7(pa[j] + c0 * 2, smem + stage * STAGE + wave * (AJ * 1024) + j * 1024);
     else glds16_7(pb[j - AJ] + (int64_t)kt_issue * (BK * 2), smem + stage * STAGE + A_BYTES + wave * (BJ * 1024) + (j - AJ) * 1024);
   };
@@ -188,8 +211,8 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
   const int lr = lane & 15, lq = lane >> 4;
-  const int rdA0 = (wm * 64 + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
-  const int rdA1 = (wm * 64 + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
+  const int rdA0 = (wm * WM + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
+  const int rdA1 = (wm * WM + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
   const int rdB0 = A_BYTES + (wn * WN + lr) * 128 + (((0 + lq) ^ (lr & 7)) << 4);
   const int rdB1 = A_BYTES + (wn * WN + lr) * 128 + (((4 + lq) ^ (lr & 7)) << 4);
   const int relu_cend = p.relu_in ? p.relu_cend : 0;
@@ -200,26 +223,43 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
     constexpr int stage = decltype(STG)::value;
     constexpr bool iss = decltype(ISS)::value;
     constexpr int NMF = 2 * MT * NT;
-    const bool relu_in = cc0 < relu_cend;   // wave-uniform
+    const short rfloor = cc0 < relu_cend ? (short)0 : (short)-32768;   // wave-uniform: ReLU on / off (relu7)
     const char* s = smem + stage * STAGE;
+    // both K halves' fragments are requested before the first MFMA: the second half's reads (LDS bandwidth: 32 KiB per half for the
+    // workgroup) run under the first half's MFMAs. (Read per half, hipcc issued the second half's reads only after ten MFMAs of the
+    // first and the wave - the only one on its SIMD - waited for LDS twice per tile: 0.45 of the 0.83 us per tile, measured with the
+    // MFMAs and the DMA switched off.)
+    h8_t af[2][MT], bf[2][NT];
+    // fragments of the second K half: read r (r < MT: pixel fragment r, else column fragment r - MT)
+    auto read1 = [&](int r) {
+      if (r < MT) af[1][r] = *(const h8_t*)(s + rdA1 + r * 2048);
+      else bf[1][r - MT] = *(const h8_t*)(s + rdB1 + (r - MT) * 2048);
+    };
+    constexpr int NRD = MT + NT, PS = NRD < MT * NT ? NRD : MT * NT;   // PS of them go behind the first MFMAs, the rest up front
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af[0][mt] = *(const h8_t*)(s + rdA0 + mt * 2048);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *(const h8_t*)(s + rdB0 + nt * 2048);
+#pragma unroll
+    for (int r = 0; r < NRD - PS; ++r) read1(r);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-      h8_t af[MT], bf[NT];
-      const int oa = k2 ? rdA1 : rdA0, ob = k2 ? rdB1 : rdB0;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const h8_t*)(s + oa + mt * 2048);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const h8_t*)(s + ob + nt * 2048);
-      if (relu_in) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = relu7(af[mt]);
-      }
+      for (int mt = 0; mt < MT; ++mt) af[k2][mt] = relu7(af[k2][mt], rfloor);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const int idx = k2 * MT * NT + mt * NT + nt;
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+#ifdef GI_ABLATION
+          if (!(p.dbg & 1))
+#endif
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[k2][nt], af[k2][mt], acc[mt][nt], 0, 0, 0);   // D^T: rows = channels
+          if (k2 == 0 && idx < PS) {               // one read of the second half behind each of the first MFMAs, pinned
+            read1(NRD - PS + idx);
+            __builtin_amdgcn_sched_barrier(0);
+          }
           if constexpr (iss) {
             static_for<NPC>([&](auto Q) {
               constexpr int q = decltype(Q)::value;
@@ -279,6 +319,17 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   // the alternative (release fence in every workgroup + acquire in the last arriver) measured 1.6x slower on these layers.
   // The tickets are zero at bind time and every launch leaves them zero (the last arriver resets its tile's ticket); a launch
   // that FAILS leaves the context unusable anyway (GI_ERR_HIP), so a stale ticket never meets a later launch of a live context.
+#ifdef GI_ABLATION
+  if (p.dbg & 4) {   // no split-K hand-off, no epilogue: keep the accumulators alive
+    float tsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) tsum += acc[i][j][0] + acc[i][j][3];
+    if (tsum == 12345.678f) p.out[0] = 1;
+    return;
+  }
+#endif
   if (p.splitk > 1) {
     constexpr int NF = MT * NT;
     constexpr int TILE_BYTES = BM * BN * 4;
@@ -288,7 +339,7 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
     const unsigned mine = (unsigned)(ks * ntile + tile) * TILE_BYTES + tid * 16;
 #pragma unroll
     for (int i = 0; i < NF; ++i)
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, acc[i / NT][i % NT]), rsW, mine + i * 4096, 0, 16);   // sc1
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, acc[i / NT][i % NT]), rsW, mine + i * (NTHR * 16), 0, 16);   // sc1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -310,7 +361,7 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
       for (int j = 0; j < PF; ++j) {
         const unsigned src = k0 + j < p.splitk ? (unsigned)((k0 + j) * ntile + tile) * TILE_BYTES + tid * 16 : 0x80000000u;
 #pragma unroll
-        for (int i = 0; i < NF; ++i) v[j][i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * 4096, 0, 16));
+        for (int i = 0; i < NF; ++i) v[j][i] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rsW, src + i * (NTHR * 16), 0, 16));
       }
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
@@ -333,7 +384,7 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   };
   constexpr int SLD = BN + 8;
   half_t* stg = (half_t*)smem;
-  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [2][BN][2]
+  float* red = (float*)(smem + (int64_t)BM * SLD * 2);   // [NWM][BN][2]
   const bool stats = p.partials || p.stat_acc;
   gi_with_act(p.act_out, [&](auto ACTc) {                // the activation, statistics and bias as compile-time constants (common.h)
   gi_with_bool(stats, [&](auto STc) {
@@ -359,7 +410,7 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
           if constexpr (ST) { s[r] += v; q[r] += v * v; }
           o[r] = (half_t)gi_act_c<ACT>(v);
         }
-        *(h4_t*)(stg + (wm * 64 + mt * 16 + lr) * SLD + ch) = o;
+        *(h4_t*)(stg + (wm * WM + mt * 16 + lr) * SLD + ch) = o;
       }
       if constexpr (ST) {
 #pragma unroll
@@ -373,7 +424,9 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   }); }); });
   __syncthreads();
   if ((p.partials || p.stat_acc) && tid < BN) {
-    const float s = red[tid * 2] + red[(BN + tid) * 2], q = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWM; ++w) { s += red[(w * BN + tid) * 2]; q += red[(w * BN + tid) * 2 + 1]; }   // (two addends: the same sum as ever)
     if (p.stat_acc) {
       const int grp = (p.stat_pg > 0 && m0 >= p.stat_pg) ? 1 : 0, rep = (mt_idx + ph) & (p.stat_reps - 1);
       gi_stat_add(p.stat_acc, p.cout, rep, grp, 0, n0 + tid, s);
@@ -386,9 +439,9 @@ __global__ void __launch_bounds__(256, 1) igemm7_kernel(KP7 p) {
   }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row
   const int oc = tid % CPRO;
-  if (!p.fold) {
+  if (NW != 4 || !p.fold) {      // (the folded normalisation below is the four-wave kernel's: op_igemm7 never asks the other for it)
 #pragma unroll 1
-    for (int r = tid / CPRO; r < BM; r += 256 / CPRO) {
+    for (int r = tid / CPRO; r < BM; r += NTHR / CPRO) {
       const int m = m0 + r;
       if (m < p.M) {
         const int64_t o = (int64_t)out_pixel(m) * p.ldout + p.coffout + n0 + oc * 8;
@@ -560,6 +613,7 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   GI_REQUIRE((int64_t)a.n * kp.Hin * kp.Win * a.ldin < (1ll << 31) && (int64_t)a.n * kp.Hout * kp.Wout * a.ldout < (1ll << 31),
              "igemm7: tensor too large for 32-bit offsets");
   kp.mtiles = mtiles; kp.ntiles = ntiles;
+  kp.dbg = gi_tune("GI_IGEMM7_DBG", 0);
   kp.fold = fold ? 1 : 0;
   a.fold_applied = kp.fold;
   if (fold) {
@@ -588,20 +642,22 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   if (BN == 128 || nstg != 6) nstg = 4;
   if (pf != 2 && pf != 4) pf = 1;
 #endif
-  const int ring = nstg * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 2 * BN * 8;
+  // waves per workgroup (kernel header): eight unless the folded normalisation is asked for (the four-wave kernel's) or GI_IGEMM7_WAVES=4
+  const int nw = (fold || gi_opt(GI_OPT_IGEMM7_WAVES) == 4) ? 4 : 8;
+  const int ring = nstg * (128 + BN) * 128, epi = 128 * (BN + 8) * 2 + 4 * BN * 8;
   const int LDS = ring > epi ? ring : epi;
   const int vi = (BN == 64 ? 2 : 0) + mode;
-  auto launch = [&](auto NS, auto PFc) -> int {
-    constexpr int ns = decltype(NS)::value, pfc = decltype(PFc)::value;
+  auto launch = [&](auto NS, auto PFc, auto NWc) -> int {
+    constexpr int ns = decltype(NS)::value, pfc = decltype(PFc)::value, nwc = decltype(NWc)::value;
     static GiDevOnce attr_set[4];
-    const void* fn[4] = {(const void*)igemm7_kernel<0, 128, ns, pfc>, (const void*)igemm7_kernel<1, 128, ns, pfc>, (const void*)igemm7_kernel<0, 64, ns, pfc>,
-                         (const void*)igemm7_kernel<1, 64, ns, pfc>};
+    const void* fn[4] = {(const void*)igemm7_kernel<0, 128, ns, pfc, nwc>, (const void*)igemm7_kernel<1, 128, ns, pfc, nwc>,
+                         (const void*)igemm7_kernel<0, 64, ns, pfc, nwc>, (const void*)igemm7_kernel<1, 64, ns, pfc, nwc>};
     if (attr_set[vi].first()) { GI_HIP(hipFuncSetAttribute(fn[vi], hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); }
     switch (vi) {
-      case 0: hipLaunchKernelGGL((igemm7_kernel<0, 128, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
-      case 1: hipLaunchKernelGGL((igemm7_kernel<1, 128, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
-      case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
-      default: hipLaunchKernelGGL((igemm7_kernel<1, 64, ns, pfc>), dim3(grid), dim3(256), LDS, st, kp); break;
+      case 0: hipLaunchKernelGGL((igemm7_kernel<0, 128, ns, pfc, nwc>), dim3(grid), dim3(nwc * 64), LDS, st, kp); break;
+      case 1: hipLaunchKernelGGL((igemm7_kernel<1, 128, ns, pfc, nwc>), dim3(grid), dim3(nwc * 64), LDS, st, kp); break;
+      case 2: hipLaunchKernelGGL((igemm7_kernel<0, 64, ns, pfc, nwc>), dim3(grid), dim3(nwc * 64), LDS, st, kp); break;
+      default: hipLaunchKernelGGL((igemm7_kernel<1, 64, ns, pfc, nwc>), dim3(grid), dim3(nwc * 64), LDS, st, kp); break;
     }
     return GI_OK;
   };
@@ -609,12 +665,15 @@ int op_igemm7(hipStream_t st, int mode, IgemmArgs& a) {
   using I2_ = std::integral_constant<int, 2>;
   using I4_ = std::integral_constant<int, 4>;
   using I6_ = std::integral_constant<int, 6>;
+  using I8_ = std::integral_constant<int, 8>;
 #ifdef GI_ABLATION
-  if (nstg == 6) { if (pf == 4) GI_TRY(launch(I6_{}, I4_{})); else if (pf == 2) GI_TRY(launch(I6_{}, I2_{})); else GI_TRY(launch(I6_{}, I1_{})); }
-  else { if (pf == 4) GI_TRY(launch(I4_{}, I4_{})); else if (pf == 2) GI_TRY(launch(I4_{}, I2_{})); else GI_TRY(launch(I4_{}, I1_{})); }
+  if (nw == 8) GI_TRY(launch(I4_{}, I1_{}, I8_{}));
+  else if (nstg == 6) { if (pf == 4) GI_TRY(launch(I6_{}, I4_{}, I4_{})); else if (pf == 2) GI_TRY(launch(I6_{}, I2_{}, I4_{})); else GI_TRY(launch(I6_{}, I1_{}, I4_{})); }
+  else { if (pf == 4) GI_TRY(launch(I4_{}, I4_{}, I4_{})); else if (pf == 2) GI_TRY(launch(I4_{}, I2_{}, I4_{})); else GI_TRY(launch(I4_{}, I1_{}, I4_{})); }
 #else
   (void)nstg; (void)pf;
-  GI_TRY(launch(std::integral_constant<int, GI7_NSTG>{}, std::integral_constant<int, GI7_PF>{}));
+  if (nw == 8) GI_TRY(launch(std::integral_constant<int, GI7_NSTG>{}, std::integral_constant<int, GI7_PF>{}, I8_{}));
+  else GI_TRY(launch(std::integral_constant<int, GI7_NSTG>{}, std::integral_constant<int, GI7_PF>{}, I4_{}));
 #endif
   { static const char* nm[8] = {"igemm7<0,128>", "igemm7<1,128>", "igemm7<0,64>", "igemm7<1,64>",
                                 "igemm7<0,128>+bn", "igemm7<1,128>+bn", "igemm7<0,64>+bn", "igemm7<1,64>+bn"}; gi_note_kernel(nm[vi + (fold ? 4 : 0)]); }

@@ -79,7 +79,9 @@ int gi_version(void);
  *   GI_C1W_FUSE [1]       0: the weight gradient of the first (single-channel) layer as its own launch reading the gradient at the
  *                         layer's output from memory, instead of from the tiles of the second layer's input-gradient GEMM while they
  *                         are in LDS (that gradient is then not stored at all unless the network's input gradient is asked for).
- *                         Needs GI_MASK_BITS = 1 */
+ *                         Needs GI_MASK_BITS = 1
+ *   GI_IGEMM7_WAVES [8]   4: the small-M ring kernel (igemm7) as four-wave workgroups (one wave per SIMD, 64 x BN/2 wave tiles)
+ *                         instead of eight-wave ones (two per SIMD); sums agree to fp32 rounding */
 int gi_set_option(const char* name, int value);
 int gi_get_option(const char* name, int* value);
 /* name of the GEMM / weight-gradient kernel family and instantiation launched most recently by this process, e.g.
