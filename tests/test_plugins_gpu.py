@@ -43,7 +43,9 @@ def test_plugin_runs_and_checkpoints(tmp_path, exp):
     if exp == "experiment1_global_local_D":
         with open(os.path.join(str(tmp_path), "model", exp, "training_epoch_history.obj"), "rb") as h:
             hist = pickle.load(h)
-        assert 0.0 < hist[-1]["losses"]["ssim"] <= 1.0                      # experiment1_global_local_D.py:209
+        # experiment1_global_local_D.py:209 logs the mean SSIM of the epoch; after four batches on random images it is ~0 with either
+        # sign (measured -2e-4 .. +1e-2 across builds that differ in fp32 summation order): only its range is a property
+        assert -1.0 <= hist[-1]["losses"]["ssim"] <= 1.0 and abs(hist[-1]["losses"]["ssim"]) > 0.0
 
 
 def test_real_data_layout_through_the_device_transform(tmp_path):
