@@ -205,7 +205,8 @@ class _StepBase:
         B.check(lib.gi_net_backward_phase(G._handle, gtok[0], B.ptr(dy), None, 1, 4))
         self.sync.launch(flat, 0, split2)       # awaited by _step(optG)
 
-    def _d_pair(self, net, real, fake, kind, t_real, t_fake, name_real, name_fake, gs_real=1.0, gs_fake=1.0, synced=False, x2=None):
+    def _d_pair(self, net, real, fake, kind, t_real, t_fake, name_real, name_fake, gs_real=1.0, gs_fake=1.0, synced=False, x2=None,
+                real_done=False):
         """A discriminator's two calls of a batch, D(real) and D(fake), as ONE [real | fake] batch whose BatchNorm
         layers are evaluated per half (gi_net_set_bn_groups): per image the reference's arithmetic, half the
         launches, one weight-gradient GEMM over both halves. Losses go to L[name_*], gradients accumulate."""
@@ -218,7 +219,8 @@ class _StepBase:
         own, dp2 = bufs[key]
         if x2 is None:
             x2 = own
-        x2[:n].copy_(real)
+        if not real_done:                             # (the caller may have copied the real half already, ahead of a wait)
+            x2[:n].copy_(real)
         if fake.data_ptr() != x2[n:].data_ptr():      # the caller may have produced `fake` in the pair buffer already
             x2[n:].copy_(fake)
         p, t = self._fwd(net, x2, bn_groups=2)
@@ -361,8 +363,9 @@ class WGANStep(_StepBase):
                 sD.wait_event(e0)
             self.optD.zero_grad()
             if self.stacked:
+                self._inp2[k][:ground.shape[0]].copy_(ground)   # the real half of the pair: before the wait for the inpainted one
                 sD.wait_event(e_inp)
-                self._critic_stacked(ground, inp, x2=self._inp2[k])
+                self._critic_stacked(ground, inp, x2=self._inp2[k], real_done=True)
             else:
                 pr, tr = self._fwd(self.D, ground)
                 o.adv(pr, MEAN, 0.0, self._loss("d_loss_real"), self.dpred, +1.0)
@@ -384,10 +387,13 @@ class WGANStep(_StepBase):
                 d_adv = self._bwd(self.D, t, self.dpred, True, False)
             self._evD[k] = sD.record_event()
         if update_g:
+            # before the wait - the main stream has nothing else to do while the critic runs: clearing the generator's gradients
+            # and every loss term that depends on (inpainted, ground) only, i.e. all but the adversarial one
+            self.optG.zero_grad()
+            g_other = self._g_losses(inp, ground)
             main.wait_event(self._evD[k])
             d_adv.record_stream(main)
-            self.optG.zero_grad()
-            o.add(d_adv, self._g_losses(inp, ground), self.tmp1)
+            o.add(d_adv, g_other, self.tmp1)
             o.mul(self.tmp1, self.mask_c, self.g_gen)
             self._bwd_G(gtok, self.g_gen)
             self._step(self.optG)
@@ -441,11 +447,12 @@ class WGANStep(_StepBase):
             self._step(self.optG)
         return self.L
 
-    def _critic_stacked(self, ground, inp, x2=None):
+    def _critic_stacked(self, ground, inp, x2=None, real_done=False):
         """D(ground) and D(inpainted) of wgan_l1.py:134-141 as one [ground | inpainted] batch, BatchNorm per half;
         backward(one) / backward(mone) are the gradient scales +1 / -1."""
         synced = self.sync is not None and self.sync.world > 1 and self.gp_lambda <= 0
-        self._d_pair(self.D, ground, inp, MEAN, 0.0, 0.0, "d_loss_real", "d_loss_fake", +1.0, -1.0, synced=synced, x2=x2)
+        self._d_pair(self.D, ground, inp, MEAN, 0.0, 0.0, "d_loss_real", "d_loss_fake", +1.0, -1.0, synced=synced, x2=x2,
+                     real_done=real_done)
         self._d_synced = synced   # the all-reduce already overlapped the tail of the backward
 
     def _g_losses(self, inp, ground):
