@@ -7,6 +7,7 @@
 // These layers carry <1% of the FLOPs and ~45% of the activation bytes, so they are written as
 // vectorised streaming kernels (16-byte feature accesses, weights in registers/LDS), not GEMMs.
 #include "common.h"
+#include "stat_acc.h"
 #include "bn_acc.h"
 
 namespace {
@@ -1307,7 +1308,7 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
                                                           float* __restrict__ dwl, float* __restrict__ dbl, int n, int Hh,
                                                           int Wh, int bands, int sigmoid, float loss_scale,
                                                           const float* __restrict__ sc4, const float* __restrict__ sh4,
-                                                          int n_per_group, int gstride) {
+                                                          int n_per_group, int gstride, HeadBwdFuse hf) {
   __shared__ float red[2 * 16 * 512];   // 64 KiB: two waves' accumulators at a time
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1337,21 +1338,67 @@ __global__ void __launch_bounds__(256) head_bwd512_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 4; ++e) { w[tap][e] = lo[e]; w[tap][4 + e] = hi[e]; }
     }
-    for (int q = q0 + wave; q < q1; q += 4) {
-      const int y = q / Wh, x = q - y * Wh;
-      const float* gq = gp + (y + 3) * GW + x + 3;
-      float g[16];
+    // hf.acc != null: the BatchNorm-backward sums of the layer in front (HeadBwdArgs::bwd_*) from the gradient this block produces -
+    // the rounded value it stores, as the separate reduction would read it back - and the layer's raw output x, four pixels' rows
+    // of x requested ahead per wave
+    const bool bw = hf.acc != nullptr;
+    float bsc[8], bsh[8], bmu[8], biv[8], bs[8], bsx[8];
+    if (bw) {
+      const int go = (nn / hf.n_per_group) * hf.stride + lane * 8;
 #pragma unroll
-      for (int tap = 0; tap < 16; ++tap) g[tap] = gq[-(tap >> 2) * GW - (tap & 3)];   // LDS broadcast reads
-      float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 8; ++e) { bsc[e] = hf.scale[go + e]; bsh[e] = hf.shift[go + e]; bmu[e] = hf.mean[go + e]; biv[e] = hf.inv[go + e]; bs[e] = bsx[e] = 0.f; }
+    }
+    const char* xrow = hf.x + (int64_t)nn * npx * 1024 + lane * 16;
+    for (int qb = q0 + wave; qb < q1; qb += 16) {
+      h8_t xs[4];
+      if (bw) {
 #pragma unroll
-      for (int tap = 0; tap < 16; ++tap)
+        for (int j = 0; j < 4; ++j) xs[j] = *(const h8_t*)(xrow + (int64_t)min(qb + 4 * j, npx - 1) * 1024);
+      }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) sacc[e] = fmaf(g[tap], w[tap][e], sacc[e]);
-      h8_t v;
+      for (int j = 0; j < 4; ++j) {
+        const int q = qb + 4 * j;
+        if (q < q1) {                              // wave-uniform
+          const int y = q / Wh, x = q - y * Wh;
+          const float* gq = gp + (y + 3) * GW + x + 3;
+          float g[16];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (half_t)sacc[e];
-      *(h8_t*)(da4 + ((int64_t)nn * npx + q) * 1024 + lane * 16) = v;
+          for (int tap = 0; tap < 16; ++tap) g[tap] = gq[-(tap >> 2) * GW - (tap & 3)];   // LDS broadcast reads
+          float sacc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int tap = 0; tap < 16; ++tap)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sacc[e] = fmaf(g[tap], w[tap][e], sacc[e]);
+          h8_t v;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (half_t)sacc[e];
+          *(h8_t*)(da4 + ((int64_t)nn * npx + q) * 1024 + lane * 16) = v;
+          if (bw) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float xf = (float)xs[j][e];
+              const float dz = (float)v[e] * (fmaf(xf, bsc[e], bsh[e]) > 0.f ? 1.f : hf.slope);
+              bs[e] += dz;
+              bsx[e] = fmaf(dz, (xf - bmu[e]) * biv[e], bsx[e]);
+            }
+          }
+        }
+      }
+    }
+    if (bw) {     // the four waves' sums through LDS (gp is done with), then one exact add per channel and quantity
+      __syncthreads();
+      float* fold = red;   // [4 waves][512][2]
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { fold[(wave * 512 + lane * 8 + e) * 2] = bs[e]; fold[(wave * 512 + lane * 8 + e) * 2 + 1] = bsx[e]; }
+      __syncthreads();
+      const int grp = nn / hf.n_per_group, rep = b & (hf.reps - 1);
+      for (int ch = threadIdx.x; ch < 512; ch += 256) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) { s0 += fold[(wv * 512 + ch) * 2]; s1 += fold[(wv * 512 + ch) * 2 + 1]; }
+        gi_stat_add(hf.acc, 512, rep, grp, 0, ch, s0);
+        gi_stat_add(hf.acc, 512, rep, grp, 1, ch, s1);
+      }
     }
     return;
   }
@@ -1750,12 +1797,17 @@ int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a) {
   if (dtype == GI_F16 && a.c == 512 && head_fast()) {
     const int bands = head_bands(a.n, a.Hh * a.Wh), nb = a.n * bands;
     const bool wg = a.dw5 != nullptr;
+    HeadBwdFuse hf;
+    hf.x = (const char*)a.bwd_x; hf.scale = a.bwd_scale; hf.shift = a.bwd_shift; hf.mean = a.bwd_mean; hf.inv = a.bwd_inv;
+    hf.stride = a.bwd_stride; hf.n_per_group = a.bwd_n_per_group > 0 ? a.bwd_n_per_group : a.n; hf.reps = a.bwd_reps > 0 ? a.bwd_reps : 1;
+    hf.slope = a.bwd_slope; hf.acc = (a.bwd_acc && a.bwd_x) ? a.bwd_acc : nullptr;
     if (!wg || (a.scratch && a.scratch_bytes >= (int64_t)nb * 8192 * 4)) {
       GI_REQUIRE(!wg || a.dwl, "head: dw5 without dwl");
       hipLaunchKernelGGL(head_bwd512_kernel, dim3(wg ? 2 * nb : nb), dim3(256), 0, st, a.dy, a.out, a.h, a.wl, a.w5, (const char*)a.a4,
                          (char*)a.da4, a.scratch, a.dwl, a.dbl, a.n, a.Hh, a.Wh, bands, a.sigmoid, a.loss_scale,
-                         a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride);
+                         a.scale4, a.shift4, a.n_per_group > 0 ? a.n_per_group : a.n, a.gstride, hf);
       GI_LAUNCH_CHECK();
+      if (hf.acc && a.bwd_applied) *a.bwd_applied = 1;
       if (wg) {
         hipLaunchKernelGGL(head_wsum512_kernel, dim3(256 + P + 1), dim3(256), 0, st, a.scratch, nb, a.dw5, a.dy, a.out, a.h, a.dwl, a.dbl, a.n, P, a.sigmoid);
         GI_LAUNCH_CHECK();

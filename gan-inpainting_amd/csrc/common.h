@@ -417,6 +417,21 @@ struct HeadBwdArgs {
   float loss_scale;
   float* scratch = nullptr; int64_t scratch_bytes = 0;   // weight-gradient partials (op_head_scratch_bytes)
   const float* scale4 = nullptr; const float* shift4 = nullptr; int n_per_group = 0, gstride = 0;   // as in HeadArgs
+  // BatchNorm-backward reduction of the layer in front of the head (conv4), fused into the input-gradient blocks: with x = bwd_x (the
+  // layer's raw output, dense, c channels), dz = da4 * (fma(x, scale, shift) > 0 ? 1 : bwd_slope), xhat = (x - mean) * inv, every
+  // block adds sum dz and sum dz * xhat per channel to the exact accumulators bwd_acc (stat_acc.h; population of image nn =
+  // nn / bwd_n_per_group, vectors bwd_stride floats apart). *bwd_applied = 1 when the kernel did it.
+  const void* bwd_x = nullptr;
+  const float* bwd_scale = nullptr; const float* bwd_shift = nullptr; const float* bwd_mean = nullptr; const float* bwd_inv = nullptr;
+  int bwd_stride = 0, bwd_n_per_group = 0, bwd_reps = 1; float bwd_slope = 1.f;
+  unsigned long long* bwd_acc = nullptr;
+  int* bwd_applied = nullptr;
+};
+// (kernel argument of the fused reduction)
+struct HeadBwdFuse {
+  const char* x; const float* scale; const float* shift; const float* mean; const float* inv;
+  int stride, n_per_group, reps; float slope;
+  unsigned long long* acc;
 };
 int64_t op_head_scratch_bytes(int max_n, int Hh, int Wh);
 int op_head_backward(hipStream_t st, int dtype, const HeadBwdArgs& a);

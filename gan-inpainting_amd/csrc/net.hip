@@ -1641,7 +1641,17 @@ int patchgan_backward(gi_net* net, int s, const float* dy, float* dx, int need_w
       if (pend.planned) GI_HIP(hipMemsetAsync(pend.acc, 0, (size_t)net->dbn[i].acc_block() * 8, st));
       pend = BwdFuse();
     }
+    // conv4's BatchNorm-backward sums ride in the head's input-gradient blocks (HeadBwdArgs::bwd_*): no reduce launch
+    BwdFuse& p4 = net->bwd_pending[net->dbn[4].id];
+    int head_bw = 0;
+    p4 = bwd_fuse_plan(net, s, net->dbn[4], net->slot(s, net->oRd[4]), (int64_t)n * net->Hh * net->Wh, (int64_t)n * 4, 0.2f);
+    if (p4.planned) {
+      hb.bwd_x = p4.x; hb.bwd_scale = p4.scale; hb.bwd_shift = p4.shift; hb.bwd_mean = p4.mean; hb.bwd_inv = p4.inv;
+      hb.bwd_stride = p4.stride; hb.bwd_n_per_group = n / (p4.groups > 0 ? p4.groups : 1); hb.bwd_reps = p4.reps_gemm; hb.bwd_slope = p4.slope;
+      hb.bwd_acc = p4.acc; hb.bwd_applied = &head_bw;
+    }
     GI_TRY(op_head_backward(st, dt, hb));
+    p4.applied = head_bw != 0;
   }
   int lrelu1_done = 0;
   C1WFuse c1w;
