@@ -235,9 +235,11 @@ struct IgemmArgs {
   // every tile adds sum dz and sum dz * xhat, dz = g * (fma(x, scale, shift) > 0 ? 1 : slope), xhat = (x - mean) * inv, to the
   // accumulator block bwd_acc (quantities 0 / 1, stat_acc.h; replicas / populations as stat_reps / stat_pg, here counted in
   // OUTPUT pixels). Kernels that implement it set bwd_applied = 1: the caller then skips the reduce pass of op_act_bn_bwd.
+  // bwd_c > 0: only the output columns [bwd_c0, bwd_c0 + bwd_c) carry that gradient (the decoder half of a U-Net concat gradient;
+  // bwd_c0 a multiple of 128): x, the vectors and the accumulators are indexed by column - bwd_c0 and hold bwd_c channels
   const void* bwd_x; int bwd_ldx;
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
-  float bwd_slope;
+  float bwd_slope; int bwd_c0, bwd_c;
   unsigned long long* bwd_acc; int bwd_reps; int64_t bwd_pg;
   int bwd_applied;
   // mode 2 (3x3 / s1) only: store the 2x2 / stride-2 max pool of the activated output instead of the output itself (`out` is then the

@@ -27,6 +27,7 @@ struct KP5 {
   const char* bwd_x; int bwd_ldx;
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
   float bwd_slope;
+  int bwd_c0, bwd_c;   // IgemmArgs::bwd_c0 / bwd_c (igemm8 only; igemm6: 0 / cout)
   unsigned long long* bwd_acc; int bwd_reps; int bwd_pg_tiles;   // bwd_pg_tiles: M tiles per BatchNorm population (0: one population)
   int pool;           // MODE 2: the epilogue stores the 2x2 max pool of the tile (IgemmArgs::pool2)
   int dbg_epi;        // builds with -DGI_ABLATION only (GI_EPI_DBG): 1 = all tiles store into one 64 KiB window (no HBM write burst)

@@ -780,17 +780,7 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
 #ifdef GI_ABLATION
   { const char* e = getenv("GI_EPI_DBG"); if (e) kp.dbg_epi = atoi(e); }
 #endif
-  kp.bwd_acc = nullptr;
-  if (a.bwd_acc && !a.mask && mode != 2 && a.cout % 128 == 0 && BN == 128) {   // (the dual-px / 64-column tiles do not take it; nor a launch with a mask)
-    const int64_t px_per_tile = 256 * (mode == 1 ? 4 : 1);          // output pixels per M tile over all phases
-    GI_REQUIRE(a.bwd_ldx % 8 == 0 && out_px * a.bwd_ldx < (1ll << 31) && (a.bwd_pg == 0 || a.bwd_pg % px_per_tile == 0) && a.coffout == 0,
-               "igemm5: fused BatchNorm-backward reduction: layout");
-    kp.bwd_x = (const char*)a.bwd_x; kp.bwd_ldx = a.bwd_ldx;
-    kp.bwd_scale = a.bwd_scale; kp.bwd_shift = a.bwd_shift; kp.bwd_mean = a.bwd_mean; kp.bwd_inv = a.bwd_inv; kp.bwd_stride = a.bwd_stride;
-    kp.bwd_slope = a.bwd_slope; kp.bwd_acc = a.bwd_acc; kp.bwd_reps = a.bwd_reps > 0 ? a.bwd_reps : 1;
-    kp.bwd_pg_tiles = a.bwd_pg > 0 ? (int)(a.bwd_pg / px_per_tile) : 0;
-    a.bwd_applied = 1;
-  }
+  kp.bwd_acc = nullptr; kp.bwd_c0 = 0; kp.bwd_c = a.cout;
   if (a.mask) {
     GI_REQUIRE(a.ldmask % 8 == 0 && a.coffmask % 8 == 0 && out_px * a.ldmask < (1ll << 31), "igemm5: mask layout");
     GI_REQUIRE(!a.add || (a.ldadd % 8 == 0 && a.coffadd % 8 == 0 && out_px * a.ldadd < (1ll << 31)), "igemm5: add layout");
@@ -811,9 +801,23 @@ int op_igemm5(hipStream_t st, int mode, IgemmArgs& a) {
   // GI_IGEMM6=0 (the first-generation halo kernels: no buffer-descriptor LDS-DMA anywhere) switches igemm8 off as well
   const int use8 = gi_opt(GI_OPT_IGEMM6) ? gi_opt(GI_OPT_IGEMM8) : 0;
   // (the 3x3 mode: 128-column tiles on 32-wide patches, no fused input ReLU; VGG-19 from conv2_1 to conv4_4)
-  if (use8 && (mode != 2 || (TW == 32 && !a.relu_in)) && (dual || BN == 128 || mode == 2) && a.cin % (mode == 0 ? 64 : 32) == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
+  const bool take8 = use8 && (mode != 2 || (TW == 32 && !a.relu_in)) && (dual || BN == 128 || mode == 2) && a.cin % (mode == 0 ? 64 : 32) == 0 && TW >= 16 && in_px * a.ldin * 2 < (1ll << 31) &&
       (int64_t)a.cout * (mode == 1 ? 4 : (mode == 2 ? 9 : 16)) * a.cin * 2 * (dual ? 2 : 1) < (1ll << 31) && !(mode == 0 && a.relu_in) &&
-      (use8 >= 2 || grid >= gi_tune("GI_IGEMM8_MINGRID", 512))) {
+      (use8 >= 2 || grid >= gi_tune("GI_IGEMM8_MINGRID", 512));
+  // fused BatchNorm-backward reduction (the dual-px / 64-column tiles do not take it; nor a launch with a mask; a column range only igemm8)
+  const bool bwd_range = a.bwd_c > 0 && (a.bwd_c0 != 0 || a.bwd_c != a.cout);
+  if (a.bwd_acc && !a.mask && mode != 2 && a.cout % 128 == 0 && BN == 128 && (!bwd_range || (take8 && a.bwd_c0 % 128 == 0 && a.bwd_c % 128 == 0 && a.bwd_c0 + a.bwd_c <= a.cout))) {
+    const int64_t px_per_tile = 256 * (mode == 1 ? 4 : 1);          // output pixels per M tile over all phases
+    GI_REQUIRE(a.bwd_ldx % 8 == 0 && out_px * a.bwd_ldx < (1ll << 31) && (a.bwd_pg == 0 || a.bwd_pg % px_per_tile == 0) && a.coffout == 0,
+               "igemm5: fused BatchNorm-backward reduction: layout");
+    kp.bwd_x = (const char*)a.bwd_x; kp.bwd_ldx = a.bwd_ldx;
+    kp.bwd_scale = a.bwd_scale; kp.bwd_shift = a.bwd_shift; kp.bwd_mean = a.bwd_mean; kp.bwd_inv = a.bwd_inv; kp.bwd_stride = a.bwd_stride;
+    kp.bwd_slope = a.bwd_slope; kp.bwd_acc = a.bwd_acc; kp.bwd_reps = a.bwd_reps > 0 ? a.bwd_reps : 1;
+    kp.bwd_pg_tiles = a.bwd_pg > 0 ? (int)(a.bwd_pg / px_per_tile) : 0;
+    if (bwd_range) { kp.bwd_c0 = a.bwd_c0; kp.bwd_c = a.bwd_c; }
+    a.bwd_applied = 1;
+  }
+  if (take8) {
     if (mode == 2 && a.pool2 && !a.mask && !a.stat_acc && !a.partials) {   // the pooled store: igemm8's 3x3 mode only
       GI_REQUIRE(a.coffout == 0 && (int64_t)a.n * (a.Hs / 2) * (a.Ws / 2) * a.ldout < (1ll << 31), "igemm8: pooled output layout");
       kp.pool = 1;

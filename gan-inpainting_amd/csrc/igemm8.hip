@@ -181,13 +181,14 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
   }
   constexpr int CPRO = BN / 8;          // 16-byte chunks per row
   const int oc = tid % CPRO;
-  const bool bwd = !DUAL && p.bwd_acc != nullptr;
+  const bool bwd = !DUAL && p.bwd_acc != nullptr && n0 >= p.bwd_c0 && n0 < p.bwd_c0 + p.bwd_c;   // (this N tile lies in the column range)
+  const int bn0 = n0 - p.bwd_c0;   // the tile's first channel of the BatchNorm layer
   float bsc[8], bsh[8], bmu[8], biv[8], bs[8], bsx[8];
   if (bwd) {
     const int go = (p.bwd_pg_tiles > 0 && mt_idx >= p.bwd_pg_tiles) ? p.bwd_stride : 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const int ch = go + n0 + oc * 8 + e;
+      const int ch = go + bn0 + oc * 8 + e;
       bsc[e] = p.bwd_scale[ch]; bsh[e] = p.bwd_shift[ch]; bmu[e] = p.bwd_mean[ch]; biv[e] = p.bwd_inv[ch];
       bs[e] = bsx[e] = 0.f;
     }
@@ -261,7 +262,7 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
           opxs[k] = out_pixel(tid / CPRO + (h * NB + k) * RP);
-          xs[k] = *(const u4_t*)(p.bwd_x + ((int64_t)opxs[k] * p.bwd_ldx + och) * 2);
+          xs[k] = *(const u4_t*)(p.bwd_x + ((int64_t)opxs[k] * p.bwd_ldx + och - p.bwd_c0) * 2);
         }
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
@@ -301,7 +302,7 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
       if (BITS && p.mask_bits) {}
       else if (p.mask) mk[k] = *(const u4_t*)(p.mask + (opx * p.ldmask + p.coffmask + och) * 2);
       if (!(BITS && p.mask_bits) && p.mask && p.add) ad[k] = *(const u4_t*)(p.add + (opx * p.ldadd + p.coffadd + och) * 2);
-      if (bwd) xs[k] = *(const u4_t*)(p.bwd_x + (opx * p.bwd_ldx + och) * 2);
+      if (bwd) xs[k] = *(const u4_t*)(p.bwd_x + (opx * p.bwd_ldx + och - p.bwd_c0) * 2);
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -408,8 +409,8 @@ __device__ __forceinline__ void epilogue8(const KP5& p, f4_t (&acc)[4][BN / 16],
 #pragma unroll
       for (int w = 0; w < 4; ++w) { s += fold[(w * BN + tid) * 2]; q += fold[(w * BN + tid) * 2 + 1]; }
       const int grp = (p.bwd_pg_tiles > 0 && mt_idx >= p.bwd_pg_tiles) ? 1 : 0, rep = (mt_idx + (MODE == 1 ? ph : 0)) & (p.bwd_reps - 1);
-      gi_stat_add(p.bwd_acc, p.cout, rep, grp, 0, n0 + tid, s);
-      gi_stat_add(p.bwd_acc, p.cout, rep, grp, 1, n0 + tid, q);
+      gi_stat_add(p.bwd_acc, p.bwd_c, rep, grp, 0, bn0 + tid, s);
+      gi_stat_add(p.bwd_acc, p.bwd_c, rep, grp, 1, bn0 + tid, q);
     }
   }
 }

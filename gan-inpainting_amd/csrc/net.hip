@@ -53,6 +53,7 @@ struct BwdFuse {
   const void* x = nullptr; int ldx = 0;
   const float* scale = nullptr; const float* shift = nullptr; const float* mean = nullptr; const float* inv = nullptr;
   int stride = 0; float slope = 1.f; int64_t pg = 0;
+  int c0 = 0, c = 0;   // IgemmArgs::bwd_c0 / bwd_c (0: all output columns)
 };
 
 struct Arena {
@@ -807,6 +808,7 @@ int igemm(gi_net* net, int phase, const void* in, int cin, int ldin, int coffin,
   if (bf && bf->planned) {
     a.bwd_x = bf->x; a.bwd_ldx = bf->ldx; a.bwd_scale = bf->scale; a.bwd_shift = bf->shift; a.bwd_mean = bf->mean; a.bwd_inv = bf->inv;
     a.bwd_stride = bf->stride; a.bwd_slope = bf->slope; a.bwd_acc = bf->acc; a.bwd_reps = bf->reps_gemm; a.bwd_pg = bf->pg;
+    a.bwd_c0 = bf->c0; a.bwd_c = bf->c;
   }
   a.relu_cend = relu_cend;
   a.mask = mask; a.ldmask = ldmask; a.coffmask = 0; a.mask_slope = mask_slope;
@@ -1297,21 +1299,40 @@ int unet_backward(gi_net* net, int s, const float* dy, float* dx, int need_wgrad
     GI_TRY(igemm(net, 0, U1, 64, 64, 0, wp, gC(1), c1, c1, 0, n, net->Hk[1], net->Wk[1], 0, GI_ACT_NONE, false, nullptr));
   }
   // decoder, outermost -> innermost: level k's concat gradient feeds up[k+1]
+  // a reduction planned by an earlier, abandoned backward left sums in its accumulator block
+  for (int k = 2; k <= nd; ++k) {
+    if (net->unorm[k].c == 0 || net->unorm[k].id < 0) continue;
+    BwdFuse& pend = net->bwd_pending[net->unorm[k].id];
+    if (pend.planned) GI_HIP(hipMemsetAsync(pend.acc, 0, (size_t)net->unorm[k].acc_block() * 8, st));
+    pend = BwdFuse();
+  }
   for (int k = 1; k <= nd - 1; ++k) {
     const int kk = k + 1;
     const int ck = net->ch[k];
     const int64_t pix = (int64_t)n * net->Hk[k] * net->Wk[k];
     const float ds = (!evalbn && net->dropout_p > 0.f && kk >= 5 && kk <= nd - 1) ? 1.f / (1.f - net->dropout_p) : 1.f;
     D = side_dz(net);
+    BwdFuse& pend = net->bwd_pending[net->unorm[kk].id];
     GI_TRY(act_bn_bwd(net, s, nullptr, 0, 0, gC(k), 2 * ck, ck, C(k), 2 * ck, ck, net->slot(s, net->oU[kk]), D, pix, ck,
-                      GI_ACT_NONE, ds, &net->unorm[kk], need_wgrad));
+                      GI_ACT_NONE, ds, &net->unorm[kk], need_wgrad, pend.planned ? &pend : nullptr));
+    pend = BwdFuse();
     const void* Sin = (kk == nd) ? (const void*)net->slot(s, net->oE) : C(kk);
     const int ca = net->up[kk].ca;
     if (need_wgrad)
       GI_TRY(wgrad(net, Sin, ca, ca, 0, kk < nd ? 1 : 0, D, ck, ck, 0, n, net->Hk[kk], net->Wk[kk], net->grads + net->up[kk].w_off));
     void* gout = (kk == nd) ? (void*)net->shared(net->ogE) : gC(kk);
+    // the upper half of this GEMM's columns is the gradient at the output of the NEXT decoder level's BatchNorm (its ReLU is the
+    // consumer's): that layer's backward reduction rides in the epilogue (IgemmArgs::bwd_c0; levels without dropout, kernels that take it)
+    BwdFuse* pbf = nullptr;
+    const int kn = kk + 1;
+    if (kk <= nd - 1 && !(net->dropout_p > 0.f && !evalbn && kn >= 5 && kn <= nd - 1)) {
+      const int64_t pixn = (int64_t)n * net->Hk[kk] * net->Wk[kk];
+      pbf = &net->bwd_pending[net->unorm[kn].id];
+      *pbf = bwd_fuse_plan(net, s, net->unorm[kn], net->slot(s, net->oU[kn]), pixn, pixn / 256, 0.f);
+      pbf->c0 = ca / 2; pbf->c = ca / 2;
+    }
     GI_TRY(igemm(net, 0, D, ck, ck, 0, packed_ptr(net, net->up[kk]), gout, ca, ca, 0, n, net->Hk[kk], net->Wk[kk], 0, GI_ACT_NONE,
-                 false, nullptr));
+                 false, nullptr, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, nullptr, nullptr, pbf));
   }
   }  // decoder half
   if (phase == 1) return GI_OK;
