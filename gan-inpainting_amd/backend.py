@@ -137,6 +137,7 @@ class IgemmEx(C.Structure):
                 ("bwd_x", _vp), ("bwd_ldx", _i),
                 ("bwd_scale", _vp), ("bwd_shift", _vp), ("bwd_mean", _vp), ("bwd_inv", _vp), ("bwd_stride", _i),
                 ("bwd_slope", _f), ("bwd_acc", _vp), ("bwd_reps", _i), ("bwd_pg", _i64),
+                ("bwd_c0", _i), ("bwd_c", _i),
                 ("mask_applied", _i), ("bwd_applied", _i), ("stat_used", _i), ("ntiles_out", _i)]
 
 

@@ -149,6 +149,7 @@ static int apply_ex(IgemmArgs& a, const gi_igemm_ex* ex) {
   a.bwd_x = ex->bwd_x; a.bwd_ldx = ex->bwd_ldx; a.bwd_scale = ex->bwd_scale; a.bwd_shift = ex->bwd_shift; a.bwd_mean = ex->bwd_mean;
   a.bwd_inv = ex->bwd_inv; a.bwd_stride = ex->bwd_stride; a.bwd_slope = ex->bwd_slope; a.bwd_acc = ex->bwd_acc; a.bwd_reps = ex->bwd_reps;
   a.bwd_pg = ex->bwd_pg;
+  a.bwd_c0 = ex->bwd_c0; a.bwd_c = ex->bwd_c;
   return GI_OK;
 }
 static void return_ex(const IgemmArgs& a, gi_igemm_ex* ex) {

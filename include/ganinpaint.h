@@ -404,6 +404,10 @@ typedef struct gi_igemm_ex {
   const void* bwd_x; int bwd_ldx;
   const float* bwd_scale; const float* bwd_shift; const float* bwd_mean; const float* bwd_inv; int bwd_stride;
   float bwd_slope; unsigned long long* bwd_acc; int bwd_reps; int64_t bwd_pg;
+  /* bwd_c > 0: only the output columns [bwd_c0, bwd_c0 + bwd_c) carry that gradient (multiples of 128; the decoder half of a U-Net
+   * concat gradient): bwd_x, the vectors and bwd_acc hold bwd_c channels, indexed by column - bwd_c0. Taken by the kernels that
+   * serve layers of >= 512 workgroups; otherwise bwd_applied stays 0 */
+  int bwd_c0, bwd_c;
   int mask_applied, bwd_applied, stat_used, ntiles_out;   /* (returned) */
 } gi_igemm_ex;
 int gi_conv_s2_forward_ex(gi_ctx* ctx, int dtype, const void* in, const void* w_packed, void* out,

@@ -256,6 +256,54 @@ def test_critic_dgrad_with_fused_batchnorm_backward_reduction(layer, family):
         assert err <= 2e-4, f"critic {layer} population {p}: fused BatchNorm-backward sums off by {err:.2e} of sum|dz|"
 
 
+@pytest.mark.parametrize("case", [("u2 dgrad", 32, 128, 64, 256), ("u3 dgrad", 32, 64, 128, 512)], ids=["u2 dgrad", "u3 dgrad"])
+def test_decoder_dgrad_with_batchnorm_backward_sums_in_the_upper_column_half(case, family):
+    """A decoder level's input gradient (the 4x4 / s2 gather on its ConvTranspose2d weights, csrc/net.hip unet_backward): the upper
+    half of the output columns is the gradient at the NEXT level's BatchNorm output, whose ReLU the consumer applies (networks.py:289
+    uprelu): the tiles of that column range add sum dz, sum dz * xhat, dz = g * [fma(x, scale, shift) > 0], to the exact accumulators
+    (gi_igemm_ex::bwd_c0 / bwd_c). Only the kernels that serve >= 512 workgroups take a column range; the others leave bwd_applied 0."""
+    name, n, HW, cin, cout = case
+    cb = cout // 2
+    Hs = HW // 2
+    x = quant(_rand((n, cb, Hs, Hs), 71, 2.0), F16)                  # the next level's raw decoder output
+    st = torch.rand((4, cb), generator=torch.Generator().manual_seed(72)) + 0.5     # [scale|shift|mean|inv][c]
+    st[1] -= 1.0
+    st[2] -= 1.0
+    std = st.cuda().contiguous()
+    xd = nhwc_dev(x, F16)
+    acc = _acc(cb)
+    ex = B.IgemmEx()
+    ex.bwd_x = B.ptr(xd); ex.bwd_ldx = cb                            # noqa: E702
+    base = std.data_ptr()
+    ex.bwd_scale, ex.bwd_shift, ex.bwd_mean, ex.bwd_inv = base, base + 4 * cb, base + 8 * cb, base + 12 * cb
+    ex.bwd_stride = 4 * cb
+    ex.bwd_slope = 0.0
+    ex.bwd_acc = B.ptr(acc)
+    tiles = n * Hs * Hs // 256
+    ex.bwd_reps = 4 if tiles > 1024 else (2 if tiles > 256 else 1)
+    ex.bwd_c0, ex.bwd_c = cb, cb
+    out, g = _conv(n, HW, HW, cin, cout, seed=73, ex=ex)
+    wgs = n * Hs * Hs // 256 * (cout // 128)
+    kern = family("igemm6<0,128>", wgs)
+    assert B.last_kernel() == kern, (name, B.last_kernel(), kern)
+    ok, msg = report(f"{name} output gradient", from_nhwc(out), g, TOL)
+    assert ok, msg
+    if not kern.startswith("igemm8"):
+        assert ex.bwd_applied == 0, "only igemm8 takes a column range"
+        return
+    assert ex.bwd_applied == 1
+    gk = from_nhwc(out).double()[:, cb:]                             # the kernel reduces the fp16 gradient it stores
+    sc, sh, mu, inv = (st[i].view(1, cb, 1, 1) for i in range(4))
+    z = torch.addcmul(sh, x, sc)
+    dz = gk * (z > 0).double()
+    xhat = ((x - mu) * inv).double()
+    ref = torch.stack([dz.sum((0, 2, 3)), (dz * xhat).sum((0, 2, 3))])
+    scale = torch.stack([dz.abs().sum((0, 2, 3)), (dz * xhat).abs().sum((0, 2, 3))])
+    got = _read_acc(acc, cb, ex.bwd_reps, 0)
+    err = float(((got - ref).abs() / scale).max())
+    assert err <= 2e-4, f"{name}: BatchNorm-backward sums of the upper column half off by {err:.2e} of sum|dz|"
+
+
 # The generator's input gradients at n = 32 as unet_backward issues them (csrc/net.hip): a decoder level's is the 4x4 / s2 gather on
 # its ConvTranspose2d weights (u2: 64 -> 256 channels onto the 64x64 grid, u3, u4), an encoder level's the sub-pixel phases on its
 # Conv2d weights (d3: 256 -> 128 channels onto the 64x64 grid, d4); networks.py:285-309 builds the layers.
