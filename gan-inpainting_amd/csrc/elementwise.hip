@@ -1494,6 +1494,9 @@ int op_bn_apply_acc(hipStream_t st, int dtype, const void* x, void* y, int64_t p
              b.groups, (long long)b.count);
   // fewer, fatter blocks than the plain pass: every block derives the affine maps of all channels first
   int grid = nblocks(pixels * (c / epc), 8);
+  // at most the 1024 workgroups that are resident at once (126 VGPRs: four per CU): a second round would derive the affine maps again
+  // (the critic's conv2 pass at 64 images: 2048 -> 1024 workgroups, 35.5 -> 33.4 us)
+  if (grid > 1024) grid = 1024;
   const bool g2 = b.groups == 2;
   BnAccP fa;
   fill_acc_params(fa, b);
