@@ -1591,7 +1591,11 @@ int op_act_bn_bwd(hipStream_t st, int dtype, const ActBnBwdArgs& a) {
   }
   if (a.has_bn && a.acc) {
     // exact accumulators: reduce pass (train mode only) + apply pass, no sums launch in between
-    const int grid3 = nblocks(a.pixels * Q, gi_tune("GI_BWD_APPLY_CPT", 8));
+    // (at most 1024 workgroups: with 214 - 250 VGPRs two are resident per CU, and every round of workgroups reads the accumulators and
+    //  derives its coefficients again - the critic's conv2-level pass 38.5 -> 34.5 us; fewer, fatter workgroups on the smaller passes
+    //  measured slower)
+    int grid3 = nblocks(a.pixels * Q, gi_tune("GI_BWD_APPLY_CPT", 8));
+    if (grid3 > 1024) grid3 = 1024;
     const size_t lds = (size_t)groups * 5 * a.c * sizeof(float);
     if (!a.eval_bn) {
       GI_REQUIRE(groups == 1 || p.pg % p.rows_per_block == 0, "act_bn_bwd: %lld pixels per group not a multiple of %d rows",
