@@ -784,6 +784,19 @@ int op_igemm8_launch(hipStream_t st, int mode, bool dual, bool relu, int grid, c
 #undef GI_K8D
       GI_LAUNCH_CHECK();
       return GI_OK;
+    }
+    // the gather mode (stride-2 convolution: the critic's conv2, the generator's d2), GI_IGEMM8_DBG0
+    const char* e0 = getenv("GI_IGEMM8_DBG0"); const int dbg0 = e0 ? atoi(e0) : 0;
+    if (dbg0 && v == 0) {
+#define GI_K8D0(D_) do { GI_HIP(hipFuncSetAttribute((const void*)igemm8_kernel<0, false, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)); \
+      hipLaunchKernelGGL((igemm8_kernel<0, false, D_>), dim3(grid), dim3(256), LDS, st, kp); } while (0)
+      switch (dbg0) {
+        case 1: GI_K8D0(1); break; case 2: GI_K8D0(2); break; case 4: GI_K8D0(4); break; case 16: GI_K8D0(16); break; case 32: GI_K8D0(32); break;
+        case 5: GI_K8D0(5); break; case 7: GI_K8D0(7); break; default: GI_K8D0(39); break;
+      }
+#undef GI_K8D0
+      GI_LAUNCH_CHECK();
+      return GI_OK;
     } }
 #endif
   switch (v) {
